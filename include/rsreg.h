@@ -1,0 +1,268 @@
+/*
+ * rsreg.h — C ABI of the MI355X-native pairwise point-cloud registration engine.
+ *
+ * This is the drop-in boundary for the ICP / NDT pair-registration hot path of
+ * hyunminch/realsense-pointcloud.  The reference has no FFI of its own; the calls that
+ * cross this boundary are the PCL calls its three registration schemes make.  Every entry
+ * point below names the reference call site (file:line under the reference's src/) and
+ * the PCL method it stands in for.
+ *
+ * Conventions
+ *   - Points are handed over as an array of records `stride` bytes apart whose first 12
+ *     bytes are `float x, y, z` (pcl::PointXYZRGB: stride 32, rgb at byte 16).  Only xyz
+ *     is ever sent to the GPU; colour stays on the host (PCL's ICP/NDT ignore it too).
+ *   - 4x4 transforms are 16 floats, COLUMN-major (memcpy-compatible with Eigen::Matrix4f).
+ *   - Every function returns an rsreg_status (0 = ok, < 0 = error).  Nothing throws across
+ *     the ABI.  "Did not converge" is a successful call with result->converged == 0.
+ *   - A ctx is bound to one device + one HIP stream and is not thread-safe; different
+ *     ctxs are independent.  Host pointers are never retained after a call returns.
+ *   - *_device variants take pointers to memory already resident in HBM (same record
+ *     layout); the plain variants take host pointers and copy xyz up themselves.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point
+ *     returns RSREG_ERR_NO_DEVICE.
+ */
+#ifndef RSREG_H_
+#define RSREG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSREG_VERSION_MAJOR 0
+#define RSREG_VERSION_MINOR 1
+
+typedef struct rsreg_ctx rsreg_ctx;
+
+typedef enum rsreg_status {
+    RSREG_OK = 0,
+    RSREG_ERR_INVALID_ARG = -1,
+    RSREG_ERR_EMPTY_CLOUD = -2,
+    RSREG_ERR_HIP = -3,
+    RSREG_ERR_RCCL = -4,
+    RSREG_ERR_NO_TARGET = -5,
+    RSREG_ERR_NO_DEVICE = -6,
+    RSREG_ERR_ALLOC = -7,
+    RSREG_ERR_NO_SOURCE = -8,
+    RSREG_ERR_STATE = -9
+} rsreg_status;
+
+/* Mirrors pcl::registration::DefaultConvergenceCriteria::ConvergenceState (same order). */
+typedef enum rsreg_convergence_state {
+    RSREG_CONV_NOT_CONVERGED = 0,
+    RSREG_CONV_ITERATIONS = 1,
+    RSREG_CONV_TRANSFORM = 2,
+    RSREG_CONV_ABS_MSE = 3,
+    RSREG_CONV_REL_MSE = 4,
+    RSREG_CONV_NO_CORRESPONDENCES = 5,
+    RSREG_CONV_FAILURE_AFTER_MAX_ITERATIONS = 6
+} rsreg_convergence_state;
+
+/* How the iteration loop decides to stop. */
+typedef enum rsreg_criteria_mode {
+    RSREG_CRITERIA_PCL = 0,   /* pcl DefaultConvergenceCriteria (reference behaviour)      */
+    RSREG_CRITERIA_FIXED = 1  /* run exactly max_iterations iterations (benchmark mode)    */
+} rsreg_criteria_mode;
+
+/* Which kernels one ICP iteration is built from. Results are bit-identical across modes. */
+typedef enum rsreg_pipeline_mode {
+    RSREG_PIPELINE_STAGED = 0, /* nn_search -> cov_reduce -> transform_reject (3 kernels)   */
+    RSREG_PIPELINE_FUSED = 1   /* one fused transform+NN+reject+sums kernel per iteration  */
+} rsreg_pipeline_mode;
+
+/*
+ * ICP parameters = the setters the reference calls on pcl::IterativeClosestPoint
+ *   setMaximumIterations / setMaxCorrespondenceDistance / setTransformationEpsilon /
+ *   setEuclideanFitnessEpsilon — incremental_icp.hpp:46-49,
+ *   icp_edge_based_registration.hpp:42-45,49-52, ndt_edge_based_registration.hpp:47-50.
+ * rsreg_icp_params_default() fills PCL's defaults (10, sqrt(DBL_MAX), 0, 0, -DBL_MAX);
+ * rsreg_icp_params_reference() fills the reference's constants (100, 0.01, 1, 0, 1000).
+ */
+typedef struct rsreg_icp_params {
+    int32_t max_iterations;
+    int32_t criteria_mode;                   /* rsreg_criteria_mode */
+    int32_t pipeline_mode;                   /* rsreg_pipeline_mode */
+    int32_t reserved0;
+    double max_correspondence_distance;
+    double transformation_epsilon;
+    double transformation_rotation_epsilon;  /* <= 0: use 1 - transformation_epsilon (PCL) */
+    double euclidean_fitness_epsilon;
+} rsreg_icp_params;
+
+/*
+ * NDT parameters = the setters the reference calls on pcl::NormalDistributionsTransform
+ *   setTransformationEpsilon(0.01) / setStepSize(0.1) / setResolution(1.0) /
+ *   setMaximumIterations(50) — ndt_edge_based_registration.hpp:38-43.
+ */
+typedef struct rsreg_ndt_params {
+    int32_t max_iterations;
+    int32_t reserved0;
+    double transformation_epsilon;
+    double step_size;
+    double resolution;
+    double outlier_ratio;                    /* PCL default 0.55 */
+} rsreg_ndt_params;
+
+/* The 17 sums one ICP iteration reduces the correspondences to (all f64):
+ *   [0] n   [1..3] sum p   [4..6] sum q   [7..15] sum q_i * p_j (row-major i,j)   [16] sum d^2
+ * p = transformed source point, q = its matched target point; only pairs that pass the
+ * distance gate contribute.  These are what an N-GPU run all-reduces. */
+#define RSREG_NUM_SUMS 17
+
+typedef struct rsreg_icp_result {
+    float transform[16];        /* final_transformation_, column-major                      */
+    int32_t converged;          /* icp.hasConverged()                                       */
+    int32_t state;              /* rsreg_convergence_state                                  */
+    int32_t iterations;         /* nr_iterations_                                           */
+    int32_t reserved0;
+    uint64_t n_correspondences; /* pairs accepted in the last iteration                     */
+    double mse;                 /* mean squared distance of those pairs (last iteration)    */
+    double sums_last[RSREG_NUM_SUMS]; /* the 17 sums of the last iteration                  */
+    /* device-time breakdown of this call (ms, HIP events on the ctx stream); 0 if profiling off */
+    double ms_total;
+    double ms_nn;               /* dominant kernel: NN search (or the fused kernel)         */
+    double ms_reduce;
+    double ms_transform;
+    int32_t n_nn_launches;
+    int32_t reserved1;
+} rsreg_icp_result;
+
+typedef struct rsreg_ndt_result {
+    float transform[16];
+    int32_t converged;
+    int32_t iterations;
+    double trans_probability;   /* ndt.getTransformationProbability()                       */
+    double score;
+    int32_t n_voxels;           /* valid target voxels (>= 6 points, invertible covariance)  */
+    int32_t n_derivative_passes;
+    double ms_total;
+    double ms_derivatives;
+} rsreg_ndt_result;
+
+/* ---- library / device ------------------------------------------------------------ */
+int rsreg_version(void);                        /* major*1000 + minor */
+const char *rsreg_status_string(int status);
+const char *rsreg_last_error(const rsreg_ctx *ctx); /* detail of the last failure on ctx   */
+int rsreg_device_count(int *count);
+
+/* stream: a hipStream_t to run on (e.g. torch's current stream), or NULL for a new one. */
+int rsreg_ctx_create(int device_id, void *stream, rsreg_ctx **out);
+int rsreg_ctx_destroy(rsreg_ctx *ctx);
+int rsreg_ctx_synchronize(rsreg_ctx *ctx);
+int rsreg_ctx_set_profiling(rsreg_ctx *ctx, int enabled);
+
+void rsreg_icp_params_default(rsreg_icp_params *p);
+void rsreg_icp_params_reference(rsreg_icp_params *p);
+void rsreg_ndt_params_default(rsreg_ndt_params *p);
+void rsreg_ndt_params_reference(rsreg_ndt_params *p);
+
+/* ---- ICP: pcl::IterativeClosestPoint<PointXYZRGB,PointXYZRGB> ------------------------ */
+
+/* icp.setInputTarget(cloud) + the search-structure build PCL does in initCompute()
+ * (incremental_icp.hpp:58, icp_edge...hpp:79,109, ndt_edge...hpp:97).  Builds the
+ * uniform-grid index over the finite target points.  The grid cell size is derived from
+ * max_correspondence_distance, so that must be known here. */
+int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride,
+                         int is_dense, double max_correspondence_distance);
+int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,
+                                int is_dense, double max_correspondence_distance);
+
+/* icp.setInputSource(cloud) (incremental_icp.hpp:57, icp_edge...hpp:78,108). */
+int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense);
+int rsreg_icp_set_source_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,
+                                int is_dense);
+
+/* icp.align(out) / icp.align(out, guess) + hasConverged() + getFinalTransformation()
+ * (incremental_icp.hpp:59-63, icp_edge...hpp:95,104,111-117, ndt_edge...hpp:99-105).
+ * guess: 16 floats column-major, NULL = identity.  aligned_out (nullable, host): receives
+ * n_source records of `out_stride` bytes: the input records with xyz <- final * xyz
+ * (only xyz and, if out_stride >= 16, data[3] = 1 are written; copy colour yourself). */
+int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params,
+                    rsreg_icp_result *result, void *aligned_out, size_t out_stride);
+
+/* Step-wise form of the same loop (parity tests, N-GPU sharding by source blocks):
+ *   begin -> { search -> sums -> [all-reduce the 17 sums] -> update } ... -> end     */
+int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params);
+/* CorrespondenceEstimation::determineCorrespondences: nearest target per current source
+ * point.  Outputs (host, each nullable, n_source entries): index into the ORIGINAL target
+ * array (-1: no target within the gate / non-finite source point), squared distance. */
+int rsreg_icp_search(rsreg_ctx *ctx, int32_t *index_out, float *sqr_dist_out);
+/* The 17 sums over the accepted correspondences of the last search (this rank's block). */
+int rsreg_icp_sums(rsreg_ctx *ctx, double sums[RSREG_NUM_SUMS]);
+/* TransformationEstimationSVD (Umeyama) from (possibly all-reduced) sums, transform the
+ * source in place, compose final = T_inc * final, evaluate the convergence criteria.
+ * t_inc_out (nullable): the incremental transform.  *done: 1 when the loop must stop. */
+int rsreg_icp_update(rsreg_ctx *ctx, const double sums[RSREG_NUM_SUMS], float *t_inc_out,
+                     int *done);
+int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t out_stride);
+
+/* Host-only pieces of the iteration, exposed for tests and for callers that run the
+ * all-reduce themselves. */
+int rsreg_umeyama_from_sums(const double sums[RSREG_NUM_SUMS], float t_out[16]);
+
+/* ---- pcl::transformPointCloud(in, out, Matrix4f) ------------------------------------ */
+/* incremental_icp.hpp:63, icp_edge...hpp:116-117, ndt_edge...hpp:104-105.  in == out is
+ * allowed.  Records are copied whole (stride bytes) and xyz rewritten; when !is_dense,
+ * non-finite points are copied unchanged. */
+int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, size_t stride,
+                          int is_dense, const float transform[16]);
+
+/* ---- pcl::ApproximateVoxelGrid<PointXYZRGB>::filter --------------------------------- */
+/* incremental_icp.hpp:54-55, icp_edge...hpp:47,59-60,75-76, ndt_edge...hpp:45,57-58,68-69.
+ * Order-dependent streaming hash-history centroiding: kept sequential on the host so the
+ * output equals PCL's record for record.  Records must be PointXYZRGB (stride >= 20, rgb
+ * at byte 16).  out must hold n records; *n_out receives the count.  in == out allowed. */
+int rsreg_approx_voxel_grid(const void *in, size_t n, size_t stride, const float leaf[3],
+                            void *out, size_t *n_out);
+
+/* ---- NDT: pcl::NormalDistributionsTransform<PointXYZRGB,PointXYZRGB> ---------------- */
+/* ndt.setInputTarget (ndt_edge...hpp:72): voxel binning + per-voxel mean / covariance /
+ * regularised inverse covariance (VoxelGridCovariance). */
+int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride,
+                         int is_dense, double resolution);
+/* ndt.setInputSource + ndt.align(out, guess) + getFinalTransformation
+ * (ndt_edge...hpp:71,83,92,104). */
+int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride, int is_dense,
+                    const float *guess, const rsreg_ndt_params *params, rsreg_ndt_result *result,
+                    void *aligned_out, size_t out_stride);
+/* One score/gradient/Hessian pass at pose p = [tx ty tz rx ry rz] (tests; the unit an
+ * N-GPU run all-reduces: 1 + 6 + 36 doubles). */
+int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
+                          int is_dense, const double pose[6], double *score, double gradient[6],
+                          double hessian[36]);
+/* Read back the valid voxels: per voxel 3 (mean) + 9 (cov) + 9 (icov) doubles and a count. */
+int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_icov /*21 each*/,
+                         int32_t *counts, int32_t capacity);
+
+/* ---- N-GPU: one pair sharded by source-point blocks --------------------------------- */
+/* One process per GPU.  Rank 0 calls rsreg_comm_unique_id, the caller ships the 128 bytes
+ * to every rank (any side channel, e.g. torch.distributed broadcast over gloo), every rank
+ * calls rsreg_comm_init.  After that rsreg_icp_align / rsreg_ndt_align all-reduce their
+ * sums (17 / 43 doubles per pass) over RCCL on the ctx stream; every rank then runs the
+ * same host solve on identical numbers, so no broadcast of the transform is needed. */
+#define RSREG_UNIQUE_ID_BYTES 128
+int rsreg_comm_unique_id(uint8_t id[RSREG_UNIQUE_ID_BYTES]);
+int rsreg_comm_init(rsreg_ctx *ctx, const uint8_t id[RSREG_UNIQUE_ID_BYTES], int rank, int nranks);
+int rsreg_comm_destroy(rsreg_ctx *ctx);
+/* All-reduce (sum) `count` doubles in place across the ranks of ctx's communicator. */
+int rsreg_comm_allreduce_f64(rsreg_ctx *ctx, double *host_buf, int count);
+
+/* ---- introspection (tests, bench) --------------------------------------------------- */
+typedef struct rsreg_grid_info {
+    float origin[3];
+    float cell_size;
+    int32_t dims[3];
+    uint32_t n_target_points;   /* finite points handed in                                  */
+    uint32_t n_unique_points;   /* after dropping exact duplicates (same xyz bits)          */
+    uint32_t n_cells;           /* occupied cells                                           */
+    uint32_t max_points_per_cell;
+    double ms_build;            /* device time of the last build (profiling on)             */
+} rsreg_grid_info;
+int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSREG_H_ */

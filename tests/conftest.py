@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure only)."""
+    import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def rs():
+    import rsreg_amd
+    return rsreg_amd

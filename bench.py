@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ICP pair-registration hot path on MI355X.
+
+Metric (BASELINE.json): point-pairs/sec per ICP iteration on a 1M <-> 1M cloud pair.
+One "step" = one complete pair registration from clouds already resident in HBM:
+target index build (the analogue of PCL's per-align kd-tree build) + source load +
+`iterations` fixed ICP iterations (NN search, gate, 17 sums, host Umeyama/SVD, transform).
+value = N_src * iterations * steps / wall time of the timed region (max over ranks).
+
+N = 1 : config.workload "icp_pair_1Mx1M_30it" (the configuration the metric is quoted on).
+N > 1 : BASELINE configs[3] — the same single pair, source sharded in N contiguous blocks,
+        target replicated, one RCCL all-reduce of 17 doubles per iteration ("strong" scaling).
+
+Launch for N > 1 (the driver does this):
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", default="N1M", choices=["50k", "N300", "N1M"])
+    ap.add_argument("--iterations", type=int, default=30)
+    ap.add_argument("--max-dist", type=float, default=0.05)
+    ap.add_argument("--pipeline", type=int, default=1, help="0 staged kernels, 1 fused kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=10)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+
+    import rsreg_amd
+    from rsreg_amd import api, lib, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not os.path.exists(lib.SO_PATH):
+        lib.build()
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic D435i-like pair, identical on every rank
+    tgt = synth.render_frame(0, a.size, "bench")
+    src = synth.render_frame(1, a.size, "bench")
+    guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    n_src_total, n_tgt = len(src), len(tgt)
+    lo = (n_src_total * rank) // world
+    hi = (n_src_total * (rank + 1)) // world
+    d_tgt = torch.from_numpy(tgt.points.view(np.uint8).reshape(-1)).cuda()
+    d_src = torch.from_numpy(np.ascontiguousarray(src.points[lo:hi]).view(np.uint8).reshape(-1)).cuda()
+    n_src = hi - lo
+    stride = tgt.points.dtype.itemsize
+
+    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=True)
+    if world > 1:
+        uid = torch.zeros(lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+
+    import ctypes as C
+
+    L = lib.lib()
+    prm = api.icp_params(max_iterations=a.iterations, criteria_mode=1, pipeline_mode=a.pipeline,
+                         max_correspondence_distance=a.max_dist)
+    g = np.ascontiguousarray(guess.T).copy()
+    res = lib.IcpResult()
+    gi = lib.GridInfo()
+
+    def step():
+        lib.check(L.rsreg_icp_set_target_device(ctx.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx.h)
+        lib.check(L.rsreg_icp_set_source_device(ctx.h, d_src.data_ptr(), n_src, stride, 0), ctx.h)
+        lib.check(L.rsreg_icp_align(ctx.h, g.ctypes.data, C.byref(prm), C.byref(res), None, 0), ctx.h)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    ms_nn = ms_red = ms_build = 0.0
+    n_launch = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        ms_nn += res.ms_nn
+        ms_red += res.ms_reduce + res.ms_transform
+        n_launch += res.n_nn_launches
+        L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
+        ms_build += gi.ms_build
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    T_gpu = api._rowmajor(res.transform)
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    pairs = float(n_src_total) * a.iterations * a.steps
+    value = pairs / elapsed
+    # roofline of the dominant kernel (k_icp_fused in pipeline 1, k_nn_search in pipeline 0):
+    # algorithmic bytes per launch, DESIGN.md §5: fused 32*N_src + 16*N_tgt_unique,
+    # staged NN 24*N_src + 16*N_tgt_unique (per rank)
+    n_unique = int(gi.n_unique_points)
+    alg_bytes = (32 if a.pipeline == 1 else 24) * n_src + 16 * n_unique
+    avg_ms = ms_nn / max(n_launch, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "point-pairs/sec per ICP iteration",
+        "value": value,
+        "unit": "point-pairs/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "icp_pair_%sx%s_%dit" % (a.size, a.size, a.iterations),
+            "n_src": n_src_total, "n_tgt": n_tgt, "iterations": a.iterations, "max_corr_dist": a.max_dist,
+            "criteria": "fixed", "pipeline": "fused" if a.pipeline == 1 else "staged",
+            "sharding": "source blocks x%d, RCCL all-reduce of 17 f64 per iteration" % world if world > 1 else "none",
+            "step": "grid build + source load + %d iterations, inputs resident in HBM" % a.iterations,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_icp_fused" if a.pipeline == 1 else "k_nn_search",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+            "launches": n_launch,
+        },
+        "breakdown_ms_per_step": {
+            "grid_build": ms_build / a.steps, "nn_kernel": ms_nn / a.steps, "reduce_transform": ms_red / a.steps,
+            "iteration_rate_pairs_per_s": float(n_src_total) * a.iterations * a.steps / max((ms_nn + ms_red) * 1e-3, 1e-12),
+        },
+        "grid": {"cell_size": float(gi.cell_size), "n_cells": int(gi.n_cells), "n_unique_points": n_unique,
+                 "max_points_per_cell": int(gi.max_points_per_cell)},
+    }
+
+    if not a.no_cpu_baseline:
+        import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product
+
+        oracle.build()
+        cores = 1
+        o = oracle.IcpOracle()
+        p = oracle.IcpParams.default()
+        p.max_iterations, p.criteria_mode, p.max_correspondence_distance = a.cpu_iterations, 1, a.max_dist
+        p.num_threads = cores
+        tc = time.perf_counter()
+        o.set_target(tgt.points, dedup=True)
+        o.set_source(src.points)
+        r = o.align(guess, p)
+        cpu_s = time.perf_counter() - tc
+        cpu_value = float(n_src_total) * a.cpu_iterations / cpu_s
+        out["cpu_baseline"] = {
+            "value": cpu_value, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+            "sample": "same %s pair, kd-tree build + %d of %d iterations, 1 thread (PCL's ICP is single-threaded); "
+                      "the reference's PCL build is not available here" % (a.size, a.cpu_iterations, a.iterations),
+            "seconds": cpu_s, "host_cpus": os.cpu_count(),
+        }
+        # same-iteration-count transform agreement (north-star bar 1e-4 Frobenius), untimed
+        if world == 1:
+            prm2 = api.icp_params(max_iterations=a.cpu_iterations, criteria_mode=1, pipeline_mode=a.pipeline,
+                                  max_correspondence_distance=a.max_dist)
+            res2 = lib.IcpResult()
+            lib.check(L.rsreg_icp_align(ctx.h, g.ctypes.data, C.byref(prm2), C.byref(res2), None, 0), ctx.h)
+            out["transform_error_vs_cpu_frobenius"] = float(np.linalg.norm(api._rowmajor(res2.transform) - r.T))
+        out["speedup_vs_cpu_port"] = value / cpu_value
+    gt = synth.ground_truth(1, 0, "bench")
+    out["transform_error_vs_ground_truth_frobenius"] = float(np.linalg.norm(T_gpu - gt))
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,363 @@
+"""Host-side mirror of the PCL class surface the reference's schemes call, over the C ABI.
+
+Method names and argument meaning follow the reference call sites:
+``pcl::IterativeClosestPoint`` (src/incremental_icp.hpp:46-63), ``pcl::NormalDistributions
+Transform`` (src/ndt_edge_based_registration.hpp:38-43,71-72,83,104), ``pcl::ApproximateVoxel
+Grid`` (src/icp_edge_based_registration.hpp:47,59-60) and ``pcl::transformPointCloud``
+(src/incremental_icp.hpp:63).  Transforms cross this layer as 4x4 numpy arrays in the usual
+row/column maths convention; the column-major packing of the ABI is handled here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+from .cloud import POINT_DTYPE, PointCloud
+
+CONV_STATES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES",
+               "FAILURE_AFTER_MAX_ITERATIONS"]
+
+
+def _colmajor(T):
+    if T is None:
+        return None
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T).copy()
+
+
+def _rowmajor(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def _records(a):
+    """(keepalive, pointer, n, stride) for a PointCloud / structured array / (n,>=3) float32."""
+    if isinstance(a, PointCloud):
+        a = a.points
+    a = np.ascontiguousarray(a)
+    if a.dtype.names:
+        return a, a.ctypes.data, a.shape[0], a.dtype.itemsize
+    if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("points must be a PointCloud, a structured array or an (n, >=3) float32 array")
+    return a, a.ctypes.data, a.shape[0], a.shape[1] * 4
+
+
+def device_count():
+    n = C.c_int(0)
+    _l.check(_l.lib().rsreg_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One (device, stream) execution context; not thread-safe (include/rsreg.h)."""
+
+    def __init__(self, device=0, stream=None, profiling=False):
+        h = C.c_void_p()
+        _l.check(_l.lib().rsreg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+        if profiling:
+            self.set_profiling(True)
+
+    def set_profiling(self, on):
+        _l.check(_l.lib().rsreg_ctx_set_profiling(self.h, int(bool(on))), self.h)
+
+    def synchronize(self):
+        _l.check(_l.lib().rsreg_ctx_synchronize(self.h), self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _l.lib().rsreg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- N-GPU
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_uint8 * _l.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _l.check(_l.lib().rsreg_comm_init(self.h, buf, rank, nranks), self.h)
+
+    def allreduce_f64(self, arr):
+        arr = np.ascontiguousarray(arr, np.float64)
+        _l.check(_l.lib().rsreg_comm_allreduce_f64(self.h, arr.ctypes.data, arr.size), self.h)
+        return arr
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * _l.UNIQUE_ID_BYTES)()
+    _l.check(_l.lib().rsreg_comm_unique_id(buf))
+    return bytes(buf)
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def icp_params(reference=False, **kw):
+    p = _l.IcpParams()
+    (_l.lib().rsreg_icp_params_reference if reference else _l.lib().rsreg_icp_params_default)(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def ndt_params(reference=False, **kw):
+    p = _l.NdtParams()
+    (_l.lib().rsreg_ndt_params_reference if reference else _l.lib().rsreg_ndt_params_default)(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class IterativeClosestPoint:
+    """pcl::IterativeClosestPoint<PointXYZRGB, PointXYZRGB> on the MI355X."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.params = icp_params()
+        self._src = self._tgt = None
+        self._tgt_dirty = True
+        self._src_dirty = True
+        self.result = None
+
+    # setters the reference calls (incremental_icp.hpp:46-49)
+    def setMaximumIterations(self, n):
+        self.params.max_iterations = int(n)
+
+    def setMaxCorrespondenceDistance(self, d):
+        if d != self.params.max_correspondence_distance:
+            self._tgt_dirty = True  # the grid cell size derives from the gate
+        self.params.max_correspondence_distance = float(d)
+
+    def setTransformationEpsilon(self, e):
+        self.params.transformation_epsilon = float(e)
+
+    def setTransformationRotationEpsilon(self, e):
+        self.params.transformation_rotation_epsilon = float(e)
+
+    def setEuclideanFitnessEpsilon(self, e):
+        self.params.euclidean_fitness_epsilon = float(e)
+
+    # engine knobs (not in PCL)
+    def setCriteriaMode(self, mode):
+        self.params.criteria_mode = int(mode)
+
+    def setPipelineMode(self, mode):
+        self.params.pipeline_mode = int(mode)
+
+    def setInputSource(self, cloud):
+        self._src = cloud
+        self._src_dirty = True
+
+    def setInputTarget(self, cloud):
+        self._tgt = cloud
+        self._tgt_dirty = True  # PCL rebuilds the kd-tree whenever the target is set
+
+    def _sync_inputs(self):
+        L, h = _l.lib(), self.ctx.h
+        if self._tgt is None or self._src is None:
+            raise ValueError("setInputSource / setInputTarget not called")
+        if self._tgt_dirty:
+            keep, p, n, s = _records(self._tgt)
+            dense = int(getattr(self._tgt, "is_dense", False))
+            _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
+            self._tgt_dirty = False
+        if self._src_dirty:
+            keep, p, n, s = _records(self._src)
+            dense = int(getattr(self._src, "is_dense", False))
+            _l.check(L.rsreg_icp_set_source(h, p, n, s, dense), h)
+            self._n_src = n
+            self._src_dirty = False
+
+    def align(self, guess=None):
+        """icp.align(out[, guess]): returns the aligned cloud (source colours, xyz <- final * xyz)."""
+        self._sync_inputs()
+        g = _colmajor(guess)
+        res = _l.IcpResult()
+        out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(self._n_src, POINT_DTYPE)
+        _l.check(_l.lib().rsreg_icp_align(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
+                                          C.byref(res), out.ctypes.data, out.dtype.itemsize), self.ctx.h)
+        self.result = res
+        src = self._src if isinstance(self._src, PointCloud) else None
+        return PointCloud(out, width=src.width if src else len(out), height=src.height if src else 1,
+                          is_dense=src.is_dense if src else False)
+
+    def hasConverged(self):
+        return bool(self.result.converged)
+
+    def getFinalTransformation(self):
+        return _rowmajor(self.result.transform)
+
+    def getConvergenceState(self):
+        return CONV_STATES[self.result.state]
+
+    # ---- step-wise form (parity tests, sharded runs)
+    def begin(self, guess=None):
+        self._sync_inputs()
+        g = _colmajor(guess)
+        _l.check(_l.lib().rsreg_icp_begin(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params)),
+                 self.ctx.h)
+
+    def search(self):
+        idx = np.empty(self._n_src, np.int32)
+        d2 = np.empty(self._n_src, np.float32)
+        _l.check(_l.lib().rsreg_icp_search(self.ctx.h, idx.ctypes.data, d2.ctypes.data), self.ctx.h)
+        return idx, d2
+
+    def sums(self):
+        s = np.zeros(_l.NUM_SUMS, np.float64)
+        _l.check(_l.lib().rsreg_icp_sums(self.ctx.h, s.ctypes.data), self.ctx.h)
+        return s
+
+    def update(self, sums):
+        sums = np.ascontiguousarray(sums, np.float64)
+        t = np.zeros(16, np.float32)
+        done = C.c_int(0)
+        _l.check(_l.lib().rsreg_icp_update(self.ctx.h, sums.ctypes.data, t.ctypes.data, C.byref(done)), self.ctx.h)
+        return _rowmajor(t), bool(done.value)
+
+    def end(self, want_aligned=False):
+        res = _l.IcpResult()
+        out = np.zeros((self._n_src, 4), np.float32) if want_aligned else None
+        _l.check(_l.lib().rsreg_icp_end(self.ctx.h, C.byref(res), out.ctypes.data if want_aligned else None, 16),
+                 self.ctx.h)
+        self.result = res
+        return (res, out) if want_aligned else res
+
+    def grid_info(self):
+        gi = _l.GridInfo()
+        _l.check(_l.lib().rsreg_icp_grid_info(self.ctx.h, C.byref(gi)), self.ctx.h)
+        return gi
+
+
+class NormalDistributionsTransform:
+    """pcl::NormalDistributionsTransform<PointXYZRGB, PointXYZRGB> on the MI355X."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.params = ndt_params()
+        self._src = self._tgt = None
+        self._tgt_dirty = True
+        self.result = None
+
+    def setTransformationEpsilon(self, e):
+        self.params.transformation_epsilon = float(e)
+
+    def setStepSize(self, s):
+        self.params.step_size = float(s)
+
+    def setResolution(self, r):
+        if r != self.params.resolution:
+            self._tgt_dirty = True
+        self.params.resolution = float(r)
+
+    def setMaximumIterations(self, n):
+        self.params.max_iterations = int(n)
+
+    def setInputSource(self, cloud):
+        self._src = cloud
+
+    def setInputTarget(self, cloud):
+        self._tgt = cloud
+        self._tgt_dirty = True
+
+    def _sync_target(self):
+        if self._tgt is None or self._src is None:
+            raise ValueError("setInputSource / setInputTarget not called")
+        if self._tgt_dirty:
+            keep, p, n, s = _records(self._tgt)
+            _l.check(_l.lib().rsreg_ndt_set_target(self.ctx.h, p, n, s, int(getattr(self._tgt, "is_dense", False)),
+                                                   self.params.resolution), self.ctx.h)
+            self._tgt_dirty = False
+
+    def align(self, guess=None):
+        self._sync_target()
+        keep, p, n, s = _records(self._src)
+        g = _colmajor(guess)
+        res = _l.NdtResult()
+        out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(n, POINT_DTYPE)
+        _l.check(_l.lib().rsreg_ndt_align(self.ctx.h, p, n, s, int(getattr(self._src, "is_dense", False)),
+                                          g.ctypes.data if g is not None else None, C.byref(self.params),
+                                          C.byref(res), out.ctypes.data, out.dtype.itemsize), self.ctx.h)
+        self.result = res
+        src = self._src if isinstance(self._src, PointCloud) else None
+        return PointCloud(out, width=src.width if src else n, height=src.height if src else 1,
+                          is_dense=src.is_dense if src else False)
+
+    def hasConverged(self):
+        return bool(self.result.converged)
+
+    def getFinalTransformation(self):
+        return _rowmajor(self.result.transform)
+
+    def getTransformationProbability(self):
+        return self.result.trans_probability
+
+    def derivatives(self, pose):
+        self._sync_target()
+        keep, p, n, s = _records(self._src)
+        pose = np.ascontiguousarray(pose, np.float64)
+        score = C.c_double(0)
+        g = np.zeros(6)
+        h = np.zeros((6, 6))
+        _l.check(_l.lib().rsreg_ndt_derivatives(self.ctx.h, p, n, s, 0, pose.ctypes.data, C.byref(score),
+                                                g.ctypes.data, h.ctypes.data), self.ctx.h)
+        return score.value, g, h
+
+    def voxels(self):
+        self._sync_target()
+        n = C.c_int32(0)
+        _l.check(_l.lib().rsreg_ndt_get_voxels(self.ctx.h, C.byref(n), None, None, 0), self.ctx.h)
+        m = np.zeros((n.value, 21), np.float64)
+        c = np.zeros(n.value, np.int32)
+        _l.check(_l.lib().rsreg_ndt_get_voxels(self.ctx.h, C.byref(n), m.ctypes.data, c.ctypes.data, n.value), self.ctx.h)
+        return m, c
+
+
+class ApproximateVoxelGrid:
+    """pcl::ApproximateVoxelGrid<PointXYZRGB> (host, sequential: see csrc/voxel_host.cpp)."""
+
+    def __init__(self):
+        self.leaf = np.ones(3, np.float32)  # PCL default leaf: 1 m (IncrementalICP never sets it)
+        self._in = None
+
+    def setLeafSize(self, lx, ly, lz):
+        self.leaf = np.array([lx, ly, lz], np.float32)
+
+    def setInputCloud(self, cloud):
+        self._in = cloud
+
+    def filter(self):
+        pts = np.ascontiguousarray(self._in.points)
+        out = np.zeros_like(pts)
+        n_out = C.c_size_t(0)
+        _l.check(_l.lib().rsreg_approx_voxel_grid(pts.ctypes.data, len(pts), pts.dtype.itemsize,
+                                                  self.leaf.ctypes.data, out.ctypes.data, C.byref(n_out)))
+        out = out[: n_out.value].copy()
+        return PointCloud(out, width=len(out), height=1, is_dense=False)
+
+
+def transformPointCloud(cloud, T, ctx=None):
+    """pcl::transformPointCloud(in, out, Matrix4f): returns the transformed copy."""
+    ctx = ctx or default_context()
+    pts = np.ascontiguousarray(cloud.points)
+    out = np.empty_like(pts)
+    t = _colmajor(T)
+    _l.check(_l.lib().rsreg_transform_cloud(ctx.h, pts.ctypes.data, out.ctypes.data, len(pts), pts.dtype.itemsize,
+                                            int(cloud.is_dense), t.ctypes.data), ctx.h)
+    return PointCloud(out, width=cloud.width, height=cloud.height, is_dense=cloud.is_dense)
+
+
+def umeyama_from_sums(sums):
+    sums = np.ascontiguousarray(sums, np.float64)
+    t = np.zeros(16, np.float32)
+    _l.check(_l.lib().rsreg_umeyama_from_sums(sums.ctypes.data, t.ctypes.data))
+    return _rowmajor(t)

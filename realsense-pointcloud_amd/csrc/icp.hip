@@ -1,0 +1,795 @@
+// icp.hip — ICP half of the C ABI (include/rsreg.h): context, target grid build, the
+// iteration loop of pcl::IterativeClosestPoint::computeTransformation, transformPointCloud.
+//
+// Reference call sites replaced: src/incremental_icp.hpp:46-49,57-63,
+// src/icp_edge_based_registration.hpp:42-52,78-79,95,104,108-117,
+// src/ndt_edge_based_registration.hpp:47-50,96-105.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+#include "icp_kernels.hpp"
+
+using namespace rsreg;
+
+namespace {
+
+constexpr int kReduceBlocks = 1024;  // fixed, so the summation order never depends on the GPU
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+hipEvent_t take_event(rsreg_ctx *ctx)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
+}
+
+struct ScopedEvents {  // records start/stop around a launch when profiling is on
+    rsreg_ctx *ctx;
+    std::vector<std::pair<size_t, size_t>> *list;
+    size_t a = 0, b = 0;
+    bool on;
+    ScopedEvents(rsreg_ctx *c, std::vector<std::pair<size_t, size_t>> *l) : ctx(c), list(l), on(c->profiling)
+    {
+        if (!on) return;
+        hipEvent_t e = take_event(ctx);
+        a = ctx->ev_used - 1;
+        if (e) (void)hipEventRecord(e, ctx->stream);
+    }
+    ~ScopedEvents()
+    {
+        if (!on) return;
+        hipEvent_t e = take_event(ctx);
+        b = ctx->ev_used - 1;
+        if (e) (void)hipEventRecord(e, ctx->stream);
+        list->push_back({a, b});
+    }
+};
+
+double sum_events(rsreg_ctx *ctx, std::vector<std::pair<size_t, size_t>> &list)
+{
+    double ms = 0;
+    for (auto &p : list) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ctx->ev_pool[p.first], ctx->ev_pool[p.second]) == hipSuccess) ms += t;
+    }
+    return ms;
+}
+
+GridDev grid_dev(const rsreg_ctx *ctx)
+{
+    const GridParams &p = ctx->grid;
+    GridDev g;
+    g.ox = p.origin[0]; g.oy = p.origin[1]; g.oz = p.origin[2];
+    g.inv_cell = p.inv_cell; g.cell = p.cell;
+    g.dx = p.dims[0]; g.dy = p.dims[1]; g.dz = p.dims[2];
+    g.mask = p.table_mask;
+    g.max_ring = p.max_ring;
+    g.table = ctx->d_table.as<CellEntry>();
+    g.pts = ctx->d_tgt_sorted.as<float4>();
+    return g;
+}
+
+// host mirror of cell_coord (same IEEE operations, no contraction)
+int host_cell_coord(float p, float origin, float inv_cell)
+{
+    volatile float d = p - origin;
+    volatile float v = d * inv_cell;
+    float f = std::floor(v);
+    f = std::min(std::max(f, -4.0f), 70000.0f);
+    return (int)f;
+}
+
+double cell_cap_from_env()
+{
+    const char *e = std::getenv("RSREG_CELL_CAP");
+    if (e) {
+        double v = std::atof(e);
+        if (v > 0) return v;
+    }
+    return 0.0125;  // metres; ~2-4 D435i pixel pitches at 1-2 m
+}
+
+int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
+{
+    hipError_t e = ctx->h_stage.reserve(n * 12 + 16);
+    if (e != hipSuccess) return fail(ctx, RSREG_ERR_ALLOC, "pinned staging", e);
+    float *dst = ctx->h_stage.as<float>();
+    const char *src = static_cast<const char *>(points);
+    if (stride == 12) {
+        std::memcpy(dst, src, n * 12);
+    } else {
+        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+    }
+    return RSREG_OK;
+}
+
+// Builds the grid from records already in HBM (d_pts/stride); keeps no pointer to them.
+int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist)
+{
+    hipStream_t st = ctx->stream;
+    ctx->have_target = false;
+    ctx->n_target_raw = n;
+    std::memset(&ctx->grid_info, 0, sizeof(ctx->grid_info));
+    std::memset(&ctx->grid, 0, sizeof(ctx->grid));
+    ctx->gate_built_for = max_dist;
+    if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "target too large");
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->profiling) {
+        ctx->ev_used = 0;
+        ev0 = take_event(ctx);
+        ev1 = take_event(ctx);
+        (void)hipEventRecord(ev0, st);
+    }
+
+    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();  // pinned scratch, 16 words used here
+    const size_t misc_bytes = 16 * sizeof(uint32_t);
+    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
+    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
+    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, misc_bytes, hipMemcpyHostToDevice, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    h_misc[6] = 0;
+    if (n > 0) {
+        k_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, kBlock), 2048), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, d_misc);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
+        RSREG_HIP(ctx, hipStreamSynchronize(st));
+    }
+    const uint32_t nfin = h_misc[6];
+    ctx->grid_info.n_target_points = nfin;
+    if (nfin == 0) {
+        ctx->have_target = true;  // an empty index: every search comes back empty
+        ctx->grid.n_points = 0;
+        ctx->grid.table_mask = 0;
+        ctx->grid.dims[0] = ctx->grid.dims[1] = ctx->grid.dims[2] = 0;
+        ctx->grid.max_ring = 0;
+        ctx->grid.cell = ctx->grid.inv_cell = 1.0f;
+        RSREG_HIP(ctx, ctx->d_table.reserve(sizeof(CellEntry)));
+        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, sizeof(CellEntry), st));
+        RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(sizeof(float4)));
+        return RSREG_OK;
+    }
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(h_misc[k]); mx[k] = ordered_float(h_misc[3 + k]); }
+
+    // ---- cell size: a whole fraction of the gate (so the rings cover it exactly), no
+    // larger than the cap; an unbounded gate searches until the grid is exhausted.
+    const double cap = cell_cap_from_env();
+    double extent = 0;
+    for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
+    double cell;
+    int max_ring;
+    const bool bounded = std::isfinite(max_dist) && max_dist > 0 && max_dist < 0.25 * extent + 1e-3;
+    if (bounded) {
+        const double padded = max_dist * 1.04;
+        const int parts = std::max(1, (int)std::ceil(padded / cap));
+        cell = padded / parts;
+    } else {
+        cell = cap;
+    }
+    cell = std::max(cell, extent / 60000.0);  // 16 bits per axis in the cell key
+    cell = std::max(cell, 1e-6);
+    GridParams &gp = ctx->grid;
+    gp.cell = (float)cell;
+    gp.inv_cell = 1.0f / gp.cell;
+    for (int k = 0; k < 3; ++k) {
+        gp.origin[k] = mn[k];
+        gp.dims[k] = host_cell_coord(mx[k], mn[k], gp.inv_cell) + 2;
+    }
+    const int max_dim = std::max(gp.dims[0], std::max(gp.dims[1], gp.dims[2]));
+    if (std::isfinite(max_dist) && max_dist >= 0) {
+        const double rings = std::ceil(max_dist / ((double)gp.cell * kRingSafety));
+        max_ring = rings < (double)(max_dim + 1) ? std::max(1, (int)rings) : max_dim + 1;
+    } else {
+        max_ring = max_dim + 1;
+    }
+    gp.max_ring = max_ring;
+
+    // ---- sort by (cell, xyz hash)
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_cellkey.reserve(((size_t)nfin + 2) * 8));
+    RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 1) * sizeof(float4)));
+    GridDev g = grid_dev(ctx);
+    const uint32_t nb = div_up((uint32_t)n, kBlock);
+    auto *keys = ctx->d_keys.as<unsigned long long>();
+    auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
+    auto *vals = ctx->d_vals.as<uint32_t>();
+    auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
+    k_cell_keys<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    size_t tmp_bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
+    size_t scan_bytes = 0;
+    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n;
+    uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n;
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
+    const uint32_t nbf = div_up(nfin, kBlock);
+    k_flag_runs<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    k_scatter_sorted<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, pos, cid,
+                                             ctx->d_tgt_sorted.as<float4>(), ctx->d_cellkey.as<unsigned long long>(),
+                                             ctx->d_cellpos.as<uint32_t>(), d_misc + 8);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t n_unique = h_misc[8], n_cells = h_misc[9];
+    gp.n_points = n_unique;
+    gp.n_cells = n_cells;
+
+    // ---- hash table of occupied cells, at most half full
+    uint32_t slots = 64;
+    while (slots < 2 * n_cells) slots <<= 1;
+    gp.table_mask = slots - 1;
+    RSREG_HIP(ctx, ctx->d_table.reserve((size_t)slots * sizeof(CellEntry)));
+    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, (size_t)slots * sizeof(CellEntry), st));
+    k_table_insert<<<div_up(n_cells, kBlock), kBlock, 0, st>>>(ctx->d_cellkey.as<unsigned long long>(),
+                                                               ctx->d_cellpos.as<uint32_t>(), n_cells,
+                                                               ctx->d_table.as<CellEntry>(), gp.table_mask, d_misc + 10);
+    RSREG_HIP(ctx, hipGetLastError());
+    if (ctx->profiling) (void)hipEventRecord(ev1, st);
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+
+    rsreg_grid_info &gi = ctx->grid_info;
+    for (int k = 0; k < 3; ++k) { gi.origin[k] = gp.origin[k]; gi.dims[k] = gp.dims[k]; }
+    gi.cell_size = gp.cell;
+    gi.n_unique_points = n_unique;
+    gi.n_cells = n_cells;
+    gi.max_points_per_cell = h_misc[10];
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
+    }
+    ctx->have_target = true;
+    return RSREG_OK;
+}
+
+int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
+{
+    if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
+    RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)kReduceBlocks * RSREG_NUM_SUMS * 8));
+    RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    ctx->n_source = n;
+    if (n) {
+        k_init_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
+            d_raw, stride, (uint32_t)n, to_mat34(Mat4f::identity()), 0, ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    ctx->have_source = true;
+    ctx->icp.active = 0;
+    return RSREG_OK;
+}
+
+// DefaultConvergenceCriteria::hasConverged
+bool criteria_has_converged(IcpState &s)
+{
+    const rsreg_icp_params &p = s.prm;
+    if (s.state != RSREG_CONV_NOT_CONVERGED) { s.similar = 0; s.state = RSREG_CONV_NOT_CONVERGED; }
+    bool is_similar = false;
+    if (s.iterations >= p.max_iterations) { s.state = RSREG_CONV_ITERATIONS; return true; }
+    if (p.criteria_mode == RSREG_CRITERIA_FIXED) return false;
+    const double rot_thr = p.transformation_rotation_epsilon > 0 ? p.transformation_rotation_epsilon
+                                                                  : 1.0 - p.transformation_epsilon;
+    const double trans_thr = p.transformation_epsilon;
+    const Mat4f &T = s.t_inc;
+    const double cos_angle = 0.5 * ((double)T(0, 0) + (double)T(1, 1) + (double)T(2, 2) - 1.0);
+    const double tsq = (double)T(0, 3) * T(0, 3) + (double)T(1, 3) * T(1, 3) + (double)T(2, 3) * T(2, 3);
+    const int max_similar = 0;  // max_iterations_similar_transforms_
+    if (cos_angle >= rot_thr && tsq <= trans_thr) {
+        if (s.similar >= max_similar) { s.state = RSREG_CONV_TRANSFORM; return true; }
+        is_similar = true;
+    }
+    if (std::fabs(s.cur_mse - s.prev_mse) < 1e-12) {
+        if (s.similar >= max_similar) { s.state = RSREG_CONV_ABS_MSE; return true; }
+        is_similar = true;
+    }
+    if (std::fabs(s.cur_mse - s.prev_mse) / s.prev_mse < p.euclidean_fitness_epsilon) {
+        if (s.similar >= max_similar) { s.state = RSREG_CONV_REL_MSE; return true; }
+        is_similar = true;
+    }
+    if (is_similar) ++s.similar; else s.similar = 0;
+    s.prev_mse = s.cur_mse;
+    return false;
+}
+
+int launch_search(rsreg_ctx *ctx)
+{
+    IcpState &s = ctx->icp;
+    const uint32_t n = (uint32_t)ctx->n_source;
+    const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
+    if (n) {
+        ScopedEvents ev(ctx, &ctx->ev_nn);
+        k_nn_search<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, grid_dev(ctx), gate2,
+                                                                    ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>());
+        RSREG_HIP(ctx, hipGetLastError());
+        s.n_nn_launches++;
+    }
+    s.have_search = true;
+    return RSREG_OK;
+}
+
+extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int count);  // comm.cpp
+
+int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
+{
+    if (global && ctx->nranks > 1) {
+        int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
+        if (rc) return rc;
+    }
+    double *h = ctx->h_sums.as<double>();
+    RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_sums.ptr, RSREG_NUM_SUMS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(sums, h, RSREG_NUM_SUMS * 8);
+    return RSREG_OK;
+}
+
+int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
+{
+    const uint32_t n = (uint32_t)ctx->n_source;
+    {
+        ScopedEvents ev(ctx, &ctx->ev_reduce);
+        k_cov_reduce<<<kReduceBlocks, kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
+                                                                ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
+                                                                ctx->d_partials.as<double>());
+        RSREG_HIP(ctx, hipGetLastError());
+        k_final_reduce<<<1, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), kReduceBlocks, ctx->d_sums.as<double>());
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    return fetch_sums(ctx, sums, global);
+}
+
+// fused pass: applies the pending increment (if any), searches, gates and reduces
+int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
+{
+    IcpState &s = ctx->icp;
+    const uint32_t n = (uint32_t)ctx->n_source;
+    const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
+    {
+        ScopedEvents ev(ctx, &ctx->ev_nn);
+        k_icp_fused<<<kReduceBlocks, kBlock, 0, ctx->stream>>>(
+            ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, grid_dev(ctx), gate2,
+            want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>());
+        RSREG_HIP(ctx, hipGetLastError());
+        s.n_nn_launches++;
+    }
+    s.pending_transform = false;
+    {
+        ScopedEvents ev(ctx, &ctx->ev_reduce);
+        k_final_reduce<<<1, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), kReduceBlocks, ctx->d_sums.as<double>());
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    s.have_search = want_corr;
+    return fetch_sums(ctx, sums, true);
+}
+
+int apply_pending_transform(rsreg_ctx *ctx)
+{
+    IcpState &s = ctx->icp;
+    if (!s.pending_transform) return RSREG_OK;
+    const uint32_t n = (uint32_t)ctx->n_source;
+    if (n) {
+        ScopedEvents ev(ctx, &ctx->ev_transform);
+        k_transform<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc));
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    s.pending_transform = false;
+    return RSREG_OK;
+}
+
+// Umeyama + compose + criteria for one iteration's (global) sums; the transform of the
+// source cloud itself is left pending so that the fused kernel can fold it into its pass.
+int update_from_sums(rsreg_ctx *ctx, const double *sums, int *done)
+{
+    IcpState &s = ctx->icp;
+    std::memcpy(s.sums_last, sums, sizeof(s.sums_last));
+    s.ncorr = (uint64_t)(sums[0] + 0.5);
+    if (s.ncorr < 3) {  // min_number_correspondences_
+        s.state = RSREG_CONV_NO_CORRESPONDENCES;
+        s.converged = 0;
+        *done = 1;
+        return RSREG_OK;
+    }
+    umeyama_from_sums(sums, s.t_inc);
+    s.pending_transform = true;
+    s.final_t = mul(s.t_inc, s.final_t);
+    s.iterations++;
+    s.cur_mse = sums[16] / sums[0];
+    s.converged = criteria_has_converged(s) ? 1 : 0;
+    s.have_search = false;
+    *done = s.converged;
+    return RSREG_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int rsreg_version(void) { return RSREG_VERSION_MAJOR * 1000 + RSREG_VERSION_MINOR; }
+
+const char *rsreg_status_string(int status)
+{
+    switch (status) {
+        case RSREG_OK: return "ok";
+        case RSREG_ERR_INVALID_ARG: return "invalid argument";
+        case RSREG_ERR_EMPTY_CLOUD: return "empty cloud";
+        case RSREG_ERR_HIP: return "HIP error";
+        case RSREG_ERR_RCCL: return "RCCL error";
+        case RSREG_ERR_NO_TARGET: return "no target set";
+        case RSREG_ERR_NO_DEVICE: return "no usable HIP device";
+        case RSREG_ERR_ALLOC: return "allocation failed";
+        case RSREG_ERR_NO_SOURCE: return "no source set";
+        case RSREG_ERR_STATE: return "call out of sequence";
+        default: return "unknown status";
+    }
+}
+
+const char *rsreg_last_error(const rsreg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int rsreg_device_count(int *count)
+{
+    if (!count) return RSREG_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return RSREG_OK;
+}
+
+int rsreg_ctx_create(int device_id, void *stream, rsreg_ctx **out)
+{
+    if (!out) return RSREG_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RSREG_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return RSREG_ERR_INVALID_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return RSREG_ERR_NO_DEVICE;
+    rsreg_ctx *ctx = new (std::nothrow) rsreg_ctx();
+    if (!ctx) return RSREG_ERR_ALLOC;
+    ctx->device = device_id;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return RSREG_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return RSREG_OK;
+}
+
+int rsreg_comm_destroy(rsreg_ctx *ctx);
+
+int rsreg_ctx_destroy(rsreg_ctx *ctx)
+{
+    if (!ctx) return RSREG_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    rsreg_comm_destroy(ctx);
+    DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_cellkey, &ctx->d_tmp,
+                      &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2,
+                      &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
+                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
+    for (DevBuf *b : bufs) b->release();
+    ctx->h_sums.release();
+    ctx->h_stage.release();
+    ctx->h_ndt.release();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RSREG_OK;
+}
+
+int rsreg_ctx_synchronize(rsreg_ctx *ctx)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RSREG_OK;
+}
+
+int rsreg_ctx_set_profiling(rsreg_ctx *ctx, int enabled)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    ctx->profiling = enabled != 0;
+    return RSREG_OK;
+}
+
+void rsreg_icp_params_default(rsreg_icp_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->max_iterations = 10;
+    p->criteria_mode = RSREG_CRITERIA_PCL;
+    p->pipeline_mode = RSREG_PIPELINE_FUSED;
+    p->max_correspondence_distance = std::sqrt(DBL_MAX);
+    p->transformation_epsilon = 0.0;
+    p->transformation_rotation_epsilon = 0.0;
+    p->euclidean_fitness_epsilon = -DBL_MAX;
+}
+
+void rsreg_icp_params_reference(rsreg_icp_params *p)
+{
+    if (!p) return;
+    rsreg_icp_params_default(p);
+    p->max_iterations = 100;                 // incremental_icp.hpp:46
+    p->max_correspondence_distance = 0.01;   // :47
+    p->transformation_epsilon = 1;           // :48
+    p->euclidean_fitness_epsilon = 1000;     // :49
+}
+
+int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense,
+                                double max_correspondence_distance)
+{
+    (void)is_dense;
+    if (!ctx || (n && !d_points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    return build_grid(ctx, static_cast<const char *>(d_points), n, stride, max_correspondence_distance);
+}
+
+int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense,
+                         double max_correspondence_distance)
+{
+    (void)is_dense;
+    if (!ctx || (n && !points) || stride < 12) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = pack_to_stage(ctx, points, n, stride);
+    if (rc) return rc;
+    RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
+    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    return build_grid(ctx, ctx->d_tgt_raw.as<char>(), n, 12, max_correspondence_distance);
+}
+
+int rsreg_icp_set_source_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense)
+{
+    (void)is_dense;
+    if (!ctx || (n && !d_points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    return load_source(ctx, static_cast<const char *>(d_points), n, stride);
+}
+
+int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense)
+{
+    (void)is_dense;
+    if (!ctx || (n && !points) || stride < 12) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = pack_to_stage(ctx, points, n, stride);
+    if (rc) return rc;
+    RSREG_HIP(ctx, ctx->d_src_raw.reserve(n * 12 + 16));
+    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_src_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    rc = load_source(ctx, ctx->d_src_raw.as<char>(), n, 12);
+    if (rc) return rc;
+    // the pinned staging buffer is reused by the next call: drain the copy first
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RSREG_OK;
+}
+
+int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params)
+{
+    if (!ctx || !params) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_icp_set_target not called");
+    if (!ctx->have_source) return fail(ctx, RSREG_ERR_NO_SOURCE, "rsreg_icp_set_source not called");
+    if (params->max_iterations < 0 || !(params->max_correspondence_distance >= 0))
+        return fail(ctx, RSREG_ERR_INVALID_ARG, "bad ICP parameters");
+    if (params->max_correspondence_distance > ctx->gate_built_for)
+        return fail(ctx, RSREG_ERR_INVALID_ARG, "max_correspondence_distance exceeds the one the target index was built for");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    IcpState &s = ctx->icp;
+    s = IcpState();
+    s.prm = *params;
+    // the rings must cover THIS call's gate (it may be smaller than the one built for)
+    s.final_t = Mat4f::identity();
+    if (guess) std::memcpy(s.final_t.m, guess, sizeof(s.final_t.m));
+    s.t_inc = Mat4f::identity();
+    s.prev_mse = DBL_MAX;
+    s.active = 1;
+    ctx->ev_used = 0;
+    ctx->ev_nn.clear();
+    ctx->ev_reduce.clear();
+    ctx->ev_transform.clear();
+    const uint32_t n = (uint32_t)ctx->n_source;
+    if (n) {
+        const int apply = s.final_t.is_identity() ? 0 : 1;
+        k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t),
+                                                                        apply, ctx->d_cur.as<float4>());
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    return RSREG_OK;
+}
+
+int rsreg_icp_search(rsreg_ctx *ctx, int32_t *index_out, float *sqr_dist_out)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->icp.active) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_begin not called");
+    int rc = apply_pending_transform(ctx);
+    if (rc) return rc;
+    rc = launch_search(ctx);
+    if (rc) return rc;
+    const size_t n = ctx->n_source;
+    if ((index_out || sqr_dist_out) && n) {
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 4 + 16));
+        if (index_out) {
+            k_corr_to_index<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
+                ctx->d_corr_pos.as<int>(), ctx->d_tgt_sorted.as<float4>(), (uint32_t)n, ctx->d_tmp.as<int>());
+            RSREG_HIP(ctx, hipGetLastError());
+            RSREG_HIP(ctx, hipMemcpyAsync(index_out, ctx->d_tmp.ptr, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (sqr_dist_out)
+            RSREG_HIP(ctx, hipMemcpyAsync(sqr_dist_out, ctx->d_corr_d2.ptr, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RSREG_OK;
+}
+
+int rsreg_icp_sums(rsreg_ctx *ctx, double sums[RSREG_NUM_SUMS])
+{
+    if (!ctx || !sums) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->icp.active) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_begin not called");
+    if (!ctx->icp.have_search) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_search not called for this iteration");
+    return launch_sums(ctx, sums, false);
+}
+
+int rsreg_umeyama_from_sums(const double sums[RSREG_NUM_SUMS], float t_out[16])
+{
+    if (!sums || !t_out) return RSREG_ERR_INVALID_ARG;
+    Mat4f T;
+    if (!umeyama_from_sums(sums, T)) return RSREG_ERR_INVALID_ARG;
+    std::memcpy(t_out, T.m, sizeof(T.m));
+    return RSREG_OK;
+}
+
+int rsreg_icp_update(rsreg_ctx *ctx, const double sums[RSREG_NUM_SUMS], float *t_inc_out, int *done)
+{
+    if (!ctx || !sums || !done) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->icp.active) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_begin not called");
+    int rc = update_from_sums(ctx, sums, done);
+    if (rc) return rc;
+    if (t_inc_out) std::memcpy(t_inc_out, ctx->icp.t_inc.m, 64);
+    return RSREG_OK;
+}
+
+int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t out_stride)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    IcpState &s = ctx->icp;
+    if (!s.active) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_begin not called");
+    const size_t n = ctx->n_source;
+    if (aligned_out && n) {
+        if (out_stride < 12) return RSREG_ERR_INVALID_ARG;
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
+        RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
+        k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), (uint32_t)n,
+                                                                                to_mat34(s.final_t), ctx->d_tmp.as<float>());
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (aligned_out && n) {
+        const float *src = ctx->h_stage.as<float>();
+        char *dst = static_cast<char *>(aligned_out);
+        const float one = 1.0f;
+        for (size_t i = 0; i < n; ++i) {
+            std::memcpy(dst + i * out_stride, src + 3 * i, 12);
+            if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
+        }
+    }
+    if (result) {
+        std::memset(result, 0, sizeof(*result));
+        std::memcpy(result->transform, s.final_t.m, 64);
+        result->converged = s.converged;
+        result->state = s.state;
+        result->iterations = s.iterations;
+        result->n_correspondences = s.ncorr;
+        result->mse = s.cur_mse;
+        std::memcpy(result->sums_last, s.sums_last, sizeof(s.sums_last));
+        result->n_nn_launches = s.n_nn_launches;
+        if (ctx->profiling) {
+            result->ms_nn = sum_events(ctx, ctx->ev_nn);
+            result->ms_reduce = sum_events(ctx, ctx->ev_reduce);
+            result->ms_transform = sum_events(ctx, ctx->ev_transform);
+            result->ms_total = result->ms_nn + result->ms_reduce + result->ms_transform;
+        }
+    }
+    s.active = 0;
+    return RSREG_OK;
+}
+
+int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result,
+                    void *aligned_out, size_t out_stride)
+{
+    int rc = rsreg_icp_begin(ctx, guess, params);
+    if (rc) return rc;
+    int done = 0;
+    double sums[RSREG_NUM_SUMS];
+    const bool fused = params->pipeline_mode == RSREG_PIPELINE_FUSED;
+    while (!done) {
+        if (fused) {
+            rc = launch_fused(ctx, sums, false);
+        } else {
+            rc = apply_pending_transform(ctx);
+            if (!rc) rc = launch_search(ctx);
+            if (!rc) rc = launch_sums(ctx, sums, true);
+        }
+        if (rc) return rc;
+        rc = update_from_sums(ctx, sums, &done);
+        if (rc) return rc;
+    }
+    return rsreg_icp_end(ctx, result, aligned_out, out_stride);
+}
+
+int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
+{
+    if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
+    *info = ctx->grid_info;
+    return RSREG_OK;
+}
+
+// pcl::transformPointCloud: whole records copied, xyz rewritten
+int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, size_t stride, int is_dense,
+                          const float transform[16])
+{
+    (void)is_dense;  // non-finite points are left unchanged either way (xform of NaN stays NaN-free here)
+    if (!ctx || !transform || (n && (!in || !out)) || stride < 12) return RSREG_ERR_INVALID_ARG;
+    if (n == 0) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = pack_to_stage(ctx, in, n, stride);
+    if (rc) return rc;
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + n * 16 + 64));
+    char *d_raw = ctx->d_tmp.as<char>();
+    float4 *d_pts = reinterpret_cast<float4 *>(d_raw + ((n * 12 + 15) & ~size_t(15)));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(((n * 12 + 15) & ~size_t(15)) + n * 16 + 64));
+    d_raw = ctx->d_tmp.as<char>();
+    d_pts = reinterpret_cast<float4 *>(d_raw + ((n * 12 + 15) & ~size_t(15)));
+    RSREG_HIP(ctx, hipMemcpyAsync(d_raw, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    Mat4f T;
+    std::memcpy(T.m, transform, 64);
+    k_init_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_raw, 12, (uint32_t)n, to_mat34(T), 1, nullptr, d_pts);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_pts, (uint32_t)n, to_mat34(Mat4f::identity()),
+                                                                            reinterpret_cast<float *>(d_raw));
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, d_raw, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const char *src = static_cast<const char *>(in);
+    char *dst = static_cast<char *>(out);
+    const float *xyz = ctx->h_stage.as<float>();
+    for (size_t i = 0; i < n; ++i) {
+        if (dst != src) std::memmove(dst + i * stride, src + i * stride, stride);
+        std::memcpy(dst + i * stride, xyz + 3 * i, 12);
+    }
+    return RSREG_OK;
+}
+
+}  // extern "C"

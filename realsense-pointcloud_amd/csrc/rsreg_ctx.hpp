@@ -1,0 +1,171 @@
+// rsreg_ctx.hpp — the per-(device, stream) context behind the C ABI (include/rsreg.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rsreg.h"
+#include "host_linalg.hpp"
+
+namespace rsreg {
+
+// Growable device allocation; never shrinks, so steady-state calls allocate nothing.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+struct PinnedBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+// Uniform-grid index over the target cloud, all device-resident (layout: DESIGN.md §3).
+struct GridParams {
+    float origin[3];
+    float inv_cell;
+    float cell;
+    int dims[3];
+    uint32_t table_mask;   // hash table has table_mask + 1 slots
+    uint32_t n_points;     // unique finite target points in `sorted`
+    uint32_t n_cells;
+    int max_ring;          // rings needed to cover the correspondence gate
+};
+
+struct CellEntry {         // 16 B, one hash-table slot
+    unsigned long long key;  // packed cell coordinate, ~0 = empty
+    uint32_t start, count;   // run in the sorted point array
+};
+
+struct IcpState {
+    rsreg_icp_params prm;
+    Mat4f final_t, t_inc;
+    int iterations = 0, state = 0, converged = 0, similar = 0, active = 0;
+    double prev_mse = 0, cur_mse = 0;
+    uint64_t ncorr = 0;
+    double sums_last[RSREG_NUM_SUMS] = {0};
+    bool have_search = false;     // corr buffers hold the current iteration's search
+    bool pending_transform = false;  // fused mode: t_inc not yet applied to d_cur
+    double ms_nn = 0, ms_reduce = 0, ms_transform = 0;
+    int n_nn_launches = 0;
+};
+
+}  // namespace rsreg
+
+struct rsreg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    std::string last_error;
+
+    // ---- ICP target index
+    bool have_target = false;
+    rsreg::GridParams grid{};
+    rsreg_grid_info grid_info{};
+    double gate_built_for = 0;
+    rsreg::DevBuf d_tgt_raw;      // packed xyz of the caller's target (n x float3)
+    rsreg::DevBuf d_tgt_sorted;   // float4 {x,y,z,bits(orig index)}, cell-sorted, de-duplicated
+    rsreg::DevBuf d_table;        // CellEntry[table_mask+1]
+    rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_cellpos, d_cellkey, d_tmp;
+    rsreg::DevBuf d_misc;         // small: bbox, counters
+    size_t n_target_raw = 0;
+
+    // ---- ICP source
+    bool have_source = false;
+    size_t n_source = 0;
+    rsreg::DevBuf d_src_raw;      // packed xyz as handed in
+    rsreg::DevBuf d_src;          // float4 {x,y,z,valid}
+    rsreg::DevBuf d_cur;          // float4 current (transformed) source
+    rsreg::DevBuf d_corr_pos;     // int32: position in d_tgt_sorted, -1 = none
+    rsreg::DevBuf d_corr_d2;      // float
+    rsreg::DevBuf d_partials;     // double[blocks][17]
+    rsreg::DevBuf d_sums;         // double[17]
+    rsreg::PinnedBuf h_sums;      // pinned double[64]
+    rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
+    rsreg::IcpState icp;
+
+    // ---- NDT
+    bool have_ndt_target = false;
+    double ndt_resolution = 0;
+    int ndt_n_voxels = 0;
+    rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
+    rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;
+    std::vector<double> ndt_mean_cov_icov;   // 21 per voxel (host copy)
+    std::vector<int> ndt_counts;
+    std::vector<float> ndt_centroid;         // 3 per voxel
+    rsreg::PinnedBuf h_ndt;
+
+    // ---- RCCL
+    void *comm = nullptr;         // ncclComm_t
+    int rank = 0, nranks = 1;
+    rsreg::DevBuf d_comm;
+
+    // ---- profiling events
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, size_t>> ev_nn, ev_reduce, ev_transform;
+};
+
+namespace rsreg {
+
+inline int fail(rsreg_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define RSREG_HIP(ctx, expr)                                              \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return rsreg::fail((ctx), RSREG_ERR_HIP, #expr, _e); \
+    } while (0)
+
+}  // namespace rsreg

@@ -1,0 +1,178 @@
+"""ctypes binding of librsreg.so — the C ABI declared in include/rsreg.h.
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or no GPU
+is usable, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+SO_PATH = os.path.join(_HERE, "librsreg.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["icp.hip", "ndt.hip", "comm.cpp", "voxel_host.cpp"]
+HEADERS = ["icp_kernels.hpp", "rsreg_ctx.hpp", "host_linalg.hpp", "ndt_kernels.hpp"]
+NUM_SUMS = 17
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/rsreg.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "rsreg_version", "rsreg_status_string", "rsreg_last_error", "rsreg_device_count",
+    "rsreg_ctx_create", "rsreg_ctx_destroy", "rsreg_ctx_synchronize", "rsreg_ctx_set_profiling",
+    "rsreg_icp_params_default", "rsreg_icp_params_reference", "rsreg_ndt_params_default",
+    "rsreg_ndt_params_reference", "rsreg_icp_set_target", "rsreg_icp_set_target_device",
+    "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_begin",
+    "rsreg_icp_search", "rsreg_icp_sums", "rsreg_icp_update", "rsreg_icp_end",
+    "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid",
+    "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
+    "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
+    "rsreg_icp_grid_info",
+]
+
+
+class RsregError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("rsreg status %d (%s)%s" % (status, status_string(status), (": " + detail) if detail else ""))
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32), ("criteria_mode", C.c_int32), ("pipeline_mode", C.c_int32),
+        ("reserved0", C.c_int32), ("max_correspondence_distance", C.c_double),
+        ("transformation_epsilon", C.c_double), ("transformation_rotation_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+    ]
+
+
+class NdtParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32), ("reserved0", C.c_int32), ("transformation_epsilon", C.c_double),
+        ("step_size", C.c_double), ("resolution", C.c_double), ("outlier_ratio", C.c_double),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("transform", C.c_float * 16), ("converged", C.c_int32), ("state", C.c_int32),
+        ("iterations", C.c_int32), ("reserved0", C.c_int32), ("n_correspondences", C.c_uint64),
+        ("mse", C.c_double), ("sums_last", C.c_double * NUM_SUMS), ("ms_total", C.c_double),
+        ("ms_nn", C.c_double), ("ms_reduce", C.c_double), ("ms_transform", C.c_double),
+        ("n_nn_launches", C.c_int32), ("reserved1", C.c_int32),
+    ]
+
+
+class NdtResult(C.Structure):
+    _fields_ = [
+        ("transform", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
+        ("trans_probability", C.c_double), ("score", C.c_double), ("n_voxels", C.c_int32),
+        ("n_derivative_passes", C.c_int32), ("ms_total", C.c_double), ("ms_derivatives", C.c_double),
+    ]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [
+        ("origin", C.c_float * 3), ("cell_size", C.c_float), ("dims", C.c_int32 * 3),
+        ("n_target_points", C.c_uint32), ("n_unique_points", C.c_uint32), ("n_cells", C.c_uint32),
+        ("max_points_per_cell", C.c_uint32), ("ms_build", C.c_double),
+    ]
+
+
+def hipcc_command(out=SO_PATH):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+            "-Wno-unused-result", *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"]
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "rsreg.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    cmd = hipcc_command()
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout[-4000:])
+    if verbose:
+        print(r.stdout)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Raises if the extension has not been built: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "librsreg.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "this package has no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, sz, i32, dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_double
+    L.rsreg_version.restype = i32
+    L.rsreg_status_string.restype = C.c_char_p
+    L.rsreg_status_string.argtypes = [i32]
+    L.rsreg_last_error.restype = C.c_char_p
+    L.rsreg_last_error.argtypes = [vp]
+    L.rsreg_device_count.argtypes = [C.POINTER(i32)]
+    L.rsreg_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.rsreg_ctx_destroy.argtypes = [vp]
+    L.rsreg_ctx_synchronize.argtypes = [vp]
+    L.rsreg_ctx_set_profiling.argtypes = [vp, i32]
+    for f in ("rsreg_icp_params_default", "rsreg_icp_params_reference"):
+        getattr(L, f).argtypes = [C.POINTER(IcpParams)]
+        getattr(L, f).restype = None
+    for f in ("rsreg_ndt_params_default", "rsreg_ndt_params_reference"):
+        getattr(L, f).argtypes = [C.POINTER(NdtParams)]
+        getattr(L, f).restype = None
+    L.rsreg_icp_set_target.argtypes = [vp, vp, sz, sz, i32, dbl]
+    L.rsreg_icp_set_target_device.argtypes = [vp, vp, sz, sz, i32, dbl]
+    L.rsreg_icp_set_source.argtypes = [vp, vp, sz, sz, i32]
+    L.rsreg_icp_set_source_device.argtypes = [vp, vp, sz, sz, i32]
+    L.rsreg_icp_align.argtypes = [vp, vp, C.POINTER(IcpParams), C.POINTER(IcpResult), vp, sz]
+    L.rsreg_icp_begin.argtypes = [vp, vp, C.POINTER(IcpParams)]
+    L.rsreg_icp_search.argtypes = [vp, vp, vp]
+    L.rsreg_icp_sums.argtypes = [vp, vp]
+    L.rsreg_icp_update.argtypes = [vp, vp, vp, C.POINTER(i32)]
+    L.rsreg_icp_end.argtypes = [vp, C.POINTER(IcpResult), vp, sz]
+    L.rsreg_umeyama_from_sums.argtypes = [vp, vp]
+    L.rsreg_transform_cloud.argtypes = [vp, vp, vp, sz, sz, i32, vp]
+    L.rsreg_approx_voxel_grid.argtypes = [vp, sz, sz, vp, vp, C.POINTER(sz)]
+    L.rsreg_ndt_set_target.argtypes = [vp, vp, sz, sz, i32, dbl]
+    L.rsreg_ndt_align.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp, sz]
+    L.rsreg_ndt_derivatives.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(dbl), vp, vp]
+    L.rsreg_ndt_get_voxels.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, C.c_int32]
+    L.rsreg_comm_unique_id.argtypes = [vp]
+    L.rsreg_comm_init.argtypes = [vp, vp, i32, i32]
+    L.rsreg_comm_destroy.argtypes = [vp]
+    L.rsreg_comm_allreduce_f64.argtypes = [vp, vp, i32]
+    L.rsreg_icp_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    _lib = L
+    return L
+
+
+def status_string(status):
+    try:
+        return lib().rsreg_status_string(status).decode()
+    except Exception:
+        return "?"
+
+
+def check(status, ctx=None):
+    if status != 0:
+        detail = ""
+        if ctx:
+            detail = lib().rsreg_last_error(ctx).decode()
+        raise RsregError(status, detail)

@@ -1,0 +1,324 @@
+"""GPU parity tests of the ICP path, through the C ABI (librsreg.so), against
+  (a) the independent numpy/scipy golden vectors (tests/golden), and
+  (b) the CPU oracle (oracle/*.c) on the same seeded synthetic inputs.
+Bars: nearest-neighbour indices and float32 squared distances bit-exact; the 17 f64 sums to
+1e-11 relative; 4x4 transforms to 2e-6 per element after one iteration, and within the
+north-star tolerance of 1e-4 Frobenius (we assert 2e-5) after multi-iteration runs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T_TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def api(rs):
+    from rsreg_amd import api as a, lib
+    lib.build()
+    if a.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return a
+
+
+def _xyz(p):
+    return np.stack([p["x"], p["y"], p["z"]], 1)
+
+
+def _ref_icp(api, src, tgt, **kw):
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(reference=True, **kw)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    return icp
+
+
+@pytest.mark.parametrize("case", ["kat_exact", "crop_parity"])
+def test_golden_stagewise_reference_params(api, rs, golden, case):
+    g = golden(case)
+    icp = _ref_icp(api, rs.PointCloud(g["src"].copy()), rs.PointCloud(g["tgt"].copy()))
+    icp.begin(g["guess"])
+    idx, d2 = icp.search()
+    gi, gd = g["ref_it0_index"], g["ref_it0_sqr_dist"]
+    np.testing.assert_array_equal(idx, gi)           # lowest-index tie-break: exact
+    np.testing.assert_array_equal(d2[gi >= 0], gd[gi >= 0])
+    s = icp.sums()
+    np.testing.assert_allclose(s, g["ref_it0_sums"], rtol=1e-12, atol=1e-12)
+    t_inc, done = icp.update(s)
+    np.testing.assert_allclose(t_inc, g["ref_it0_t_inc"], atol=T_TOL)
+    res = icp.end()
+    assert done and (res.iterations, res.state, res.converged) == tuple(g["ref_meta"])
+    np.testing.assert_allclose(api._rowmajor(res.transform), g["ref_final"], atol=T_TOL)
+
+
+def test_kat_recovers_known_transform(api, rs, golden):
+    g = golden("kat_exact")
+    icp = _ref_icp(api, rs.PointCloud(g["src"].copy()), rs.PointCloud(g["tgt"].copy()))
+    out = icp.align()
+    assert icp.hasConverged() and icp.result.iterations == 1
+    assert np.abs(icp.getFinalTransformation() - g["T_true"]).max() < 2e-6
+    assert np.abs(out.xyz - _xyz(g["tgt"])).max() < 1e-4
+    assert (out.points["w"] == 1).all()
+    np.testing.assert_array_equal(out.points["rgba"], g["src"]["rgba"])
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_golden_fixed_iterations_and_pcl_criteria(api, rs, golden, pipeline):
+    g = golden("crop_parity")
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=8, criteria_mode=1, pipeline_mode=pipeline,
+                                max_correspondence_distance=0.02, transformation_epsilon=1e-12,
+                                euclidean_fitness_epsilon=1e-12)
+    icp.setInputSource(rs.PointCloud(g["src"].copy()))
+    icp.setInputTarget(rs.PointCloud(g["tgt"].copy()))
+    icp.align(g["guess"])
+    r = icp.result
+    assert (r.iterations, r.state, r.converged) == tuple(g["fixed8_meta"])
+    np.testing.assert_allclose(icp.getFinalTransformation(), g["fixed8_final"], atol=5e-6)
+    np.testing.assert_allclose(r.mse, g["fixed8_mse"][0], rtol=1e-4)
+
+    g = golden("crop_bench")
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=30, pipeline_mode=pipeline, max_correspondence_distance=0.05,
+                                transformation_epsilon=1e-9, euclidean_fitness_epsilon=1e-7)
+    icp.setInputSource(rs.PointCloud(g["src"].copy()))
+    icp.setInputTarget(rs.PointCloud(g["tgt"].copy()))
+    icp.begin(g["guess"])
+    idx, d2 = icp.search()
+    np.testing.assert_array_equal(idx, g["pcl_it0_index"])
+    icp.end()
+    icp.align(g["guess"])
+    r = icp.result
+    assert (r.iterations, r.state, r.converged) == tuple(g["pcl_meta"])
+    np.testing.assert_allclose(icp.getFinalTransformation(), g["pcl_final"], atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def frames(rs):
+    s = rs.synth
+    return {
+        ("50k", "parity"): (s.render_frame(1, "50k", "parity"), s.render_frame(0, "50k", "parity")),
+        ("N300", "parity"): (s.render_frame(1, "N300", "parity"), s.render_frame(0, "N300", "parity")),
+        ("N300", "bench"): (s.render_frame(1, "N300", "bench"), s.render_frame(0, "N300", "bench")),
+    }
+
+
+@pytest.mark.parametrize("size", ["50k", "N300"])
+def test_vs_oracle_reference_params(api, orc, frames, size):
+    src, tgt = frames[(size, "parity")]
+    icp = _ref_icp(api, src, tgt)
+    icp.begin()
+    idx, d2 = icp.search()
+    o = orc.IcpOracle()
+    o.set_target(tgt.points, dedup=True)
+    o.set_source(src.points)
+    p = orc.IcpParams.reference()
+    o.begin(None, p)
+    oi, od = o.search()
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(d2[oi >= 0], od[oi >= 0])
+    s, so = icp.sums(), o.sums()
+    np.testing.assert_allclose(s, so, rtol=1e-11, atol=1e-11)
+    assert s[0] == so[0] > 0.5 * len(src)
+    t_inc, done = icp.update(s)
+    to, _ = o.update(so)
+    np.testing.assert_allclose(t_inc, to, atol=T_TOL)
+    res, aligned = icp.end(want_aligned=True)
+    ro, oaligned = o.end(want_aligned=True)
+    assert (res.iterations, res.state, res.converged) == (ro.iterations, ro.state, ro.converged) == (1, 2, 1)
+    np.testing.assert_allclose(api._rowmajor(res.transform), ro.T, atol=T_TOL)
+    np.testing.assert_allclose(aligned, oaligned, atol=1e-5)
+    gi = icp.grid_info()
+    assert gi.n_target_points == len(tgt) and gi.n_unique_points < gi.n_target_points  # (0,0,0) pixels collapse
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_vs_oracle_bench_mode_30_iterations(api, orc, frames, rs, pipeline):
+    """BASELINE configs[1] shape: 2 x 300k, 30 fixed iterations, 5 cm gate."""
+    src, tgt = frames[("N300", "bench")]
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=30, criteria_mode=1, pipeline_mode=pipeline,
+                                max_correspondence_distance=0.05)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    icp.align(guess)
+    o = orc.IcpOracle()
+    o.set_target(tgt.points, dedup=True)
+    o.set_source(src.points)
+    p = orc.IcpParams.default()
+    p.max_iterations, p.criteria_mode, p.max_correspondence_distance, p.num_threads = 30, 1, 0.05, 8
+    ro = o.align(guess, p)
+    r = icp.result
+    assert (r.iterations, r.state, r.converged) == (ro.iterations, ro.state, ro.converged) == (30, 1, 1)
+    err = np.linalg.norm(icp.getFinalTransformation() - ro.T)
+    assert err < 2e-5, err                              # north-star bar: 1e-4 Frobenius
+    assert abs(r.n_correspondences - ro.n_correspondences) <= 1e-4 * ro.n_correspondences
+    gt = rs.synth.ground_truth(1, 0, "bench")
+    assert np.linalg.norm(icp.getFinalTransformation() - gt) < np.linalg.norm(guess - gt)
+
+
+def test_fused_and_staged_pipelines_are_bit_identical(api, frames):
+    src, tgt = frames[("50k", "parity")]
+    out = []
+    for pipeline in (0, 1):
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(max_iterations=6, criteria_mode=1, pipeline_mode=pipeline,
+                                    max_correspondence_distance=0.02)
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        icp.align()
+        out.append((np.array(icp.result.transform), np.array(icp.result.sums_last), icp.result.n_correspondences))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+
+
+def test_run_to_run_determinism(api, frames):
+    src, tgt = frames[("N300", "parity")]
+    res = []
+    for _ in range(2):
+        icp = _ref_icp(api, src, tgt, max_iterations=4, criteria_mode=1)
+        icp.align()
+        res.append((bytes(icp.result.transform), bytes(icp.result.sums_last)))
+    assert res[0] == res[1]
+
+
+def test_source_block_sums_add_up(api, frames):
+    """What the N-GPU path relies on: the sums of source blocks add to the sums of the whole."""
+    src, tgt = frames[("50k", "parity")]
+    whole = _ref_icp(api, src, tgt)
+    whole.begin()
+    whole.search()
+    s_all = whole.sums()
+    whole.end()
+    n = len(src)
+    acc = np.zeros(17)
+    for lo, hi in ((0, n // 3), (n // 3, n // 2), (n // 2, n)):
+        part = _ref_icp(api, src.points[lo:hi], tgt)
+        part.begin()
+        part.search()
+        acc += part.sums()
+        part.end()
+    np.testing.assert_allclose(acc, s_all, rtol=1e-12, atol=1e-9)
+    assert acc[0] == s_all[0]
+
+
+def test_edge_cases(api, rs, golden):
+    g = golden("kat_exact")
+    tgt = rs.PointCloud(g["tgt"].copy())
+    src = rs.PointCloud(g["src"].copy())
+    # far apart: fewer than 3 correspondences -> not converged, identity, state NO_CORRESPONDENCES
+    far = src.copy()
+    far.points["x"] += 50.0
+    icp = _ref_icp(api, far, tgt)
+    icp.align()
+    assert not icp.hasConverged() and icp.getConvergenceState() == "NO_CORRESPONDENCES" and icp.result.iterations == 0
+    np.testing.assert_array_equal(icp.getFinalTransformation(), np.eye(4, dtype=np.float32))
+    # non-finite points on both sides are skipped
+    s2, t2 = src.copy(), tgt.copy()
+    s2.points["x"][5] = np.nan
+    t2.points["y"][7] = np.inf
+    icp = _ref_icp(api, s2, t2)
+    icp.begin()
+    idx, _ = icp.search()
+    assert idx[5] == -1 and idx[7] == -1 and (idx[[4, 6, 8]] == [4, 6, 8]).all()
+    icp.end()
+    icp.align()
+    assert np.abs(icp.getFinalTransformation() - g["T_true"]).max() < 2e-6
+    # empty source / empty target / all-invalid target
+    for s_, t_ in ((rs.PointCloud(src.points[:0].copy()), tgt), (src, rs.PointCloud(tgt.points[:0].copy()))):
+        icp = _ref_icp(api, s_, t_)
+        icp.align()
+        assert not icp.hasConverged() and icp.getConvergenceState() == "NO_CORRESPONDENCES"
+    t3 = tgt.copy()
+    t3.points["z"] = np.nan
+    icp = _ref_icp(api, src, t3)
+    icp.align()
+    assert not icp.hasConverged()
+    # max_iterations = 0 edge: PCL still runs one iteration, then reports ITERATIONS
+    icp = _ref_icp(api, src, tgt, max_iterations=0, transformation_epsilon=0.0, euclidean_fitness_epsilon=-1.0)
+    icp.align()
+    assert icp.result.iterations == 1 and icp.getConvergenceState() == "ITERATIONS"
+
+
+def test_guess_is_applied_and_composed(api, rs, golden, orc):
+    g = golden("kat_exact")
+    G = rs.synth.small_transform(0.05, (0.001, 0.0, -0.0005)).astype(np.float32)
+    icp = _ref_icp(api, rs.PointCloud(g["src"].copy()), rs.PointCloud(g["tgt"].copy()))
+    icp.align(G)
+    o = orc.IcpOracle()
+    o.set_target(g["tgt"])
+    o.set_source(g["src"])
+    r = o.align(G, orc.IcpParams.reference())
+    np.testing.assert_allclose(icp.getFinalTransformation(), r.T, atol=T_TOL)
+    assert np.abs(icp.getFinalTransformation() - g["T_true"]).max() < 3e-6
+
+
+def test_unbounded_gate_matches_brute_force(api, rs, orc):
+    """PCL's default gate is sqrt(DBL_MAX): the ring search must stay exact without one."""
+    rng = np.random.default_rng(3)
+    tgt = (rng.random((3000, 3)).astype(np.float32) * 2 - 1)
+    src = (rng.random((2000, 3)).astype(np.float32) * 2.6 - 1.3)
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=3, criteria_mode=1)
+    icp.setInputSource(np.ascontiguousarray(src))
+    icp.setInputTarget(np.ascontiguousarray(tgt))
+    icp.begin()
+    idx, d2 = icp.search()
+    icp.end()
+    o = orc.IcpOracle()
+    o.set_target(tgt)
+    o.set_source(src)
+    p = orc.IcpParams.default()
+    p.nn_mode = 1
+    o.begin(None, p)
+    oi, od = o.search()
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(d2, od)
+
+
+def test_transform_point_cloud(api, rs, orc, golden):
+    g = golden("crop_parity")
+    T = g["ref_final"]
+    c = rs.PointCloud(g["src"].copy(), is_dense=False)
+    c.points["x"][3] = np.nan
+    out = api.transformPointCloud(c, T)
+    exp = orc.transform_cloud(c.points, T, is_dense=False)
+    for f in ("x", "y", "z", "w", "rgba"):
+        np.testing.assert_array_equal(out.points[f], exp[f])
+    assert (out.width, out.height) == (c.width, c.height)
+
+
+@pytest.mark.parametrize("size", ["N1M"])
+def test_full_size_properties(api, rs, size):
+    """BASELINE full size (1M <-> 1M): size-independent properties, no oracle needed."""
+    tgt = rs.synth.render_frame(0, size, "parity")
+    # (1) a cloud registered against itself: every finite point matches at distance 0, T = I
+    icp = _ref_icp(api, tgt, tgt)
+    icp.begin()
+    idx, d2 = icp.search()
+    s = icp.sums()
+    icp.end()
+    assert (d2 == 0).all() and (idx >= 0).all() and s[0] == len(tgt) and s[16] == 0
+    xyz = tgt.xyz
+    np.testing.assert_array_equal(xyz[idx], xyz)            # matched coordinates are the point itself
+    nz = tgt.points["z"] != 0
+    np.testing.assert_array_equal(idx[nz], np.nonzero(nz)[0])  # unique points match themselves
+    assert (idx[~nz] == np.nonzero(~nz)[0][0]).all()        # duplicates -> lowest index copy
+    np.testing.assert_allclose(api.umeyama_from_sums(s), np.eye(4), atol=1e-6)
+    # (2) exactly moved copy of the valid points: one iteration recovers the motion
+    T = rs.synth.small_transform(0.005, (0.0002, -0.0001, 0.00015))
+    base = rs.PointCloud(np.ascontiguousarray(tgt.points[nz]))
+    moved = base.copy()
+    p64 = base.xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    moved.points["x"], moved.points["y"], moved.points["z"] = p64[:, 0], p64[:, 1], p64[:, 2]
+    icp = _ref_icp(api, base, moved)
+    icp.begin()
+    idx, _ = icp.search()
+    icp.end()
+    assert (idx == np.arange(len(base))).mean() > 0.999
+    icp.align()
+    assert icp.hasConverged() and icp.result.iterations == 1
+    assert np.abs(icp.getFinalTransformation() - T).max() < 2e-5

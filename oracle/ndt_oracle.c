@@ -49,6 +49,7 @@ struct orc_ndt {
     double d1, d2;
     double jang[8][3], hang[15][3];
     int passes;
+    int centroid_mode; /* 0: PCL's f32 running sum / n; 1: the f64 mean rounded to f32 (what the HIP path stores) */
 };
 
 void orc_ndt_params_default(orc_ndt_params *p)
@@ -72,6 +73,7 @@ void orc_ndt_params_reference(orc_ndt_params *p)
 }
 
 orc_ndt *orc_ndt_create(void) { return (orc_ndt *)calloc(1, sizeof(orc_ndt)); }
+void orc_ndt_set_centroid_mode(orc_ndt *o, int mode) { o->centroid_mode = mode; }
 void orc_ndt_destroy(orc_ndt *o)
 {
     if (!o) return;
@@ -155,8 +157,8 @@ int orc_ndt_set_target(orc_ndt *o, const void *pts, size_t n, size_t stride, int
             }
             double nn = (double)cnt;
             for (int d = 0; d < 3; d++) {
-                lf->centroid[d] = lf->csum[d] / (float)cnt;
                 lf->mean[d] = lf->sum[d] / nn;
+                lf->centroid[d] = o->centroid_mode ? (float)lf->mean[d] : lf->csum[d] / (float)cnt;
             }
             for (int r = 0; r < 3; r++)
                 for (int c = 0; c < 3; c++)

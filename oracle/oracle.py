@@ -113,6 +113,8 @@ def lib():
         L.orc_approx_voxel_grid.argtypes = [vp, sz, sz, vp, vp, C.POINTER(sz)]
         L.orc_ndt_create.restype = vp
         L.orc_ndt_destroy.argtypes = [vp]
+        L.orc_ndt_set_centroid_mode.argtypes = [vp, i32]
+        L.orc_ndt_set_centroid_mode.restype = None
         L.orc_ndt_set_target.argtypes = [vp, vp, sz, sz, i32, dbl]
         L.orc_ndt_get_voxels.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, C.c_int32]
         L.orc_ndt_derivatives.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(dbl), vp, vp]
@@ -218,6 +220,9 @@ class NdtOracle:
         if getattr(self, "_h", None):
             lib().orc_ndt_destroy(self._h)
             self._h = None
+
+    def set_centroid_mode(self, mode):
+        lib().orc_ndt_set_centroid_mode(self._h, int(mode))
 
     def set_target(self, pts, resolution, is_dense=False):
         a, p, n, s = _pts(pts)

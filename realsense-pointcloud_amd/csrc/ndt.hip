@@ -1,21 +1,652 @@
-// ndt.hip — NDT half of the C ABI (placeholder until the kernel set lands).
-#include "rsreg_ctx.hpp"
+// ndt.hip — NDT half of the C ABI (include/rsreg.h): pcl::NormalDistributionsTransform as
+// the reference drives it (src/ndt_edge_based_registration.hpp:38-43,71-72,83,92,104).
+//
+// Device: voxel binning, per-voxel moments, the per-point derivative pass (ndt_kernels.hpp).
+// Host:   covariance regularisation + inversion per voxel (tens to hundreds of 3x3s), the
+//         Newton step (6x6 SVD solve) and the More-Thuente line search.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "ndt_kernels.hpp"
+
 using namespace rsreg;
+
+extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int count);  // comm.cpp
+
+namespace {
+
+constexpr int kPassBlocks = 256;  // fixed: the summation order does not depend on the GPU
+constexpr int kMinPointsPerVoxel = 6;
+constexpr double kMinCovarEigMult = 0.01;
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// order-preserving float <-> uint map (same as the ICP build's)
+__device__ __forceinline__ uint32_t f2o(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+float o2f(uint32_t u)
+{
+    uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void k_ndt_bbox(const char *pts, size_t stride, uint32_t n, uint32_t *bbox)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *p = reinterpret_cast<const float *>(pts + (size_t)i * stride);
+        const float x = p[0], y = p[1], z = p[2];
+        if (ndt_finite3(x, y, z)) {
+            mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+            mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+            ++cnt;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
+        }
+        cnt += __shfl_down(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bbox[k], f2o(mn[k]));
+            atomicMax(&bbox[3 + k], f2o(mx[k]));
+        }
+        atomicAdd(&bbox[6], cnt);
+    }
+}
+
+struct Pose {
+    double p[6];
+};
+
+// Translation(p0..2) * Rx(p3) * Ry(p4) * Rz(p5) assembled in f32 (PCL builds it with
+// Eigen::Translation<float> * AngleAxis<float> products)
+Mat4f pose_matrix(const double *p)
+{
+    const float ax = (float)p[3], ay = (float)p[4], az = (float)p[5];
+    const float cx = std::cos(ax), sx = std::sin(ax), cy = std::cos(ay), sy = std::sin(ay), cz = std::cos(az), sz = std::sin(az);
+    Mat4f Rx = Mat4f::identity(), Ry = Mat4f::identity(), Rz = Mat4f::identity(), Tr = Mat4f::identity();
+    Rx(1, 1) = cx; Rx(1, 2) = -sx; Rx(2, 1) = sx; Rx(2, 2) = cx;
+    Ry(0, 0) = cy; Ry(0, 2) = sy; Ry(2, 0) = -sy; Ry(2, 2) = cy;
+    Rz(0, 0) = cz; Rz(0, 1) = -sz; Rz(1, 0) = sz; Rz(1, 1) = cz;
+    Tr(0, 3) = (float)p[0]; Tr(1, 3) = (float)p[1]; Tr(2, 3) = (float)p[2];
+    return mul(mul(mul(Tr, Rx), Ry), Rz);
+}
+
+// Eigen 3.3 Matrix3f::eulerAngles(0, 1, 2)
+void euler_xyz(const Mat4f &M, float *res)
+{
+    const float kPi = 3.14159265358979323846f;
+    res[0] = std::atan2(M(1, 2), M(2, 2));
+    const float c2 = std::sqrt(M(0, 0) * M(0, 0) + M(0, 1) * M(0, 1));
+    if (res[0] > 0.0f) {
+        res[0] -= kPi;
+        res[1] = std::atan2(-M(0, 2), -c2);
+    } else {
+        res[1] = std::atan2(-M(0, 2), c2);
+    }
+    const float s1 = std::sin(res[0]), c1 = std::cos(res[0]);
+    res[2] = std::atan2(s1 * M(2, 0) - c1 * M(1, 0), c1 * M(1, 1) - s1 * M(2, 1));
+    res[0] = -res[0]; res[1] = -res[1]; res[2] = -res[2];
+}
+
+void gauss_constants(const rsreg_ndt_params &prm, double &d1, double &d2)
+{
+    const double c1 = 10.0 * (1 - prm.outlier_ratio);
+    const double c2 = prm.outlier_ratio / std::pow(prm.resolution, 3);
+    const double d3 = -std::log(c2);
+    d1 = -std::log(c1 + c2) - d3;
+    d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / d1);
+}
+
+// computeAngleDerivatives (Magnusson 2009 eq. 6.19 / 6.21), with PCL's small-angle snap
+void angle_terms(const double *p, NdtPassParams &pp)
+{
+    double cx, cy, cz, sx, sy, sz;
+    if (std::fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p[3]); sx = std::sin(p[3]); }
+    if (std::fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p[4]); sy = std::sin(p[4]); }
+    if (std::fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p[5]); sz = std::sin(p[5]); }
+    auto set = [](double *v, double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; };
+    set(pp.jang[0], -sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy);
+    set(pp.jang[1], cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy);
+    set(pp.jang[2], -sy * cz, sy * sz, cy);
+    set(pp.jang[3], sx * cy * cz, -sx * cy * sz, sx * sy);
+    set(pp.jang[4], -cx * cy * cz, cx * cy * sz, -cx * sy);
+    set(pp.jang[5], -cy * sz, -cy * cz, 0);
+    set(pp.jang[6], cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0);
+    set(pp.jang[7], sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0);
+    set(pp.hang[0], -cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy);
+    set(pp.hang[1], -sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy);
+    set(pp.hang[2], cx * cy * cz, -cx * cy * sz, cx * sy);
+    set(pp.hang[3], sx * cy * cz, -sx * cy * sz, sx * sy);
+    set(pp.hang[4], -sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0);
+    set(pp.hang[5], cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0);
+    set(pp.hang[6], -cy * cz, cy * sz, sy);
+    set(pp.hang[7], -sx * sy * cz, sx * sy * sz, sx * cy);
+    set(pp.hang[8], cx * sy * cz, -cx * sy * sz, -cx * cy);
+    set(pp.hang[9], sy * sz, sy * cz, 0);
+    set(pp.hang[10], -sx * cy * sz, -sx * cy * cz, 0);
+    set(pp.hang[11], cx * cy * sz, cx * cy * cz, 0);
+    set(pp.hang[12], -cy * cz, cy * sz, 0);
+    set(pp.hang[13], -cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0);
+    set(pp.hang[14], -sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0);
+}
+
+struct NdtRun {
+    rsreg_ctx *ctx;
+    rsreg_ndt_params prm;
+    uint32_t n;
+    double d1, d2;
+    Mat4f final_t;
+    int passes = 0;
+    double ms_derivatives = 0;
+};
+
+// One derivative pass at pose p with transform M; mode as in NdtPassParams.
+// On return grad (6) / hess (36, symmetric) hold the requested parts; returns the score.
+int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool store_trans, double *score,
+                    double *grad, double *hess)
+{
+    rsreg_ctx *ctx = r.ctx;
+    NdtPassParams pp;
+    for (int row = 0; row < 3; ++row)
+        for (int c = 0; c < 4; ++c) pp.M[row * 4 + c] = M(row, c);
+    angle_terms(p, pp);
+    pp.d1 = r.d1;
+    pp.d2 = r.d2;
+    pp.r2 = (float)(r.prm.resolution * r.prm.resolution);
+    pp.n_vox = ctx->ndt_n_voxels;
+    pp.mode = mode;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profiling) {
+        if (ctx->ev_pool.size() < 2) {
+            ctx->ev_pool.resize(2);
+            (void)hipEventCreate(&ctx->ev_pool[0]);
+            (void)hipEventCreate(&ctx->ev_pool[1]);
+        }
+        e0 = ctx->ev_pool[0];
+        e1 = ctx->ev_pool[1];
+        (void)hipEventRecord(e0, ctx->stream);
+    }
+    k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
+                                                           store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
+                                                           ctx->d_ndt_partials.as<double>());
+    RSREG_HIP(ctx, hipGetLastError());
+    k_ndt_final_reduce<<<1, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks, ctx->d_ndt_out.as<double>());
+    RSREG_HIP(ctx, hipGetLastError());
+    if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
+    if (ctx->nranks > 1) {
+        int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_ndt_out.as<double>(), kNdtAcc);
+        if (rc) return rc;
+    }
+    double *h = ctx->h_ndt.as<double>();
+    RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_ndt_out.ptr, kNdtAcc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) r.ms_derivatives += ms;
+    }
+    r.passes++;
+    if (mode != 2) {
+        *score = h[0];
+        for (int i = 0; i < 6; ++i) grad[i] = h[1 + i];
+    }
+    for (int k = 0; k < 36; ++k) hess[k] = 0.0;  // PCL zeroes the Hessian at the start of every pass
+    if (mode != 1) {
+        int k = 7;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) {
+                hess[a * 6 + b] = h[k];
+                hess[b * 6 + a] = h[k];
+                ++k;
+            }
+    }
+    return RSREG_OK;
+}
+
+// More-Thuente helpers (ndt.hpp auxilaryFunction_PsiMT / dPsiMT, updateIntervalMT, trialValueSelectionMT)
+double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+bool update_interval(double &a_l, double &f_l, double &g_l, double &a_u, double &f_u, double &g_u, double a_t, double f_t,
+                     double g_t)
+{
+    if (f_t > f_l) {
+        a_u = a_t; f_u = f_t; g_u = g_t;
+        return false;
+    }
+    if (g_t * (a_l - a_t) > 0) {
+        a_l = a_t; f_l = f_t; g_l = g_t;
+        return false;
+    }
+    if (g_t * (a_l - a_t) < 0) {
+        a_u = a_l; f_u = f_l; g_u = g_l;
+        a_l = a_t; f_l = f_t; g_l = g_t;
+        return false;
+    }
+    return true;
+}
+
+double cubic_min(double a_1, double f_1, double g_1, double a_t, double f_t, double g_t)
+{
+    const double z = 3 * (f_t - f_1) / (a_t - a_1) - g_t - g_1;
+    const double w = std::sqrt(z * z - g_t * g_1);
+    return a_1 + (a_t - a_1) * (w - g_1 - z) / (g_t - g_1 + 2 * w);
+}
+
+double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
+{
+    if (f_t > f_l) {  // case 1
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+    }
+    if (g_t * g_l < 0) {  // case 2
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
+    }
+    if (std::fabs(g_t) <= std::fabs(g_l)) {  // case 3
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double a_next = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
+        return a_t > a_l ? std::min(a_t + 0.66 * (a_u - a_t), a_next) : std::max(a_t + 0.66 * (a_u - a_t), a_next);
+    }
+    return cubic_min(a_u, f_u, g_u, a_t, f_t, g_t);  // case 4
+}
+
+// computeStepLengthMT
+int step_length(NdtRun &r, const double *x, double *dir, double step_init, double step_max, double step_min,
+                double &score, double *grad, double *hess, double &a_out)
+{
+    const double phi_0 = -score;
+    double d_phi_0 = 0;
+    for (int i = 0; i < 6; ++i) d_phi_0 -= grad[i] * dir[i];
+    if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) { a_out = 0; return RSREG_OK; }
+        d_phi_0 = -d_phi_0;
+        for (int i = 0; i < 6; ++i) dir[i] = -dir[i];
+    }
+    const int max_step_iterations = 10;
+    int step_iterations = 0;
+    const double mu = 1.e-4, nu = 0.9;
+    double a_l = 0, a_u = 0;
+    double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
+    double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
+    bool interval_converged = (step_max - step_min) < 0, open_interval = true;
+    double a_t = std::max(std::min(step_init, step_max), step_min);
+    double x_t[6];
+    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+    r.final_t = pose_matrix(x_t);
+    int rc = derivative_pass(r, x_t, r.final_t, 0, true, &score, grad, hess);
+    if (rc) return rc;
+    double phi_t = -score, d_phi_t = 0;
+    for (int i = 0; i < 6; ++i) d_phi_t -= grad[i] * dir[i];
+    double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+    while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        a_t = open_interval ? trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
+                            : trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        a_t = std::max(std::min(a_t, step_max), step_min);
+        for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+        r.final_t = pose_matrix(x_t);
+        rc = derivative_pass(r, x_t, r.final_t, 1, true, &score, grad, hess);
+        if (rc) return rc;
+        phi_t = -score;
+        d_phi_t = 0;
+        for (int i = 0; i < 6; ++i) d_phi_t -= grad[i] * dir[i];
+        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
+        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+            open_interval = false;
+            f_l = f_l + phi_0 - mu * d_phi_0 * a_l;
+            g_l = g_l + mu * d_phi_0;
+            f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
+            g_u = g_u + mu * d_phi_0;
+        }
+        interval_converged = open_interval ? update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
+                                           : update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        ++step_iterations;
+    }
+    if (step_iterations) {
+        double dummy;
+        rc = derivative_pass(r, x_t, r.final_t, 2, false, &dummy, grad, hess);
+        if (rc) return rc;
+    }
+    a_out = a_t;
+    return RSREG_OK;
+}
+
+int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
+{
+    RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
+    float *dst = ctx->h_stage.as<float>();
+    const char *src = static_cast<const char *>(source);
+    for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+    RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
+    RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
+    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
+    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    if (n) {
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.ptr, dst, n * 12, hipMemcpyHostToDevice, ctx->stream));
+        k_ndt_load_source<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(ctx->d_tmp.as<char>(), 12, (uint32_t)n,
+                                                                                        ctx->d_ndt_src.as<float4>());
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RSREG_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
 void rsreg_ndt_params_default(rsreg_ndt_params *p)
 {
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
-    p->max_iterations = 35; p->transformation_epsilon = 0.1; p->step_size = 0.1; p->resolution = 1.0; p->outlier_ratio = 0.55;
+    p->max_iterations = 35;
+    p->transformation_epsilon = 0.1;
+    p->step_size = 0.1;
+    p->resolution = 1.0;
+    p->outlier_ratio = 0.55;
 }
+
 void rsreg_ndt_params_reference(rsreg_ndt_params *p)
 {
     if (!p) return;
     rsreg_ndt_params_default(p);
-    p->transformation_epsilon = 0.01; p->step_size = 0.1; p->resolution = 1.0; p->max_iterations = 50;
+    p->transformation_epsilon = 0.01;  // ndt_edge_based_registration.hpp:39
+    p->step_size = 0.1;                // :40
+    p->resolution = 1.0;               // :41
+    p->max_iterations = 50;            // :43
 }
-int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *, size_t, size_t, int, double) { return fail(ctx, RSREG_ERR_STATE, "NDT not built yet"); }
-int rsreg_ndt_align(rsreg_ctx *ctx, const void *, size_t, size_t, int, const float *, const rsreg_ndt_params *, rsreg_ndt_result *, void *, size_t) { return fail(ctx, RSREG_ERR_STATE, "NDT not built yet"); }
-int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *, size_t, size_t, int, const double *, double *, double *, double *) { return fail(ctx, RSREG_ERR_STATE, "NDT not built yet"); }
-int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *, double *, int32_t *, int32_t) { return fail(ctx, RSREG_ERR_STATE, "NDT not built yet"); }
+
+int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense, double resolution)
+{
+    (void)is_dense;
+    if (!ctx || (n && !points) || stride < 12 || !(resolution > 0)) return RSREG_ERR_INVALID_ARG;
+    if (n > 0xfffffff0ull) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ctx->have_ndt_target = false;
+    ctx->ndt_n_voxels = 0;
+    ctx->ndt_resolution = resolution;
+    ctx->ndt_mean_cov_icov.clear();
+    ctx->ndt_counts.clear();
+    ctx->ndt_centroid.clear();
+
+    // ---- upload xyz, bounding box of the finite points (pcl::getMinMax3D)
+    RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
+    {
+        float *dst = ctx->h_stage.as<float>();
+        const char *src = static_cast<const char *>(points);
+        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+    }
+    RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
+    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * 4));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    const char *d_pts = ctx->d_tgt_raw.as<char>();
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_misc = ctx->h_ndt.as<uint32_t>();
+    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
+    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
+    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, 64, hipMemcpyHostToDevice, st));
+    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    h_misc[6] = 0;
+    if (n) {
+        k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 1024), 256, 0, st>>>(d_pts, 12, (uint32_t)n, d_misc);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
+        RSREG_HIP(ctx, hipStreamSynchronize(st));
+    }
+    const uint32_t nfin = h_misc[6];
+    if (nfin == 0) {
+        ctx->have_ndt_target = true;
+        RSREG_HIP(ctx, ctx->d_ndt_vox.reserve(sizeof(NdtVoxel)));
+        return RSREG_OK;
+    }
+    NdtBinParams bp;
+    const float leaf = (float)resolution;
+    bp.inv_leaf = 1.0f / leaf;
+    int div_b[3];
+    for (int k = 0; k < 3; ++k) {
+        volatile float lo = o2f(h_misc[k]) * bp.inv_leaf, hi = o2f(h_misc[3 + k]) * bp.inv_leaf;
+        bp.min_b[k] = (int)std::floor(lo);
+        div_b[k] = (int)std::floor(hi) - bp.min_b[k] + 1;
+    }
+    bp.mul[0] = 1;
+    bp.mul[1] = div_b[0];
+    bp.mul[2] = (long long)div_b[0] * div_b[1];
+
+    // ---- bin: key per point, sort, segment
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
+    auto *keys = ctx->d_keys.as<unsigned long long>();
+    auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
+    auto *vals = ctx->d_vals.as<uint32_t>();
+    auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
+    uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_cellpos.as<uint32_t>();
+    k_ndt_keys<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, 12, (uint32_t)n, bp, keys, vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    size_t sort_bytes = 0, scan_bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
+    k_ndt_flag_starts<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    k_ndt_seg_offsets<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(start, sid, nfin, seg_begin, d_misc + 8);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t nseg = h_misc[8];
+
+    // ---- per-voxel moments on the device, one block per occupied leaf
+    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * 10 * 8, 64 * 8)));
+    k_ndt_voxel_stats<<<nseg, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, 12, ctx->d_ndt_out.as<double>());
+    RSREG_HIP(ctx, hipGetLastError());
+    std::vector<double> stats((size_t)nseg * 10);
+    RSREG_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->d_ndt_out.ptr, stats.size() * 8, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+
+    // ---- host: mean, single-pass covariance, eigenvalue floor, inverse (App. A.6)
+    std::vector<NdtVoxel> table;
+    for (uint32_t v = 0; v < nseg; ++v) {
+        const double *s = &stats[(size_t)v * 10];
+        const int cnt = (int)(s[0] + 0.5);
+        if (cnt < kMinPointsPerVoxel) continue;
+        const double nn = cnt;
+        const double sum[3] = {s[1], s[2], s[3]};
+        const double sxx[9] = {s[4], s[5], s[6], s[5], s[7], s[8], s[6], s[8], s[9]};
+        double mean[3], cov[9], icov[9];
+        for (int k = 0; k < 3; ++k) mean[k] = sum[k] / nn;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                cov[r * 3 + c] = (sxx[r * 3 + c] - 2.0 * (sum[r] * mean[c])) / nn + mean[r] * mean[c];
+        for (int k = 0; k < 9; ++k) cov[k] *= (nn - 1.0) / nn;
+        double sym[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) sym[r * 3 + c] = r >= c ? cov[r * 3 + c] : cov[c * 3 + r];
+        double ev[3], evec[9];
+        eig_sym3(sym, ev, evec);
+        std::memset(icov, 0, sizeof(icov));
+        if (!(ev[0] < 0 || ev[1] < 0 || ev[2] <= 0)) {
+            const double floor_ev = kMinCovarEigMult * ev[2];
+            if (ev[0] < floor_ev) {
+                ev[0] = floor_ev;
+                if (ev[1] < floor_ev) ev[1] = floor_ev;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        double acc = 0;
+                        for (int k = 0; k < 3; ++k) acc += evec[r * 3 + k] * ev[k] * evec[c * 3 + k];
+                        cov[r * 3 + c] = acc;
+                    }
+            }
+            if (!inv3(cov, icov)) std::memset(icov, 0, sizeof(icov));
+        }
+        NdtVoxel nv;
+        std::memset(&nv, 0, sizeof(nv));
+        for (int k = 0; k < 3; ++k) {
+            nv.mean[k] = mean[k];
+            nv.centroid[k] = (float)mean[k];  // PCL: f32 running sum / n; here the f64 mean rounded
+        }
+        std::memcpy(nv.icov, icov, sizeof(icov));
+        table.push_back(nv);
+        ctx->ndt_counts.push_back(cnt);
+        ctx->ndt_mean_cov_icov.insert(ctx->ndt_mean_cov_icov.end(), mean, mean + 3);
+        ctx->ndt_mean_cov_icov.insert(ctx->ndt_mean_cov_icov.end(), cov, cov + 9);
+        ctx->ndt_mean_cov_icov.insert(ctx->ndt_mean_cov_icov.end(), icov, icov + 9);
+        for (int k = 0; k < 3; ++k) ctx->ndt_centroid.push_back(nv.centroid[k]);
+    }
+    ctx->ndt_n_voxels = (int)table.size();
+    RSREG_HIP(ctx, ctx->d_ndt_vox.reserve(std::max<size_t>(table.size(), 1) * sizeof(NdtVoxel)));
+    if (!table.empty()) {
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_ndt_vox.ptr, table.data(), table.size() * sizeof(NdtVoxel), hipMemcpyHostToDevice, st));
+        RSREG_HIP(ctx, hipStreamSynchronize(st));
+    }
+    ctx->have_ndt_target = true;
+    return RSREG_OK;
 }
+
+int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_icov, int32_t *counts, int32_t capacity)
+{
+    if (!ctx || !n_voxels) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
+    *n_voxels = ctx->ndt_n_voxels;
+    const int m = std::min<int>(capacity, ctx->ndt_n_voxels);
+    if (mean_cov_icov && m > 0) std::memcpy(mean_cov_icov, ctx->ndt_mean_cov_icov.data(), (size_t)m * 21 * 8);
+    if (counts && m > 0) std::memcpy(counts, ctx->ndt_counts.data(), (size_t)m * 4);
+    return RSREG_OK;
+}
+
+int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *source, size_t n, size_t stride, int is_dense, const double pose[6],
+                          double *score, double gradient[6], double hessian[36])
+{
+    (void)is_dense;
+    if (!ctx || (n && !source) || stride < 12 || !pose || !score || !gradient || !hessian) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = load_ndt_source(ctx, source, n, stride);
+    if (rc) return rc;
+    NdtRun r;
+    r.ctx = ctx;
+    rsreg_ndt_params_default(&r.prm);
+    r.prm.resolution = ctx->ndt_resolution;
+    r.n = (uint32_t)n;
+    gauss_constants(r.prm, r.d1, r.d2);
+    return derivative_pass(r, pose, pose_matrix(pose), 0, false, score, gradient, hessian);
+}
+
+int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride, int is_dense, const float *guess,
+                    const rsreg_ndt_params *params, rsreg_ndt_result *result, void *aligned_out, size_t out_stride)
+{
+    (void)is_dense;
+    if (!ctx || !params || (n && !source) || stride < 12) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
+    if (aligned_out && out_stride < 12) return RSREG_ERR_INVALID_ARG;
+    if (std::fabs(params->resolution - ctx->ndt_resolution) > 0)
+        return fail(ctx, RSREG_ERR_INVALID_ARG, "resolution differs from the one the NDT target was built with");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = load_ndt_source(ctx, source, n, stride);
+    if (rc) return rc;
+
+    NdtRun r;
+    r.ctx = ctx;
+    r.prm = *params;
+    r.n = (uint32_t)n;
+    gauss_constants(r.prm, r.d1, r.d2);
+    r.final_t = Mat4f::identity();
+    if (guess) {
+        Mat4f G;
+        std::memcpy(G.m, guess, 64);
+        if (!G.is_identity()) r.final_t = G;
+    }
+    float er[3];
+    euler_xyz(r.final_t, er);
+    double p[6] = {r.final_t(0, 3), r.final_t(1, 3), r.final_t(2, 3), er[0], er[1], er[2]};
+    double delta_p[6], grad[6], hess[36], score = 0;
+    int nr_iterations = 0, converged = 0;
+    // first pass on the guess-transformed cloud: the cloud is moved by the guess MATRIX, the
+    // angle terms come from its Euler angles (ndt.hpp computeTransformation)
+    rc = derivative_pass(r, p, r.final_t, 0, true, &score, grad, hess);
+    if (rc) return rc;
+    while (!converged) {
+        double neg_g[6];
+        for (int i = 0; i < 6; ++i) neg_g[i] = -grad[i];
+        svd_solve<6>(hess, neg_g, delta_p);
+        double nrm = 0;
+        for (int i = 0; i < 6; ++i) nrm += delta_p[i] * delta_p[i];
+        nrm = std::sqrt(nrm);
+        if (nrm == 0 || nrm != nrm) {
+            converged = (nrm == nrm) ? 1 : 0;
+            break;
+        }
+        for (int i = 0; i < 6; ++i) delta_p[i] /= nrm;
+        double a = 0;
+        rc = step_length(r, p, delta_p, nrm, params->step_size, params->transformation_epsilon / 2, score, grad, hess, a);
+        if (rc) return rc;
+        nrm = a;
+        for (int i = 0; i < 6; ++i) {
+            delta_p[i] *= nrm;
+            p[i] += delta_p[i];
+        }
+        if (nr_iterations > params->max_iterations || (nr_iterations && (std::fabs(nrm) < params->transformation_epsilon)))
+            converged = 1;
+        ++nr_iterations;
+    }
+    if (aligned_out && n) {  // output cloud = the cloud at the last evaluated pose
+        RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_ndt_trans.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const float *xyz = ctx->h_stage.as<float>();
+        const char *in = static_cast<const char *>(source);
+        char *dst = static_cast<char *>(aligned_out);
+        const float one = 1.0f;
+        for (size_t i = 0; i < n; ++i) {
+            float q[3];
+            std::memcpy(q, in + i * stride, 12);
+            const bool ok = std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]);
+            std::memcpy(dst + i * out_stride, ok ? xyz + 3 * i : q, 12);
+            if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
+        }
+    }
+    if (result) {
+        std::memset(result, 0, sizeof(*result));
+        std::memcpy(result->transform, r.final_t.m, 64);
+        result->converged = converged;
+        result->iterations = nr_iterations;
+        result->score = score;
+        result->trans_probability = score / (double)(n ? n : 1);
+        result->n_voxels = ctx->ndt_n_voxels;
+        result->n_derivative_passes = r.passes;
+        result->ms_derivatives = r.ms_derivatives;
+        result->ms_total = r.ms_derivatives;
+    }
+    return RSREG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// ndt_kernels.hpp — device code of the NDT path (gfx950, wave64).  Included by ndt.hip only.
+//
+// Second kernel set of the engine (north star): voxel-grid binning + per-voxel mean and
+// covariance of the target (pcl::VoxelGridCovariance::applyFilter) and the
+// per-point score / gradient / Hessian pass of pcl::NormalDistributionsTransform
+// (computeDerivatives / updateDerivatives / computeHessian, App. A.7).
+// Reference call sites: src/ndt_edge_based_registration.hpp:38-43,71-72,83,92.
+// All statistics and derivatives are f64 like PCL's; none of this is a dense contraction, so
+// MFMA is unused: the pass is f64-VALU work over an LDS-resident voxel table.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "rsreg_ctx.hpp"
+
+namespace rsreg {
+
+constexpr int kNdtBlock = 256;
+constexpr int kNdtAcc = 28;        // score + 6 gradient + 21 upper-triangle Hessian entries
+constexpr int kNdtVoxChunk = 256;  // voxels staged through LDS per pass over the table
+constexpr int kNdtStatBlocks = 1;  // (per voxel) one block reduces one voxel's points
+
+struct NdtVoxel {        // 128 B, device voxel table entry
+    double mean[3];
+    double icov[9];
+    float centroid[3];
+    float pad;
+    double pad2;
+};
+
+struct NdtBinParams {
+    float inv_leaf;
+    int min_b[3];
+    long long mul[3];
+};
+
+struct NdtPassParams {
+    float M[12];          // rows of the 3x4 pose matrix (f32, like PCL's transformPointCloud)
+    double jang[8][3];    // j_ang_a .. j_ang_h
+    double hang[15][3];   // h_ang_a2 .. h_ang_f3
+    double d1, d2;
+    float r2;             // resolution^2 as float (radiusSearch)
+    int n_vox;
+    int mode;             // 0 score+gradient+Hessian, 1 score+gradient, 2 Hessian only
+};
+
+__device__ __forceinline__ bool ndt_finite3(float x, float y, float z)
+{
+    return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// leaf key = ijk0 + ijk1*div0 + ijk2*div0*div1, ijk = floor(p*inv_leaf) - min_b (PCL formula)
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_keys(const char *pts, size_t stride, uint32_t n, NdtBinParams bp,
+                                                        unsigned long long *keys, uint32_t *vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = reinterpret_cast<const float *>(pts + (size_t)i * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    unsigned long long key = ~0ull;
+    if (ndt_finite3(x, y, z)) {
+        const int i0 = (int)(floorf(__fmul_rn(x, bp.inv_leaf)) - (float)bp.min_b[0]);
+        const int i1 = (int)(floorf(__fmul_rn(y, bp.inv_leaf)) - (float)bp.min_b[1]);
+        const int i2 = (int)(floorf(__fmul_rn(z, bp.inv_leaf)) - (float)bp.min_b[2]);
+        key = (unsigned long long)((long long)i0 * bp.mul[0] + (long long)i1 * bp.mul[1] + (long long)i2 * bp.mul[2]);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_flag_starts(const unsigned long long *keys, uint32_t nfin, uint32_t *start)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfin) return;
+    start[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_seg_offsets(const uint32_t *start, const uint32_t *sid, uint32_t nfin,
+                                                               uint32_t *seg_begin, uint32_t *counts /*[1]*/)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfin) return;
+    if (start[i]) seg_begin[sid[i]] = i;
+    if (i == nfin - 1) {
+        const uint32_t ns = sid[i] + start[i];
+        counts[0] = ns;
+        seg_begin[ns] = nfin;
+    }
+}
+
+// One block per voxel: n, sum p (3), sum p p^T (6 unique) in f64, fixed reduction order.
+// out[v*10 + k]: 0 n, 1..3 sum, 4..9 xx xy xz yy yz zz
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_voxel_stats(const uint32_t *vals, const uint32_t *seg_begin,
+                                                               const char *pts, size_t stride, double *out)
+{
+    const uint32_t v = blockIdx.x;
+    const uint32_t b = seg_begin[v], e = seg_begin[v + 1];
+    double a[9];
+    for (int k = 0; k < 9; ++k) a[k] = 0.0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const float *p = reinterpret_cast<const float *>(pts + (size_t)vals[i] * stride);
+        const double x = p[0], y = p[1], z = p[2];
+        a[0] += x; a[1] += y; a[2] += z;
+        a[3] += x * x; a[4] += x * y; a[5] += x * z;
+        a[6] += y * y; a[7] += y * z; a[8] += z * z;
+    }
+    __shared__ double sh[kNdtBlock / 64][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 9; ++k) {
+        double s = a[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) sh[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double s = sh[0][threadIdx.x];
+        for (int w = 1; w < kNdtBlock / 64; ++w) s += sh[w][threadIdx.x];
+        out[(size_t)v * 10 + 1 + threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) out[(size_t)v * 10] = (double)(e - b);
+}
+
+__device__ __forceinline__ double dot3d(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// One derivative pass: transform each source point by the pose (f32, PCL op order), find the
+// voxels whose centroid is within the resolution (f32 L2_Simple, strict <), accumulate
+// score / gradient / Hessian in f64.  Voxel table chunks are staged through LDS.
+// partials[block][28]: 0 score, 1..6 gradient, 7..27 Hessian upper triangle (row-major i<=j)
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp,
+                                                        float *trans_out, double *partials)
+{
+    __shared__ NdtVoxel sv[kNdtVoxChunk];
+    __shared__ double sh[kNdtBlock / 64][kNdtAcc];
+    double acc[kNdtAcc];
+    for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
+
+    const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per_block;
+    const uint32_t hi = min(n, lo + per_block);
+
+    for (int c0 = 0; c0 < pp.n_vox; c0 += kNdtVoxChunk) {
+        const int cn = min(kNdtVoxChunk, pp.n_vox - c0);
+        __syncthreads();
+        {   // cooperative copy of the chunk (16 doubles per voxel)
+            const double *g = reinterpret_cast<const double *>(vox + c0);
+            double *s = reinterpret_cast<double *>(sv);
+            for (int k = threadIdx.x; k < cn * 16; k += blockDim.x) s[k] = g[k];
+        }
+        __syncthreads();
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const float4 s4 = src[i];
+            if (s4.w == 0.0f) continue;
+            const float tx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[0], s4.x), __fmul_rn(pp.M[1], s4.y)), __fmul_rn(pp.M[2], s4.z)), pp.M[3]);
+            const float ty = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[4], s4.x), __fmul_rn(pp.M[5], s4.y)), __fmul_rn(pp.M[6], s4.z)), pp.M[7]);
+            const float tz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[8], s4.x), __fmul_rn(pp.M[9], s4.y)), __fmul_rn(pp.M[10], s4.z)), pp.M[11]);
+            if (trans_out && c0 == 0) { trans_out[3 * i] = tx; trans_out[3 * i + 1] = ty; trans_out[3 * i + 2] = tz; }
+            const double x[3] = {s4.x, s4.y, s4.z};
+            // point gradient columns 3..5 (columns 0..2 are the identity)
+            const double g13 = dot3d(x, pp.jang[0]), g23 = dot3d(x, pp.jang[1]);
+            const double g04 = dot3d(x, pp.jang[2]), g14 = dot3d(x, pp.jang[3]), g24 = dot3d(x, pp.jang[4]);
+            const double g05 = dot3d(x, pp.jang[5]), g15 = dot3d(x, pp.jang[6]), g25 = dot3d(x, pp.jang[7]);
+            const double J[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, g13, g23}, {g04, g14, g24}, {g05, g15, g25}};
+            double ha[3], hb[3], hc[3], hd[3], he[3], hf[3];
+            if (pp.mode != 1) {
+                ha[0] = 0; ha[1] = dot3d(x, pp.hang[0]); ha[2] = dot3d(x, pp.hang[1]);
+                hb[0] = 0; hb[1] = dot3d(x, pp.hang[2]); hb[2] = dot3d(x, pp.hang[3]);
+                hc[0] = 0; hc[1] = dot3d(x, pp.hang[4]); hc[2] = dot3d(x, pp.hang[5]);
+                hd[0] = dot3d(x, pp.hang[6]); hd[1] = dot3d(x, pp.hang[7]); hd[2] = dot3d(x, pp.hang[8]);
+                he[0] = dot3d(x, pp.hang[9]); he[1] = dot3d(x, pp.hang[10]); he[2] = dot3d(x, pp.hang[11]);
+                hf[0] = dot3d(x, pp.hang[12]); hf[1] = dot3d(x, pp.hang[13]); hf[2] = dot3d(x, pp.hang[14]);
+            }
+            for (int v = 0; v < cn; ++v) {
+                const NdtVoxel &vx = sv[v];
+                const float dx = __fsub_rn(tx, vx.centroid[0]), dy = __fsub_rn(ty, vx.centroid[1]), dz = __fsub_rn(tz, vx.centroid[2]);
+                const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                if (!(dd < pp.r2)) continue;
+                const double xm[3] = {(double)tx - vx.mean[0], (double)ty - vx.mean[1], (double)tz - vx.mean[2]};
+                const double *ci = vx.icov;
+                const double cx[3] = {ci[0] * xm[0] + ci[1] * xm[1] + ci[2] * xm[2],
+                                      ci[3] * xm[0] + ci[4] * xm[1] + ci[5] * xm[2],
+                                      ci[6] * xm[0] + ci[7] * xm[1] + ci[8] * xm[2]};
+                double e = exp(-pp.d2 * dot3d(xm, cx) / 2);
+                const double score_inc = -pp.d1 * e;
+                e = pp.d2 * e;
+                if (e > 1 || e < 0 || e != e) continue;
+                if (pp.mode != 2) acc[0] += score_inc;
+                e *= pp.d1;
+                double cg[6][3], xcg[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) cg[a][r] = ci[r * 3] * J[a][0] + ci[r * 3 + 1] * J[a][1] + ci[r * 3 + 2] * J[a][2];
+                    xcg[a] = dot3d(xm, cg[a]);
+                    if (pp.mode != 2) acc[1 + a] += xcg[a] * e;
+                }
+                if (pp.mode == 1) continue;
+                int h = 7;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int b = a; b < 6; ++b) {
+                        // second derivative of the transformed point w.r.t. (p_a, p_b)
+                        double xh = 0.0;
+                        if (a >= 3) {
+                            const double *hv = (a == 3) ? (b == 3 ? ha : (b == 4 ? hb : hc))
+                                             : (a == 4) ? (b == 4 ? hd : he)
+                                                        : hf;
+                            // x'^T Sigma^-1 h  (PCL: x_trans.dot(c_inv * block)); Sigma^-1 symmetric
+                            const double ch[3] = {ci[0] * hv[0] + ci[1] * hv[1] + ci[2] * hv[2],
+                                                  ci[3] * hv[0] + ci[4] * hv[1] + ci[5] * hv[2],
+                                                  ci[6] * hv[0] + ci[7] * hv[1] + ci[8] * hv[2]};
+                            xh = dot3d(xm, ch);
+                        }
+                        const double jc = J[b][0] * cg[a][0] + J[b][1] * cg[a][1] + J[b][2] * cg[a][2];
+                        acc[h++] += e * (-pp.d2 * xcg[a] * xcg[b] + xh + jc);
+                    }
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < kNdtAcc; ++k) {
+        double s = acc[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) sh[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNdtAcc) {
+        double s = sh[0][threadIdx.x];
+        for (int w = 1; w < kNdtBlock / 64; ++w) s += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *partials, uint32_t nblocks, double *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < kNdtAcc; k += kNdtBlock / 64) {
+        double v = 0.0;
+        for (uint32_t b = lane; b < nblocks; b += 64) v += partials[(size_t)b * kNdtAcc + k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) out[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_load_source(const char *raw, size_t stride, uint32_t n, float4 *src)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = reinterpret_cast<const float *>(raw + (size_t)i * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    src[i] = make_float4(x, y, z, ndt_finite3(x, y, z) ? 1.0f : 0.0f);
+}
+
+}  // namespace rsreg

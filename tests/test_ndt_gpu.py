@@ -1,0 +1,129 @@
+"""GPU parity tests of the NDT path (voxel statistics kernel set + derivative pass + host
+Newton / More-Thuente) through the C ABI, against the numpy golden vectors and the CPU oracle.
+f64 statistics to 1e-10 relative; score / gradient / Hessian to 1e-9 relative of their scale;
+final transform within 1e-4 Frobenius of the oracle (north-star tolerance)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(rs):
+    from rsreg_amd import api as a, lib
+    lib.build()
+    if a.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return a
+
+
+def _ndt(api, src, tgt, **kw):
+    n = api.NormalDistributionsTransform()
+    n.params = api.ndt_params(reference=True, **kw)
+    n.setInputSource(src)
+    n.setInputTarget(tgt)
+    return n
+
+
+def test_voxel_statistics_match_golden_and_oracle(api, orc, golden):
+    g = golden("ndt_small")
+    tgt = np.ascontiguousarray(g["tgt"])
+    n = _ndt(api, np.ascontiguousarray(g["src"]), tgt)
+    m, c = n.voxels()
+    np.testing.assert_array_equal(c, g["vox_n"])
+    np.testing.assert_allclose(m[:, 0:3], g["vox_mean"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(m[:, 3:12].reshape(-1, 3, 3), g["vox_cov"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m[:, 12:21].reshape(-1, 3, 3), g["vox_icov"], rtol=1e-7, atol=1e-9)
+    o = orc.NdtOracle()
+    o.set_target(tgt, 1.0)
+    mo, co = o.voxels()
+    np.testing.assert_array_equal(c, co)
+    np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-11)
+
+
+def test_derivative_pass_matches_oracle_and_finite_differences(api, orc, golden):
+    g = golden("ndt_small")
+    tgt, src = np.ascontiguousarray(g["tgt"]), np.ascontiguousarray(g["src"])
+    n = _ndt(api, src, tgt)
+    score, grad, hess = n.derivatives(g["pose"])
+    o = orc.NdtOracle()
+    o.set_centroid_mode(1)   # the HIP path stores round(mean_f64) as the search centroid
+    o.set_target(tgt, 1.0)
+    so, go, ho = o.derivatives(src, g["pose"], orc.NdtParams.reference())
+    assert abs(score - so) < 1e-10 * abs(so)
+    np.testing.assert_allclose(grad, go, rtol=1e-9, atol=1e-9 * np.abs(go).max())
+    np.testing.assert_allclose(hess, ho, rtol=1e-9, atol=1e-9 * np.abs(ho).max())
+    # independent check: numpy score and finite-difference derivatives (float64 positions)
+    assert abs(score - g["score"][0]) < 1e-6 * abs(g["score"][0])
+    np.testing.assert_allclose(grad, g["grad_fd"], rtol=5e-4, atol=0.5)
+    np.testing.assert_allclose(hess, g["hess_fd"], rtol=2e-3, atol=np.abs(g["hess_fd"]).max() * 2e-4)
+
+
+@pytest.fixture(scope="module")
+def edge_like(rs):
+    """~30 k-point subsets standing in for the edge clouds of BASELINE configs[2]."""
+    s = rs.synth
+    out = []
+    for k in (0, 2):
+        f = s.render_frame(k, "N300", "bench").crop(0, 0, 640, 480, step=3)
+        out.append(rs.PointCloud(np.ascontiguousarray(f.points[f.points["z"] != 0])))
+    return out
+
+
+@pytest.mark.parametrize("guess_kind", ["identity", "yaw"])
+def test_align_matches_oracle(api, orc, rs, edge_like, guess_kind):
+    tgt, src = edge_like
+    guess = None if guess_kind == "identity" else rs.synth.small_transform(2.0, (0.0, 0.0, 0.0)).astype(np.float32)
+    n = _ndt(api, src, tgt)
+    out = n.align(guess)
+    o = orc.NdtOracle()
+    o.set_centroid_mode(1)
+    o.set_target(tgt.points, 1.0)
+    ro, oal = o.align(src.points, guess, orc.NdtParams.reference(), want_aligned=True)
+    r = n.result
+    assert (r.converged, r.iterations) == (ro.converged, ro.iterations)
+    assert r.n_voxels == ro.n_voxels and r.n_derivative_passes == ro.n_derivative_passes
+    err = np.linalg.norm(n.getFinalTransformation() - ro.T)
+    assert err < 1e-5, err
+    assert abs(r.score - ro.score) < 1e-7 * abs(ro.score)
+    np.testing.assert_allclose(out.xyz, oal[:, :3], atol=2e-5)
+    # PCL-faithful f32 running-sum centroids: still inside the north-star tolerance
+    o2 = orc.NdtOracle()
+    o2.set_target(tgt.points, 1.0)
+    r2 = o2.align(src.points, guess, orc.NdtParams.reference())
+    assert np.linalg.norm(n.getFinalTransformation() - r2.T) < 1e-4
+    if guess is None:  # from a cold start the 1 m NDT must move towards the true pose
+        gt = rs.synth.ground_truth(2, 0, "bench")
+        assert np.linalg.norm(n.getFinalTransformation() - gt) < np.linalg.norm(np.eye(4) - gt)
+
+
+def test_ndt_then_icp_pair_like_the_reference_scheme(api, orc, rs, edge_like):
+    """configs[2] shape: NDT on the subset gives the guess, ICP refines (ndt_edge...hpp:71-99)."""
+    tgt, src = edge_like
+    n = _ndt(api, src, tgt)
+    aligned = n.align(rs.synth.small_transform(1.0, (0, 0, 0)).astype(np.float32))
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(reference=True)
+    icp.setInputSource(aligned)
+    icp.setInputTarget(tgt)
+    icp.align()
+    o = orc.IcpOracle()
+    o.set_target(tgt.points)
+    o.set_source(aligned.points)
+    ro = o.align(None, orc.IcpParams.reference())
+    assert icp.hasConverged() == bool(ro.converged)
+    np.testing.assert_allclose(icp.getFinalTransformation(), ro.T, atol=2e-6)
+
+
+def test_ndt_edge_cases(api, rs):
+    pts = np.zeros((100, 4), np.float32)
+    pts[:, 0] = np.linspace(0, 0.5, 100)
+    n = _ndt(api, pts, pts[:4])            # fewer than 6 points per voxel: no voxels
+    n.align()
+    assert n.result.n_voxels == 0 and n.result.iterations == 0
+    np.testing.assert_array_equal(n.getFinalTransformation(), np.eye(4, dtype=np.float32))
+    bad = pts.copy()
+    bad[3, 1] = np.nan
+    n = _ndt(api, bad, pts)                # collinear target: eigenvalue floor keeps it usable
+    n.align()
+    assert np.isfinite(n.getFinalTransformation()).all()

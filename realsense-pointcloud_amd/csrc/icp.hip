@@ -16,12 +16,13 @@
 #include <new>
 
 #include "icp_kernels.hpp"
+#include "icp_tile_kernel.hpp"
 
 using namespace rsreg;
 
 namespace {
 
-constexpr int kReduceBlocks = 1024;  // fixed, so the summation order never depends on the GPU
+inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n + kTile - 1) / kTile, 1); }  // depends on n only
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -67,16 +68,30 @@ double sum_events(rsreg_ctx *ctx, std::vector<std::pair<size_t, size_t>> &list)
     return ms;
 }
 
-GridDev grid_dev(const rsreg_ctx *ctx)
+GridDev grid_dev(const rsreg_ctx *ctx, double max_dist)
 {
     const GridParams &p = ctx->grid;
     GridDev g;
     g.ox = p.origin[0]; g.oy = p.origin[1]; g.oz = p.origin[2];
     g.inv_cell = p.inv_cell; g.cell = p.cell;
     g.dx = p.dims[0]; g.dy = p.dims[1]; g.dz = p.dims[2];
-    g.mask = p.table_mask;
+    g.bmask = p.table_mask;
     g.max_ring = p.max_ring;
-    g.table = ctx->d_table.as<CellEntry>();
+    static const int halo_env = std::getenv("RSREG_HALO") ? std::atoi(std::getenv("RSREG_HALO")) : 1;
+    g.halo = std::max(1, std::min(p.max_ring, std::min(halo_env, kHaloMax)));
+    // squared search radius as a float that is never below the f64 gate PCL compares with
+    const double gate2 = max_dist * max_dist;
+    if (!(gate2 < (double)FLT_MAX)) {
+        g.prune2 = INFINITY;
+    } else {
+        float f = (float)gate2;
+        if ((double)f < gate2) f = std::nextafter(f, INFINITY);
+        g.prune2 = f;
+    }
+    static const int dbg = std::getenv("RSREG_DEBUG") ? std::atoi(std::getenv("RSREG_DEBUG")) : 0;
+    g.dbg = dbg;
+    g.bricks = ctx->d_table.as<BrickEntry>();
+    g.cellpos = ctx->d_cellpos.as<uint32_t>();
     g.pts = ctx->d_tgt_sorted.as<float4>();
     return g;
 }
@@ -115,8 +130,32 @@ int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
     return RSREG_OK;
 }
 
+// bounding box + count of the finite points of a device-resident cloud (one host sync)
+int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, float mn[3], float mx[3], uint32_t *nfin)
+{
+    hipStream_t st = ctx->stream;
+    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();  // pinned scratch, 16 words used here
+    const size_t misc_bytes = 16 * sizeof(uint32_t);
+    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
+    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
+    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, misc_bytes, hipMemcpyHostToDevice, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));  // h_misc is reused as the read-back buffer
+    if (n > 0) {
+        k_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, d_misc);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    *nfin = h_misc[6];
+    for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(h_misc[k]); mx[k] = ordered_float(h_misc[3 + k]); }
+    return RSREG_OK;
+}
+
 // Builds the grid from records already in HBM (d_pts/stride); keeps no pointer to them.
-int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist)
+int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, double refine = 1.0)
 {
     hipStream_t st = ctx->stream;
     ctx->have_target = false;
@@ -133,54 +172,39 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         ev1 = take_event(ctx);
         (void)hipEventRecord(ev0, st);
     }
-
-    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    float mn[3], mx[3];
+    uint32_t nfin = 0;
+    int rc = device_bbox(ctx, d_pts, n, stride, mn, mx, &nfin);
+    if (rc) return rc;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
-    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();  // pinned scratch, 16 words used here
+    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
     const size_t misc_bytes = 16 * sizeof(uint32_t);
-    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
-    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
-    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, misc_bytes, hipMemcpyHostToDevice, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
-    h_misc[6] = 0;
-    if (n > 0) {
-        k_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, kBlock), 2048), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, d_misc);
-        RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
-        RSREG_HIP(ctx, hipStreamSynchronize(st));
-    }
-    const uint32_t nfin = h_misc[6];
     ctx->grid_info.n_target_points = nfin;
     if (nfin == 0) {
         ctx->have_target = true;  // an empty index: every search comes back empty
-        ctx->grid.n_points = 0;
-        ctx->grid.table_mask = 0;
-        ctx->grid.dims[0] = ctx->grid.dims[1] = ctx->grid.dims[2] = 0;
-        ctx->grid.max_ring = 0;
         ctx->grid.cell = ctx->grid.inv_cell = 1.0f;
-        RSREG_HIP(ctx, ctx->d_table.reserve(sizeof(CellEntry)));
-        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, sizeof(CellEntry), st));
+        RSREG_HIP(ctx, ctx->d_table.reserve(sizeof(BrickEntry)));
+        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, sizeof(BrickEntry), st));
         RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(sizeof(float4)));
+        RSREG_HIP(ctx, ctx->d_cellpos.reserve(16));
         return RSREG_OK;
     }
-    float mn[3], mx[3];
-    for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(h_misc[k]); mx[k] = ordered_float(h_misc[3 + k]); }
 
-    // ---- cell size: a whole fraction of the gate (so the rings cover it exactly), no
-    // larger than the cap; an unbounded gate searches until the grid is exhausted.
+    // ---- cell size: a whole fraction of the gate, no larger than the cap; an unbounded
+    // gate searches outward until the grid is exhausted.  `refine` (second pass only) shrinks
+    // the cells of a dense cloud towards ~8 points per occupied cell.
     const double cap = cell_cap_from_env();
     double extent = 0;
     for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
     double cell;
-    int max_ring;
     const bool bounded = std::isfinite(max_dist) && max_dist > 0 && max_dist < 0.25 * extent + 1e-3;
     if (bounded) {
         const double padded = max_dist * 1.04;
-        const int parts = std::max(1, (int)std::ceil(padded / cap));
+        int parts = std::max(1, (int)std::ceil(padded / (cap * refine)));
+        parts = std::min(parts, 8);   // the far phase walks (2*parts/4+3)^3 bricks for an unmatched query
         cell = padded / parts;
     } else {
-        cell = cap;
+        cell = cap * refine;
     }
     cell = std::max(cell, extent / 60000.0);  // 16 bits per axis in the cell key
     cell = std::max(cell, 1e-6);
@@ -192,25 +216,24 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         gp.dims[k] = host_cell_coord(mx[k], mn[k], gp.inv_cell) + 2;
     }
     const int max_dim = std::max(gp.dims[0], std::max(gp.dims[1], gp.dims[2]));
+    int max_ring = max_dim + 1;
     if (std::isfinite(max_dist) && max_dist >= 0) {
-        const double rings = std::ceil(max_dist / ((double)gp.cell * kRingSafety));
-        max_ring = rings < (double)(max_dim + 1) ? std::max(1, (int)rings) : max_dim + 1;
-    } else {
-        max_ring = max_dim + 1;
+        const double rings = std::ceil(max_dist / (double)gp.cell + 2.0 * kCellMargin);
+        if (rings < (double)(max_dim + 1)) max_ring = std::max(1, (int)rings);
     }
     gp.max_ring = max_ring;
 
-    // ---- sort by (cell, xyz hash)
+    // ---- sort by (brick, cell in brick, xyz hash)
     RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
-    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 12));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 12));
     RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
-    RSREG_HIP(ctx, ctx->d_cellkey.reserve(((size_t)nfin + 2) * 8));
+    RSREG_HIP(ctx, ctx->d_brick.reserve(((size_t)nfin + 2) * 20));
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 1) * sizeof(float4)));
-    GridDev g = grid_dev(ctx);
+    GridDev g = grid_dev(ctx, max_dist);
     const uint32_t nb = div_up((uint32_t)n, kBlock);
     auto *keys = ctx->d_keys.as<unsigned long long>();
     auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
@@ -221,35 +244,43 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     size_t tmp_bytes = 0;
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
     size_t scan_bytes = 0;
-    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n;
-    uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n;
+    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n, *bstart = cstart + n;
+    uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n, *bid = cid + n;
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
     const uint32_t nbf = div_up(nfin, kBlock);
-    k_flag_runs<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart);
+    k_flag_runs<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, bstart);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    k_scatter_sorted<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, pos, cid,
-                                             ctx->d_tgt_sorted.as<float4>(), ctx->d_cellkey.as<unsigned long long>(),
-                                             ctx->d_cellpos.as<uint32_t>(), d_misc + 8);
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, bstart, bid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    // brick staging arrays: key[nfin+1] u64 | mask[nfin+1] u64 | base[nfin+1] u32
+    auto *brickkey = ctx->d_brick.as<unsigned long long>();
+    auto *brickmask = brickkey + (nfin + 1);
+    auto *brickbase = reinterpret_cast<uint32_t *>(brickmask + (nfin + 1));
+    RSREG_HIP(ctx, hipMemsetAsync(brickmask, 0, ((size_t)nfin + 1) * 8, st));
+    k_scatter_sorted<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, bstart, pos, cid, bid,
+                                             ctx->d_tgt_sorted.as<float4>(), ctx->d_cellpos.as<uint32_t>(), brickkey, brickmask,
+                                             brickbase, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t n_unique = h_misc[8], n_cells = h_misc[9];
+    const uint32_t n_unique = h_misc[8], n_cells = h_misc[9], n_bricks = h_misc[11];
     gp.n_points = n_unique;
     gp.n_cells = n_cells;
+    gp.n_bricks = n_bricks;
 
-    // ---- hash table of occupied cells, at most half full
+    // ---- hash table of occupied bricks, at most half full
     uint32_t slots = 64;
-    while (slots < 2 * n_cells) slots <<= 1;
+    while (slots < 2 * n_bricks) slots <<= 1;
     gp.table_mask = slots - 1;
-    RSREG_HIP(ctx, ctx->d_table.reserve((size_t)slots * sizeof(CellEntry)));
-    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, (size_t)slots * sizeof(CellEntry), st));
-    k_table_insert<<<div_up(n_cells, kBlock), kBlock, 0, st>>>(ctx->d_cellkey.as<unsigned long long>(),
-                                                               ctx->d_cellpos.as<uint32_t>(), n_cells,
-                                                               ctx->d_table.as<CellEntry>(), gp.table_mask, d_misc + 10);
+    RSREG_HIP(ctx, ctx->d_table.reserve((size_t)slots * sizeof(BrickEntry)));
+    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0xff, (size_t)slots * sizeof(BrickEntry), st));
+    k_brick_insert<<<div_up(n_bricks, kBlock), kBlock, 0, st>>>(brickkey, brickmask, brickbase, n_bricks,
+                                                                ctx->d_table.as<BrickEntry>(), gp.table_mask);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_max_cell_count<<<div_up(n_cells, kBlock), kBlock, 0, st>>>(ctx->d_cellpos.as<uint32_t>(), n_cells, d_misc + 10);
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
@@ -266,27 +297,69 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
     }
     ctx->have_target = true;
+    // dense cloud: rebuild once with smaller cells (fewer candidates per query)
+    static const bool adaptive = !(std::getenv("RSREG_NO_ADAPTIVE_CELL") && std::getenv("RSREG_NO_ADAPTIVE_CELL")[0] == '1');
+    if (adaptive && refine == 1.0 && n_cells > 0) {
+        const double per_cell = (double)n_unique / (double)n_cells;
+        if (per_cell > 14.0) {
+            const double ms_first = gi.ms_build;
+            const double r = std::max(0.2, std::sqrt(8.0 / per_cell));
+            const float cell_before = gp.cell;
+            int rc2 = build_grid(ctx, d_pts, n, stride, max_dist, r);
+            if (rc2) return rc2;
+            ctx->grid_info.ms_build += ms_first;
+            (void)cell_before;
+        }
+    }
     return RSREG_OK;
 }
 
+// Loads the source and orders it spatially (brick-major cell order in its own grid): lanes
+// of a wave then query neighbouring cells, which is what makes the search cache-friendly.
+// d_perm maps the sorted position back to the caller's index.
 int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
 {
     if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
+    hipStream_t st = ctx->stream;
     RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)kReduceBlocks * RSREG_NUM_SUMS * 8));
+    RSREG_HIP(ctx, ctx->d_perm.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     ctx->n_source = n;
+    ctx->have_source = false;
+    ctx->icp.active = 0;
     if (n) {
-        k_init_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
-            d_raw, stride, (uint32_t)n, to_mat34(Mat4f::identity()), 0, ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
+        float mn[3], mx[3];
+        uint32_t nfin = 0;
+        int rc = device_bbox(ctx, d_raw, n, stride, mn, mx, &nfin);
+        if (rc) return rc;
+        if (nfin == 0) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
+        double extent = 0;
+        for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
+        // fine Morton resolution (a few mm): consecutive points then form compact blobs
+        const float cell = (float)std::max(cell_cap_from_env() / 8.0, extent / 60000.0);
+        RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
+        RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
+        RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
+        auto *keys = ctx->d_keys.as<unsigned long long>();
+        auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
+        auto *vals = ctx->d_vals.as<uint32_t>();
+        uint32_t *perm = ctx->d_perm.as<uint32_t>();
+        const uint32_t nb = div_up((uint32_t)n, kBlock);
+        k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, keys, vals);
+        RSREG_HIP(ctx, hipGetLastError());
+        size_t tmp_bytes = 0;
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(tmp_bytes + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, tmp_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
     }
     ctx->have_source = true;
-    ctx->icp.active = 0;
     return RSREG_OK;
 }
 
@@ -322,6 +395,24 @@ bool criteria_has_converged(IcpState &s)
     return false;
 }
 
+bool use_tile_kernel()
+{
+    // The LDS-staged tile kernel is exact but, with fixed 128-point tiles, not yet faster than
+    // the global-memory search on clouds whose areal density varies 10x:
+    // opt in with RSREG_TILE=1.
+    static const bool on = [] {
+        const char *e = std::getenv("RSREG_TILE");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
+uint32_t *tile_stats(rsreg_ctx *ctx)
+{
+    static const bool on = std::getenv("RSREG_TILE_STATS") != nullptr;
+    return on ? ctx->d_misc.as<uint32_t>() + 32 : nullptr;
+}
+
 int launch_search(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
@@ -329,8 +420,14 @@ int launch_search(rsreg_ctx *ctx)
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     if (n) {
         ScopedEvents ev(ctx, &ctx->ev_nn);
-        k_nn_search<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, grid_dev(ctx), gate2,
-                                                                    ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>());
+        const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
+        if (use_tile_kernel())
+            k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(Mat4f::identity()), 0, g,
+                                                                      gate2, ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
+                                                                      1, nullptr, 0, tile_stats(ctx));
+        else
+            k_nn_search<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, g, gate2,
+                                                                       ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
     }
@@ -358,11 +455,11 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
     const uint32_t n = (uint32_t)ctx->n_source;
     {
         ScopedEvents ev(ctx, &ctx->ev_reduce);
-        k_cov_reduce<<<kReduceBlocks, kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
+        k_cov_reduce<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
                                                                 ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
                                                                 ctx->d_partials.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
-        k_final_reduce<<<1, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), kReduceBlocks, ctx->d_sums.as<double>());
+        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
     }
     return fetch_sums(ctx, sums, global);
@@ -376,16 +473,23 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
-        k_icp_fused<<<kReduceBlocks, kBlock, 0, ctx->stream>>>(
-            ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, grid_dev(ctx), gate2,
-            want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>());
+        const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
+        if (use_tile_kernel())
+            k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
+                                                                     s.pending_transform ? 1 : 0, g, gate2, ctx->d_corr_pos.as<int>(),
+                                                                     ctx->d_corr_d2.as<float>(), want_corr ? 1 : 0,
+                                                                     ctx->d_partials.as<double>(), 1, tile_stats(ctx));
+        else
+            k_icp_fused<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
+                ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, g, gate2,
+                want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
     }
     s.pending_transform = false;
     {
         ScopedEvents ev(ctx, &ctx->ev_reduce);
-        k_final_reduce<<<1, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), kReduceBlocks, ctx->d_sums.as<double>());
+        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
     }
     s.have_search = want_corr;
@@ -498,7 +602,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rsreg_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_cellkey, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
@@ -638,15 +742,15 @@ int rsreg_icp_search(rsreg_ctx *ctx, int32_t *index_out, float *sqr_dist_out)
     if (rc) return rc;
     const size_t n = ctx->n_source;
     if ((index_out || sqr_dist_out) && n) {
-        RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 4 + 16));
-        if (index_out) {
-            k_corr_to_index<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
-                ctx->d_corr_pos.as<int>(), ctx->d_tgt_sorted.as<float4>(), (uint32_t)n, ctx->d_tmp.as<int>());
-            RSREG_HIP(ctx, hipGetLastError());
-            RSREG_HIP(ctx, hipMemcpyAsync(index_out, ctx->d_tmp.ptr, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        if (sqr_dist_out)
-            RSREG_HIP(ctx, hipMemcpyAsync(sqr_dist_out, ctx->d_corr_d2.ptr, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 8 + 32));
+        int *d_idx = ctx->d_tmp.as<int>();
+        float *d_d2 = reinterpret_cast<float *>(d_idx + n);
+        k_export_corr<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
+            ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), ctx->d_perm.as<uint32_t>(),
+            (uint32_t)n, d_idx, d_d2);
+        RSREG_HIP(ctx, hipGetLastError());
+        if (index_out) RSREG_HIP(ctx, hipMemcpyAsync(index_out, d_idx, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (sqr_dist_out) RSREG_HIP(ctx, hipMemcpyAsync(sqr_dist_out, d_d2, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return RSREG_OK;
@@ -689,12 +793,19 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         if (out_stride < 12) return RSREG_ERR_INVALID_ARG;
         RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
         RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
-        k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), (uint32_t)n,
-                                                                                to_mat34(s.final_t), ctx->d_tmp.as<float>());
+        k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), (uint32_t)n, to_mat34(s.final_t),
+                                                                                ctx->d_perm.as<uint32_t>(), ctx->d_tmp.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (uint32_t *st = tile_stats(ctx)) {
+        uint32_t h[9] = {0};
+        (void)hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[rsreg] tiles: %u staged in LDS, %u global fallback, %u empty; fallback causes: box %u bricks %u cells %u pts %u; max box %u max pts %u\n",
+                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        (void)hipMemset(st, 0, sizeof(h));
+    }
     if (aligned_out && n) {
         const float *src = ctx->h_stage.as<float>();
         char *dst = static_cast<char *>(aligned_out);
@@ -775,9 +886,9 @@ int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, s
     RSREG_HIP(ctx, hipMemcpyAsync(d_raw, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
     Mat4f T;
     std::memcpy(T.m, transform, 64);
-    k_init_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_raw, 12, (uint32_t)n, to_mat34(T), 1, nullptr, d_pts);
+    k_gather_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_raw, 12, (uint32_t)n, nullptr, d_pts, nullptr);
     RSREG_HIP(ctx, hipGetLastError());
-    k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_pts, (uint32_t)n, to_mat34(Mat4f::identity()),
+    k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_pts, (uint32_t)n, to_mat34(T), nullptr,
                                                                             reinterpret_cast<float *>(d_raw));
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, d_raw, n * 12, hipMemcpyDeviceToHost, ctx->stream));

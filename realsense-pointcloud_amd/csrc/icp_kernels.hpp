@@ -1,9 +1,10 @@
 // icp_kernels.hpp — device code of the ICP path (gfx950, wave64).  Included by icp.hip only.
 //
 // Kernels (each cites the PCL step it replaces; reference call sites in include/rsreg.h):
-//   grid build   k_bbox / k_cell_keys / k_flag_runs / k_scatter_sorted / k_table_insert
+//   grid build   k_bbox / k_cell_keys / k_flag_runs / k_scatter_sorted / k_brick_insert
 //                  = KdTreeFLANN build in Registration::initCompute
-//   k_init_source     input_transformed = guess * input               (App. A.2 prologue)
+//   k_source_keys / k_gather_source   spatial ordering of the source (engine-internal)
+//   k_restart_source  input_transformed = guess * input               (App. A.2 prologue)
 //   k_nn_search       CorrespondenceEstimation::determineCorrespondences (App. A.1, A.7a)
 //   k_cov_reduce + k_final_reduce   the sums Eigen::umeyama needs     (App. A.3)
 //   k_transform       ICP transformCloud in place                     (App. A.2)
@@ -12,6 +13,11 @@
 // un-fused operations in a fixed order (the file is also built with -ffp-contract=off):
 //   d2 = ((dx*dx + dy*dy) + dz*dz)            FLANN L2_Simple<float>
 //   x' = ((m00*x + m01*y) + m02*z) + m03      PCL transformCloud
+//
+// Target index: uniform grid of cells of edge `cell`; 4x4x4 cells form a
+// brick.  Points are sorted brick-major, then by cell inside the brick (x fastest), exact
+// duplicates dropped.  A hash table maps a brick coordinate to {64-bit occupancy mask, id of
+// its first occupied cell}; cellpos[id] is the first sorted point of an occupied cell.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,14 +31,19 @@ namespace rsreg {
 
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr unsigned long long kEmptyKey = ~0ull;
-constexpr float kRingSafety = 0.96875f;  // ring r proves distances up to r*cell*kRingSafety
+constexpr float kCellMargin = 0.03f;   // slack (in cells) on every geometric lower bound: covers
+                                       // the float rounding of the point -> cell assignment
 
 struct GridDev {
     float ox, oy, oz, inv_cell, cell;
-    int dx, dy, dz;
-    uint32_t mask;
-    int max_ring;
-    const CellEntry *table;
+    int dx, dy, dz;          // grid extent in cells
+    uint32_t bmask;          // brick hash table has bmask + 1 slots
+    int max_ring;            // rings (in cells) that cover the correspondence gate
+    float prune2;            // squared search radius as float, rounded up (+inf: unbounded)
+    int halo;                // rings of cells the LDS tile stages around its queries (1..3)
+    int dbg;                 // timing experiments only (RSREG_DEBUG), 0 in production
+    const BrickEntry *bricks;
+    const uint32_t *cellpos;
     const float4 *pts;
 };
 
@@ -66,26 +77,38 @@ __device__ __forceinline__ bool finite3(float x, float y, float z)
     return isfinite(x) && isfinite(y) && isfinite(z);
 }
 
+// position in cell units relative to the grid origin; the SAME expression feeds the build
+// and every query, so equal coordinates always land in the same cell
+__device__ __forceinline__ float cell_pos(float p, float origin, float inv_cell)
+{
+    return __fmul_rn(__fsub_rn(p, origin), inv_cell);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float origin, float inv_cell)
 {
-    // same expression in the build and in every query: a point and a query with equal
-    // coordinates always land in the same cell
-    float v = floorf(__fmul_rn(__fsub_rn(p, origin), inv_cell));
+    float v = floorf(cell_pos(p, origin, inv_cell));
     v = fminf(fmaxf(v, -4.0f), 70000.0f);
     return (int)v;
 }
 
-__device__ __forceinline__ unsigned long long pack_cell(int x, int y, int z)
+// brick-major key of a cell: [bz:14 | by:14 | bx:14 | lz:2 | ly:2 | lx:2]
+__device__ __forceinline__ unsigned long long cell_key(int x, int y, int z)
 {
-    return ((unsigned long long)(unsigned)z << 32) | ((unsigned long long)(unsigned)y << 16) |
-           (unsigned long long)(unsigned)x;
+    const unsigned long long bx = (unsigned)x >> 2, by = (unsigned)y >> 2, bz = (unsigned)z >> 2;
+    const unsigned long long bit = ((unsigned)z & 3u) << 4 | ((unsigned)y & 3u) << 2 | ((unsigned)x & 3u);
+    return (((bz << 14 | by) << 14 | bx) << 6) | bit;
 }
 
-__device__ __forceinline__ uint32_t hash_cell(unsigned long long k)
+__device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz)
 {
-    k ^= k >> 29;
+    return ((unsigned long long)(unsigned)bz << 14 | (unsigned long long)(unsigned)by) << 14 | (unsigned long long)(unsigned)bx;
+}
+
+__device__ __forceinline__ uint32_t hash_brick(unsigned long long k)
+{
+    k ^= k >> 23;
     k *= 0xbf58476d1ce4e5b9ull;
-    k ^= k >> 32;
+    k ^= k >> 29;
     return (uint32_t)k;
 }
 
@@ -141,16 +164,30 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const char *pts, size_t stride,
         }
         cnt += __shfl_down(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[k], float_ordered(mn[k]));
-            atomicMax(&bbox[3 + k], float_ordered(mx[k]));
+    __shared__ float smn[kBlock / 64][3], smx[kBlock / 64][3];
+    __shared__ uint32_t scnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k) { smn[wave][k] = mn[k]; smx[wave][k] = mx[k]; }
+        scnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one set of atomics per block
+        for (int w = 1; w < kBlock / 64; ++w) {
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], smn[w][k]); mx[k] = fmaxf(mx[k], smx[w][k]); }
+            cnt += scnt[w];
         }
-        atomicAdd(&bbox[6], cnt);
+        if (cnt) {
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&bbox[k], float_ordered(mn[k]));
+                atomicMax(&bbox[3 + k], float_ordered(mx[k]));
+            }
+            atomicAdd(&bbox[6], cnt);
+        }
     }
 }
 
-// sort key: [cell z:16 | y:16 | x:16 | hash16(xyz)]; non-finite points sort to the very end
+// sort key: [cell_key:48 | hash16(xyz)]; non-finite points sort to the very end
 __global__ __launch_bounds__(kBlock) void k_cell_keys(const char *pts, size_t stride, uint32_t n, GridDev g,
                                                       unsigned long long *keys, uint32_t *vals)
 {
@@ -162,25 +199,26 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys(const char *pts, size_t st
     if (finite3(x, y, z)) {
         const int cx = cell_coord(x, g.ox, g.inv_cell), cy = cell_coord(y, g.oy, g.inv_cell),
                   cz = cell_coord(z, g.oz, g.inv_cell);
-        key = (pack_cell(cx, cy, cz) << 16) | hash_xyz16(x, y, z);
+        key = (cell_key(cx, cy, cz) << 16) | hash_xyz16(x, y, z);
     }
     keys[i] = key;
     vals[i] = i;
 }
 
 // keep[i]: not a value-equal duplicate of its predecessor in the same (cell, hash) run;
-// cstart[i]: first point of a cell
+// cstart[i] / bstart[i]: first point of a cell / of a brick
 __global__ __launch_bounds__(kBlock) void k_flag_runs(const unsigned long long *keys, const uint32_t *vals,
                                                       const char *pts, size_t stride, uint32_t nfin,
-                                                      uint32_t *keep, uint32_t *cstart)
+                                                      uint32_t *keep, uint32_t *cstart, uint32_t *bstart)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
     const unsigned long long k = keys[i];
-    uint32_t kp = 1, cs = 1;
+    uint32_t kp = 1, cs = 1, bs = 1;
     if (i > 0) {
         const unsigned long long kprev = keys[i - 1];
         cs = (k >> 16) != (kprev >> 16);
+        bs = (k >> 22) != (kprev >> 22);
         if (k == kprev) {
             const float *a = rec_xyz(pts, stride, vals[i]);
             const float *b = rec_xyz(pts, stride, vals[i - 1]);
@@ -189,74 +227,111 @@ __global__ __launch_bounds__(kBlock) void k_flag_runs(const unsigned long long *
     }
     keep[i] = kp;
     cstart[i] = cs;
+    bstart[i] = bs;
 }
 
-// pos = exclusive scan of keep, cid = exclusive scan of cstart
+// pos / cid / bid = exclusive scans of keep / cstart / bstart
 __global__ __launch_bounds__(kBlock) void k_scatter_sorted(const unsigned long long *keys, const uint32_t *vals,
                                                            const char *pts, size_t stride, uint32_t nfin,
-                                                           const uint32_t *keep, const uint32_t *cstart,
-                                                           const uint32_t *pos, const uint32_t *cid,
-                                                           float4 *sorted, unsigned long long *cellkey,
-                                                           uint32_t *cellpos, uint32_t *counts /*[2]*/)
+                                                           const uint32_t *keep, const uint32_t *cstart, const uint32_t *bstart,
+                                                           const uint32_t *pos, const uint32_t *cid, const uint32_t *bid,
+                                                           float4 *sorted, uint32_t *cellpos, unsigned long long *brickkey,
+                                                           unsigned long long *brickmask, uint32_t *brickbase,
+                                                           uint32_t *counts /*[4]*/)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
     const uint32_t v = vals[i];
+    const unsigned long long k = keys[i];
     if (keep[i]) {
         const float *p = rec_xyz(pts, stride, v);
         sorted[pos[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(v));
     }
     if (cstart[i]) {
-        cellkey[cid[i]] = keys[i] >> 16;
         cellpos[cid[i]] = pos[i];
+        const uint32_t b = bstart[i] ? bid[i] : bid[i] - 1;   // brick this cell belongs to
+        atomicOr(&brickmask[b], 1ull << ((k >> 16) & 63));
+    }
+    if (bstart[i]) {
+        brickkey[bid[i]] = k >> 22;
+        brickbase[bid[i]] = cid[i];
     }
     if (i == nfin - 1) {
-        const uint32_t nu = pos[i] + keep[i], nc = cid[i] + cstart[i];
+        const uint32_t nu = pos[i] + keep[i], nc = cid[i] + cstart[i], nb = bid[i] + bstart[i];
         counts[0] = nu;
         counts[1] = nc;
+        counts[3] = nb;
         cellpos[nc] = nu;  // sentinel
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_table_insert(const unsigned long long *cellkey, const uint32_t *cellpos,
-                                                         uint32_t ncells, CellEntry *table, uint32_t mask,
-                                                         uint32_t *max_count)
+__global__ __launch_bounds__(kBlock) void k_brick_insert(const unsigned long long *brickkey, const unsigned long long *brickmask,
+                                                         const uint32_t *brickbase, uint32_t nbricks, BrickEntry *table,
+                                                         uint32_t mask)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const unsigned long long key = cellkey[c];
-    const uint32_t start = cellpos[c], count = cellpos[c + 1] - start;
-    uint32_t slot = hash_cell(key) & mask;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbricks) return;
+    const unsigned long long key = brickkey[b];
+    uint32_t slot = hash_brick(key) & mask;
     for (;;) {
         const unsigned long long prev = atomicCAS(&table[slot].key, kEmptyKey, key);
         if (prev == kEmptyKey) {
-            table[slot].start = start;
-            table[slot].count = count;
+            table[slot].mask = brickmask[b];
+            table[slot].base = brickbase[b];
             break;
         }
         slot = (slot + 1) & mask;  // keys are unique, the table is at most half full
     }
-    atomicMax(max_count, count);
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_cell_count(const uint32_t *cellpos, uint32_t ncells, uint32_t *out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = c < ncells ? cellpos[c + 1] - cellpos[c] : 0;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
 // ------------------------------------------------------------------------------ source
-// src = {x,y,z,valid}; cur = guess * src (or a copy when the guess is the identity)
-__global__ __launch_bounds__(kBlock) void k_init_source(const char *raw, size_t stride, uint32_t n, Mat34 guess,
-                                                        int apply_guess, float4 *src, float4 *cur)
+// spread the low 16 bits of v so that there are two zero bits between consecutive bits
+__device__ __forceinline__ unsigned long long spread3(unsigned long long v)
+{
+    v &= 0xffffull;
+    v = (v | (v << 16)) & 0x0000ff0000ffull;
+    v = (v | (v << 8)) & 0x00f00f00f00full;
+    v = (v | (v << 4)) & 0x0c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x249249249249ull;
+    return v;
+}
+
+// Spatial sort key of a source point: Morton (Z-order) code of its cell in the source's own
+// grid, so that any run of consecutive points is a compact patch in all three dimensions.
+__global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t stride, uint32_t n, float ox, float oy,
+                                                        float oz, float inv_cell, unsigned long long *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = rec_xyz(raw, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    const bool ok = finite3(x, y, z);
-    const float4 s = make_float4(x, y, z, ok ? 1.0f : 0.0f);
-    if (src) src[i] = s;
-    float4 c = s;
-    if (ok && apply_guess) {
-        const float3 t = xform(guess, x, y, z);
-        c = make_float4(t.x, t.y, t.z, 1.0f);
-    }
-    cur[i] = c;
+    unsigned long long key = kEmptyKey;
+    if (finite3(x, y, z))
+        key = spread3((unsigned)cell_coord(x, ox, inv_cell)) | spread3((unsigned)cell_coord(y, oy, inv_cell)) << 1 |
+              spread3((unsigned)cell_coord(z, oz, inv_cell)) << 2;
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// src[j] = {xyz of original point perm[j], valid}; cur = copy
+__global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_t stride, uint32_t n, const uint32_t *perm,
+                                                          float4 *src, float4 *cur)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float *p = rec_xyz(raw, stride, perm ? perm[j] : j);
+    const float x = p[0], y = p[1], z = p[2];
+    const float4 s = make_float4(x, y, z, finite3(x, y, z) ? 1.0f : 0.0f);
+    src[j] = s;
+    if (cur) cur[j] = s;
 }
 
 __global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, uint32_t n, Mat34 guess, int apply_guess,
@@ -283,76 +358,235 @@ __global__ __launch_bounds__(kBlock) void k_transform(float4 *cur, uint32_t n, M
     }
 }
 
-// out = final * src as packed float3 (the aligned cloud icp.align() hands back)
-__global__ __launch_bounds__(kBlock) void k_apply_final(const float4 *src, uint32_t n, Mat34 T, float *out_xyz)
+// out[perm[j]] = T * src[j] as packed float3 (the aligned cloud icp.align() hands back)
+__global__ __launch_bounds__(kBlock) void k_apply_final(const float4 *src, uint32_t n, Mat34 T, const uint32_t *perm,
+                                                        float *out_xyz)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 s = src[i];
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float4 s = src[j];
     float3 t = make_float3(s.x, s.y, s.z);
     if (s.w != 0.0f) t = xform(T, s.x, s.y, s.z);
-    out_xyz[3 * i] = t.x;
-    out_xyz[3 * i + 1] = t.y;
-    out_xyz[3 * i + 2] = t.z;
+    const size_t o = perm ? perm[j] : j;
+    out_xyz[3 * o] = t.x;
+    out_xyz[3 * o + 1] = t.y;
+    out_xyz[3 * o + 2] = t.z;
 }
 
 // ------------------------------------------------------------------------------ NN search
 struct Best {
-    float d2;
-    uint32_t oidx;  // original target index of the current best (tie-break: lowest wins)
+    // key = d2 bits << 32 | original target index: unsigned order = (distance, index) order,
+    // so "key < best" is "closer, or equally close with a lower index" (d2 >= +0 always)
+    unsigned long long key;
     int pos;        // position in the sorted target array
+    float d2;
 };
 
-__device__ __forceinline__ void scan_cell(const GridDev &g, int x, int y, int z, float qx, float qy, float qz, Best &b)
+__device__ __forceinline__ void consider(Best &b, float d, uint32_t oi, uint32_t p)
 {
-    const unsigned long long key = pack_cell(x, y, z);
-    uint32_t slot = hash_cell(key) & g.mask;
-    for (;;) {
-        const CellEntry e = g.table[slot];
-        if (e.key == key) {
-            for (uint32_t p = e.start, end = e.start + e.count; p < end; ++p) {
-                const float4 t = g.pts[p];
-                const float d = l2_simple(qx, qy, qz, t.x, t.y, t.z);
-                const uint32_t oi = __float_as_uint(t.w);
-                if (d < b.d2 || (d == b.d2 && oi < b.oidx)) {
-                    b.d2 = d;
-                    b.oidx = oi;
-                    b.pos = (int)p;
-                }
-            }
-            return;
-        }
-        if (e.key == kEmptyKey) return;
-        slot = (slot + 1) & g.mask;
+    const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | oi;
+    if (k < b.key) {
+        b.key = k;
+        b.pos = (int)p;
+        b.d2 = d;
     }
 }
 
-// Exact nearest neighbour by ring expansion over the uniform grid.  After ring r every
-// target whose cell is within Chebyshev distance r of the query's cell has been seen, so
-// anything unseen is farther than r*cell; the search stops when the best distance is inside
-// that bound or when the rings cover the correspondence gate.
-__device__ __forceinline__ Best nn_query(const GridDev &g, float qx, float qy, float qz)
+// 4 independent loads in flight per lane; the clamped tail re-evaluates the last point,
+// which cannot change the result
+__device__ __forceinline__ void scan_points(const float4 *pts, uint32_t s, uint32_t e, float qx, float qy, float qz, Best &b)
 {
-    Best b{FLT_MAX, 0xffffffffu, -1};
-    const int cx = min(max(cell_coord(qx, g.ox, g.inv_cell), -1), g.dx);
-    const int cy = min(max(cell_coord(qy, g.oy, g.inv_cell), -1), g.dy);
-    const int cz = min(max(cell_coord(qz, g.oz, g.inv_cell), -1), g.dz);
-    for (int r = 0; r <= g.max_ring; ++r) {
-        for (int dz = -r; dz <= r; ++dz) {
-            const int z = cz + dz;
-            if (z < 0 || z >= g.dz) continue;
-            for (int dy = -r; dy <= r; ++dy) {
-                const int y = cy + dy;
-                if (y < 0 || y >= g.dy) continue;
-                const bool face = (abs(dz) == r) || (abs(dy) == r);
-                const int step = face ? 1 : max(2 * r, 1);
-                for (int x = cx - r; x <= cx + r; x += step)
-                    if (x >= 0 && x < g.dx) scan_cell(g, x, y, z, qx, qy, qz, b);
+    if (s >= e) return;
+    const uint32_t last = e - 1;
+    for (uint32_t p = s; p < e; p += 4) {
+        const uint32_t p1 = min(p + 1, last), p2 = min(p + 2, last), p3 = min(p + 3, last);
+        const float4 t0 = pts[p], t1 = pts[p1], t2 = pts[p2], t3 = pts[p3];
+        consider(b, l2_simple(qx, qy, qz, t0.x, t0.y, t0.z), __float_as_uint(t0.w), p);
+        consider(b, l2_simple(qx, qy, qz, t1.x, t1.y, t1.z), __float_as_uint(t1.w), p1);
+        consider(b, l2_simple(qx, qy, qz, t2.x, t2.y, t2.z), __float_as_uint(t2.w), p2);
+        consider(b, l2_simple(qx, qy, qz, t3.x, t3.y, t3.z), __float_as_uint(t3.w), p3);
+    }
+}
+
+__device__ __forceinline__ bool brick_lookup(const GridDev &g, int bx, int by, int bz, unsigned long long &mask, uint32_t &base)
+{
+    const unsigned long long key = brick_key(bx, by, bz);
+    uint32_t slot = hash_brick(key) & g.bmask;
+    for (;;) {
+        const BrickEntry e = g.bricks[slot];
+        if (e.key == key) { mask = e.mask; base = e.base; return true; }
+        if (e.key == kEmptyKey) return false;
+        slot = (slot + 1) & g.bmask;
+    }
+}
+
+// lower bound (in cells) on the distance along one axis from a query at in-grid position u
+// (cell units) to cells lo..hi; kCellMargin absorbs the float rounding of cell assignment
+__device__ __forceinline__ float axis_gap(float u, int lo, int hi)
+{
+    const float a = (float)lo - u, b = u - (float)(hi + 1);
+    return fmaxf(fmaxf(a, b) - kCellMargin, 0.0f);
+}
+
+// bits of a 4x4x4 brick whose local coordinates lie in [x0,x1] x [y0,y1] x [z0,z1] (all in 0..3)
+__device__ __forceinline__ unsigned long long box_mask(int x0, int x1, int y0, int y1, int z0, int z1)
+{
+    const unsigned long long xm = ((1u << (x1 + 1)) - (1u << x0)) & 0xfu;
+    const unsigned long long row = xm * 0x1111ull;                       // x pattern in all 4 y rows
+    const unsigned long long ym = ((1ull << (4 * (y1 + 1))) - (1ull << (4 * y0))) & 0xffffull;
+    const unsigned long long plane = (row & ym) * 0x0001000100010001ull; // in all 4 z planes
+    const unsigned long long hi = (z1 >= 3) ? ~0ull : ((1ull << (16 * (z1 + 1))) - 1ull);
+    const unsigned long long zm = hi & ~((1ull << (16 * z0)) - 1ull);
+    return plane & zm;
+}
+
+// Visit the occupied cells of one brick selected by `sel`, nearest-bound pruned.
+__device__ __forceinline__ void visit_brick(const GridDev &g, unsigned long long sel, uint32_t base, unsigned long long mask,
+                                            int bx, int by, int bz, float ux, float uy, float uz, float cell2, float qx,
+                                            float qy, float qz, Best &b, float &limit2)
+{
+    while (sel) {
+        const int bit = __ffsll((long long)sel) - 1;
+        sel &= sel - 1;
+        const int x = (bx << 2) | (bit & 3), y = (by << 2) | ((bit >> 2) & 3), z = (bz << 2) | (bit >> 4);
+        const float gx = axis_gap(ux, x, x), gy = axis_gap(uy, y, y), gz = axis_gap(uz, z, z);
+        const float lb2 = (gx * gx + gy * gy + gz * gz) * cell2;
+        if (lb2 > limit2) continue;
+        const uint32_t id = base + __popcll(mask & ((1ull << bit) - 1ull));
+        scan_points(g.pts, g.cellpos[id], g.cellpos[id + 1], qx, qy, qz, b);
+        limit2 = fminf(limit2, b.d2);
+    }
+}
+
+struct QueryGeom {   // where a query sits in the grid
+    float ux, uy, uz;    // position in cell units relative to the grid origin
+    int cx, cy, cz;      // its cell, clamped to [-1, dim]
+};
+
+__device__ __forceinline__ QueryGeom query_geom(const GridDev &g, float qx, float qy, float qz)
+{
+    QueryGeom q;
+    q.ux = cell_pos(qx, g.ox, g.inv_cell);
+    q.uy = cell_pos(qy, g.oy, g.inv_cell);
+    q.uz = cell_pos(qz, g.oz, g.inv_cell);
+    q.cx = min(max((int)fminf(fmaxf(floorf(q.ux), -4.0f), 70000.0f), -1), g.dx);
+    q.cy = min(max((int)fminf(fmaxf(floorf(q.uy), -4.0f), 70000.0f), -1), g.dy);
+    q.cz = min(max((int)fminf(fmaxf(floorf(q.uz), -4.0f), 70000.0f), -1), g.dz);
+    return q;
+}
+
+// Rings 0 and 1 from global memory: the 3x3x3 cells around the query, at most 8 bricks.
+__device__ __forceinline__ void nn_near_global(const GridDev &g, const QueryGeom &qg, float qx, float qy, float qz, Best &b,
+                                               float &limit2)
+{
+    const float ux = qg.ux, uy = qg.uy, uz = qg.uz;
+    const int cx = qg.cx, cy = qg.cy, cz = qg.cz;
+    const float cell2 = g.cell * g.cell;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+    const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
+    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
+    if (x0 > x1 || y0 > y1 || z0 > z1) return;
+    // own cell first, then the rest of its brick, then the other bricks: the nearest
+    // point is usually in the own cell and tightens the limit for everything else
+    const int ocx = min(max(cx, x0), x1), ocy = min(max(cy, y0), y1), ocz = min(max(cz, z0), z1);
+    const int obx = ocx >> 2, oby = ocy >> 2, obz = ocz >> 2;
+    const unsigned long long own_bit = 1ull << ((ocz & 3) << 4 | (ocy & 3) << 2 | (ocx & 3));
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int bz = z0 >> 2; bz <= z1 >> 2; ++bz)
+            for (int by = y0 >> 2; by <= y1 >> 2; ++by)
+                for (int bx = x0 >> 2; bx <= x1 >> 2; ++bx) {
+                    const bool own = (bx == obx && by == oby && bz == obz);
+                    if (own != (pass == 0)) continue;
+                    const float gx = axis_gap(ux, max(bx << 2, x0), min((bx << 2) + 3, x1));
+                    const float gy = axis_gap(uy, max(by << 2, y0), min((by << 2) + 3, y1));
+                    const float gz = axis_gap(uz, max(bz << 2, z0), min((bz << 2) + 3, z1));
+                    if ((gx * gx + gy * gy + gz * gz) * cell2 > limit2) continue;
+                    unsigned long long mask;
+                    uint32_t base;
+                    if (!brick_lookup(g, bx, by, bz, mask, base)) continue;
+                    unsigned long long sel =
+                        mask & box_mask(max(x0 - (bx << 2), 0), min(x1 - (bx << 2), 3), max(y0 - (by << 2), 0),
+                                        min(y1 - (by << 2), 3), max(z0 - (bz << 2), 0), min(z1 - (bz << 2), 3));
+                    if (own && (sel & own_bit)) {
+                        visit_brick(g, own_bit, base, mask, bx, by, bz, ux, uy, uz, cell2, qx, qy, qz, b, limit2);
+                        sel &= ~own_bit;
+                    }
+                    visit_brick(g, sel, base, mask, bx, by, bz, ux, uy, uz, cell2, qx, qy, qz, b, limit2);
+                }
+    }
+}
+
+// Farther rings from global memory, only while something unvisited could still be closer.
+// Expands in shells of BRICKS around the query's brick (nearest first, so the limit tightens
+// early).  After shell rb every unvisited brick is >= rb+1 bricks away along some axis, i.e.
+// at least 4*rb cells from the query.  Cells within `inner` rings of the query's cell are
+// assumed visited already.
+__device__ __forceinline__ void nn_far_global(const GridDev &g, const QueryGeom &qg, float qx, float qy, float qz, Best &b,
+                                              float &limit2, int inner = 1)
+{
+    const float ux = qg.ux, uy = qg.uy, uz = qg.uz;
+    const int cx = qg.cx, cy = qg.cy, cz = qg.cz;
+    const float cell2 = g.cell * g.cell;
+    // after ring `inner` every unvisited cell is at least (inner - margin) cells away along some axis
+    const float ring1 = ((float)inner - kCellMargin) * g.cell;
+    if (limit2 <= ring1 * ring1 || g.max_ring <= inner) return;
+    const int nbx = (g.dx + 3) >> 2, nby = (g.dy + 3) >> 2, nbz = (g.dz + 3) >> 2;
+    const int qbx = min(max(cx, 0), g.dx - 1) >> 2, qby = min(max(cy, 0), g.dy - 1) >> 2, qbz = min(max(cz, 0), g.dz - 1) >> 2;
+    const int rb_grid = max(max(max(qbx, nbx - 1 - qbx), max(qby, nby - 1 - qby)), max(qbz, nbz - 1 - qbz));
+    const int rb_max = min(rb_grid, (g.max_ring + 3) / 4 + 1);
+    const int ix0 = max(cx - inner, 0), ix1 = min(cx + inner, g.dx - 1);
+    const int iy0 = max(cy - inner, 0), iy1 = min(cy + inner, g.dy - 1);
+    const int iz0 = max(cz - inner, 0), iz1 = min(cz + inner, g.dz - 1);
+    const bool inner_ok = ix0 <= ix1 && iy0 <= iy1 && iz0 <= iz1;
+    const int rb_inner = (inner + 3) / 4 + 1;  // bricks farther than this cannot touch the inner block
+    for (int rb = 0; rb <= rb_max; ++rb) {
+        for (int dz = -rb; dz <= rb; ++dz) {
+            const int bz = qbz + dz;
+            if (bz < 0 || bz >= nbz) continue;
+            const float gz = axis_gap(uz, bz << 2, (bz << 2) + 3);
+            if (gz * gz * cell2 > limit2) continue;
+            for (int dy = -rb; dy <= rb; ++dy) {
+                const int by = qby + dy;
+                if (by < 0 || by >= nby) continue;
+                const float gy = axis_gap(uy, by << 2, (by << 2) + 3);
+                if ((gy * gy + gz * gz) * cell2 > limit2) continue;
+                const bool face = (abs(dz) == rb) || (abs(dy) == rb);
+                const int step = face ? 1 : max(2 * rb, 1);
+                for (int bx = qbx - rb; bx <= qbx + rb; bx += step) {
+                    if (bx < 0 || bx >= nbx) continue;
+                    const float gx = axis_gap(ux, bx << 2, (bx << 2) + 3);
+                    if ((gx * gx + gy * gy + gz * gz) * cell2 > limit2) continue;
+                    unsigned long long mask;
+                    uint32_t base;
+                    if (!brick_lookup(g, bx, by, bz, mask, base)) continue;
+                    unsigned long long sel = mask;
+                    if (inner_ok && rb <= rb_inner) {  // drop the visited inner block where it intersects this brick
+                        const int jx0 = max(ix0 - (bx << 2), 0), jx1 = min(ix1 - (bx << 2), 3);
+                        const int jy0 = max(iy0 - (by << 2), 0), jy1 = min(iy1 - (by << 2), 3);
+                        const int jz0 = max(iz0 - (bz << 2), 0), jz1 = min(iz1 - (bz << 2), 3);
+                        if (jx0 <= jx1 && jy0 <= jy1 && jz0 <= jz1) sel &= ~box_mask(jx0, jx1, jy0, jy1, jz0, jz1);
+                    }
+                    visit_brick(g, sel, base, mask, bx, by, bz, ux, uy, uz, cell2, qx, qy, qz, b, limit2);
+                }
             }
         }
-        const float bound = (float)r * g.cell * kRingSafety;
-        if (b.d2 <= bound * bound) break;
+        const float reach = fmaxf((float)(4 * rb) - kCellMargin, 0.0f) * g.cell;
+        if (limit2 <= reach * reach) break;
     }
+}
+
+// Exact nearest neighbour within the gate.  Every cell that could hold a point at least as
+// close as the current best (or the gate) is visited; cells and bricks are skipped only on a
+// conservative geometric lower bound, so the result equals a brute-force scan including the
+// lowest-index tie-break.
+__device__ __forceinline__ Best nn_query(const GridDev &g, float qx, float qy, float qz)
+{
+    Best b{~0ull, -1, FLT_MAX};
+    if (g.dx <= 0) return b;
+    const QueryGeom qg = query_geom(g, qx, qy, qz);
+    float limit2 = g.prune2;  // nothing farther than this can be accepted or improve the best
+    nn_near_global(g, qg, qx, qy, qz, b, limit2);
+    nn_far_global(g, qg, qx, qy, qz, b, limit2);
     return b;
 }
 
@@ -393,29 +627,37 @@ __device__ __forceinline__ void accum_pair(double *a, float px, float py, float 
     a[16] += (double)d2;
 }
 
-// block-level reduction of per-thread sums into partials[blockIdx][17], fixed order
-__device__ __forceinline__ void block_reduce_store(double *a, double *partials)
+constexpr int kTile = 128;         // source points per workgroup in the iteration kernels: 2 waves
+constexpr int kTileWaves = kTile / 64;
+
+// Block-level reduction of per-thread sums into partials[k][blockIdx] (transposed slabs: the
+// final reduction reads each sum contiguously).  Fixed order, so the result depends only on
+// the number of source points, never on the GPU or on timing.
+__device__ __forceinline__ void tile_reduce_store(double *a, double *partials, uint32_t nblocks)
 {
-    __shared__ double sh[kBlock / 64][RSREG_NUM_SUMS];
+    __shared__ double shr[kTileWaves][RSREG_NUM_SUMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) {
         const double v = wave_sum(a[k]);
-        if (lane == 0) sh[wave][k] = v;
+        if (lane == 0) shr[wave][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < RSREG_NUM_SUMS) {
-        double v = sh[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; ++w) v += sh[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * RSREG_NUM_SUMS + threadIdx.x] = v;
+        double v = shr[0][threadIdx.x];
+        for (int w = 1; w < kTileWaves; ++w) v += shr[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * nblocks + blockIdx.x] = v;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cov_reduce(const float4 *cur, const int *corr_pos, const float *corr_d2,
-                                                       const float4 *tgt, uint32_t n, double *partials)
+// one source point per thread; block b covers points [b*128, b*128+128): every iteration
+// kernel uses the same mapping, so all pipelines add the same numbers in the same order
+__global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const int *corr_pos, const float *corr_d2,
+                                                      const float4 *tgt, uint32_t n, double *partials)
 {
     double a[RSREG_NUM_SUMS];
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
         const int pos = corr_pos[i];
         if (pos >= 0) {
             const float4 p = cur[i];
@@ -423,33 +665,39 @@ __global__ __launch_bounds__(kBlock) void k_cov_reduce(const float4 *cur, const 
             accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i]);
         }
     }
-    block_reduce_store(a, partials);
+    tile_reduce_store(a, partials, gridDim.x);
 }
 
-// one block: wave w reduces sums k = w, w+4, ... over all partial slabs in a fixed order
+// 17 blocks of 256 threads: block k adds sum k over all slabs, fixed order
 __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials, uint32_t nblocks, double *sums)
 {
+    __shared__ double shf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < RSREG_NUM_SUMS; k += kBlock / 64) {
-        double v = 0.0;
-        for (uint32_t b = lane; b < nblocks; b += 64) v += partials[(size_t)b * RSREG_NUM_SUMS + k];
-        v = wave_sum(v);
-        if (lane == 0) sums[k] = v;
+    const double *src = partials + (size_t)blockIdx.x * nblocks;
+    double v = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) v += src[b];
+    v = wave_sum(v);
+    if (lane == 0) shf[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = shf[0];
+        for (int w = 1; w < kBlock / 64; ++w) t += shf[w];
+        sums[blockIdx.x] = t;
     }
 }
 
-// One ICP iteration in one pass: apply the previous increment, search, gate, accumulate.
-// Writes the transformed source back (next iteration starts from it, like PCL's in-place
-// transformCloud) and, when asked, the correspondences.
-__global__ __launch_bounds__(kBlock) void k_icp_fused(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g,
-                                                      double gate2, int *corr_pos, float *corr_d2, double *partials)
+// One ICP iteration in one pass from global memory (the LDS-staged form is k_icp_tile):
+// apply the previous increment, search, gate, accumulate.  Writes the transformed source back
+// (next iteration starts from it, like PCL's in-place transformCloud).
+__global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g,
+                                                     double gate2, int *corr_pos, float *corr_d2, double *partials)
 {
-    double a[RSREG_NUM_SUMS];
-    for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 q = cur[i];
-        int pos = -1;
-        float d2 = 0.0f;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int pos = -1;
+    float d2 = 0.0f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        q = cur[i];
         if (q.w != 0.0f) {
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
@@ -460,22 +708,30 @@ __global__ __launch_bounds__(kBlock) void k_icp_fused(float4 *cur, uint32_t n, M
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
                 d2 = b.d2;
-                const float4 t = g.pts[b.pos];
-                accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2);
             }
         }
         if (corr_pos) { corr_pos[i] = pos; corr_d2[i] = d2; }
     }
-    block_reduce_store(a, partials);
+    // the 17 accumulators only come alive after the search: they do not cost it registers
+    double a[RSREG_NUM_SUMS];
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
+    if (pos >= 0) {
+        const float4 t = g.pts[pos];
+        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2);
+    }
+    tile_reduce_store(a, partials, gridDim.x);
 }
 
-// corr position in the sorted array -> index in the caller's target array
-__global__ __launch_bounds__(kBlock) void k_corr_to_index(const int *corr_pos, const float4 *tgt, uint32_t n, int *index_out)
+// corr (sorted source order, position in the sorted target) -> caller's order and indices
+__global__ __launch_bounds__(kBlock) void k_export_corr(const int *corr_pos, const float *corr_d2, const float4 *tgt,
+                                                        const uint32_t *perm, uint32_t n, int *index_out, float *d2_out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int pos = corr_pos[i];
-    index_out[i] = pos >= 0 ? (int)__float_as_uint(tgt[pos].w) : -1;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int pos = corr_pos[j];
+    const uint32_t o = perm ? perm[j] : j;
+    index_out[o] = pos >= 0 ? (int)__float_as_uint(tgt[pos].w) : -1;
+    d2_out[o] = corr_d2[j];
 }
 
 }  // namespace rsreg

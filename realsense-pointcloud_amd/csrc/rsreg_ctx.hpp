@@ -67,15 +67,18 @@ struct GridParams {
     float inv_cell;
     float cell;
     int dims[3];
-    uint32_t table_mask;   // hash table has table_mask + 1 slots
+    uint32_t table_mask;   // brick hash table has table_mask + 1 slots
     uint32_t n_points;     // unique finite target points in `sorted`
-    uint32_t n_cells;
-    int max_ring;          // rings needed to cover the correspondence gate
+    uint32_t n_cells;      // occupied cells
+    uint32_t n_bricks;     // occupied 4x4x4-cell bricks
+    int max_ring;          // rings (cells) needed to cover the correspondence gate
 };
 
-struct CellEntry {         // 16 B, one hash-table slot
-    unsigned long long key;  // packed cell coordinate, ~0 = empty
-    uint32_t start, count;   // run in the sorted point array
+struct BrickEntry {          // 32 B, one hash-table slot
+    unsigned long long key;  // packed brick coordinate, ~0 = empty
+    unsigned long long mask; // occupancy of its 64 cells, bit = lz*16 + ly*4 + lx
+    uint32_t base;           // id of its first occupied cell (cellpos index)
+    uint32_t pad[3];
 };
 
 struct IcpState {
@@ -107,8 +110,9 @@ struct rsreg_ctx {
     double gate_built_for = 0;
     rsreg::DevBuf d_tgt_raw;      // packed xyz of the caller's target (n x float3)
     rsreg::DevBuf d_tgt_sorted;   // float4 {x,y,z,bits(orig index)}, cell-sorted, de-duplicated
-    rsreg::DevBuf d_table;        // CellEntry[table_mask+1]
-    rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_cellpos, d_cellkey, d_tmp;
+    rsreg::DevBuf d_table;        // BrickEntry[table_mask+1]
+    rsreg::DevBuf d_cellpos;      // uint32[n_cells+1]: first sorted point of each occupied cell
+    rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     size_t n_target_raw = 0;
 
@@ -116,7 +120,8 @@ struct rsreg_ctx {
     bool have_source = false;
     size_t n_source = 0;
     rsreg::DevBuf d_src_raw;      // packed xyz as handed in
-    rsreg::DevBuf d_src;          // float4 {x,y,z,valid}
+    rsreg::DevBuf d_perm;         // uint32: spatially sorted position -> caller's index
+    rsreg::DevBuf d_src;          // float4 {x,y,z,valid}, spatially sorted
     rsreg::DevBuf d_cur;          // float4 current (transformed) source
     rsreg::DevBuf d_corr_pos;     // int32: position in d_tgt_sorted, -1 = none
     rsreg::DevBuf d_corr_d2;      // float

@@ -1,0 +1,401 @@
+// pcl_compat.hpp — header-only C++ host layer over the C ABI (include/rsreg.h).
+//
+// The reference (hyunminch/realsense-pointcloud) is compiled C++ that calls PCL classes; this
+// header offers the same class surface — names, argument meaning, error behaviour — for
+// exactly the calls its registration schemes make, so that a scheme written
+// against PCL compiles against `rsreg::` with a namespace switch:
+//
+//   pcl::PointXYZRGB / pcl::PointCloud<T> / ::Ptr          src/types.hpp:8-10
+//   pcl::IterativeClosestPoint<S,T>                         src/incremental_icp.hpp:37,46-63
+//   pcl::NormalDistributionsTransform<S,T>                  src/ndt_edge_based_registration.hpp:37-43,71-104
+//   pcl::ApproximateVoxelGrid<T>                            src/icp_edge_based_registration.hpp:38,47,59-60
+//   pcl::transformPointCloud(in, out, Matrix4f)             src/incremental_icp.hpp:63
+//   pcl::io::loadPCDFile / savePCDFileBinary                src/main.cpp:81,87
+//   Eigen::Matrix4f, AngleAxisf * Translation3f products    src/icp_edge...hpp:81-92 (as rsreg::Matrix4f helpers)
+//
+// No PCL, Eigen or Boost is needed.  All numerics run on the MI355X through librsreg.so; a
+// missing GPU makes the calls throw rsreg::Error (there is no CPU fallback).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rsreg.h"
+
+namespace rsreg {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(int status, rsreg_ctx *ctx = nullptr)
+{
+    if (status == RSREG_OK) return;
+    std::string msg = std::string("rsreg: ") + rsreg_status_string(status);
+    if (ctx) msg += std::string(" (") + rsreg_last_error(ctx) + ")";
+    throw Error(status, msg);
+}
+
+// ---- pcl::PointXYZRGB: 32 bytes, 16-byte aligned, rgb at byte 16
+struct alignas(16) PointXYZRGB {
+    float x = 0.f, y = 0.f, z = 0.f, data3 = 1.f;
+    union {
+        struct { uint8_t b, g, r, a; };
+        float rgb;
+        uint32_t rgba;
+    };
+    uint32_t pad_[3] = {0, 0, 0};
+    PointXYZRGB() : rgba(0xff000000u) {}
+    PointXYZRGB(float x_, float y_, float z_) : x(x_), y(y_), z(z_), rgba(0xff000000u) {}
+};
+static_assert(sizeof(PointXYZRGB) == 32, "PointXYZRGB must stay byte-compatible with pcl::PointXYZRGB");
+
+// ---- pcl::PointCloud<PointT>
+template <typename PointT> struct PointCloud {
+    using Ptr = std::shared_ptr<PointCloud<PointT>>;
+    using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
+    std::vector<PointT> points;
+    uint32_t width = 0, height = 0;
+    bool is_dense = true;
+
+    size_t size() const { return points.size(); }
+    bool empty() const { return points.empty(); }
+    bool isOrganized() const { return height > 1; }
+    void clear() { points.clear(); width = height = 0; }
+    void push_back(const PointT &p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
+    PointT &operator[](size_t i) { return points[i]; }
+    const PointT &operator[](size_t i) const { return points[i]; }
+
+    // concatenation: width = size, height = 1, dense only if both are
+    PointCloud &operator+=(const PointCloud &rhs)
+    {
+        points.insert(points.end(), rhs.points.begin(), rhs.points.end());
+        width = (uint32_t)points.size();
+        height = 1;
+        is_dense = is_dense && rhs.is_dense;
+        return *this;
+    }
+    PointCloud operator+(const PointCloud &rhs) const
+    {
+        PointCloud out = *this;
+        out += rhs;
+        return out;
+    }
+};
+
+// ---- Eigen::Matrix4f stand-in: 16 floats, column-major
+struct Matrix4f {
+    float m[16];
+    Matrix4f() { std::memset(m, 0, sizeof(m)); }
+    static Matrix4f Identity()
+    {
+        Matrix4f r;
+        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f;
+        return r;
+    }
+    float &operator()(int r, int c) { return m[c * 4 + r]; }
+    float operator()(int r, int c) const { return m[c * 4 + r]; }
+    const float *data() const { return m; }
+    float *data() { return m; }
+    Matrix4f operator*(const Matrix4f &o) const
+    {
+        Matrix4f r;
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+                for (int k = 0; k < 4; ++k) s += m[k * 4 + i] * o.m[j * 4 + k];
+                r.m[j * 4 + i] = s;
+            }
+        return r;
+    }
+    bool operator==(const Matrix4f &o) const { return std::memcmp(m, o.m, sizeof(m)) == 0; }
+    bool operator!=(const Matrix4f &o) const { return !(*this == o); }
+    // (Eigen::Translation3f(t) * Eigen::AngleAxisf(angle, axis)).matrix() pieces
+    static Matrix4f RotationX(float a) { Matrix4f r = Identity(); const float c = std::cos(a), s = std::sin(a); r(1, 1) = c; r(1, 2) = -s; r(2, 1) = s; r(2, 2) = c; return r; }
+    static Matrix4f RotationY(float a) { Matrix4f r = Identity(); const float c = std::cos(a), s = std::sin(a); r(0, 0) = c; r(0, 2) = s; r(2, 0) = -s; r(2, 2) = c; return r; }
+    static Matrix4f RotationZ(float a) { Matrix4f r = Identity(); const float c = std::cos(a), s = std::sin(a); r(0, 0) = c; r(0, 1) = -s; r(1, 0) = s; r(1, 1) = c; return r; }
+    static Matrix4f Translation(float x, float y, float z) { Matrix4f r = Identity(); r(0, 3) = x; r(1, 3) = y; r(2, 3) = z; return r; }
+};
+
+// ---- one execution context per (device, stream); shared default on device 0
+class Context {
+  public:
+    explicit Context(int device = 0, void *stream = nullptr) { check(rsreg_ctx_create(device, stream, &ctx_)); }
+    ~Context() { if (ctx_) rsreg_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    rsreg_ctx *get() const { return ctx_; }
+    static std::shared_ptr<Context> Default()
+    {
+        static std::shared_ptr<Context> ctx = std::make_shared<Context>(0);
+        return ctx;
+    }
+  private:
+    rsreg_ctx *ctx_ = nullptr;
+};
+
+namespace detail {
+template <typename PointT> void copy_aligned(const PointCloud<PointT> &src, PointCloud<PointT> &out)
+{
+    out.points = src.points;  // fields other than xyz are the source's (PCL copies the input first)
+    out.width = src.width;
+    out.height = src.height;
+    out.is_dense = src.is_dense;
+}
+}  // namespace detail
+
+// ---- pcl::IterativeClosestPoint
+template <typename PointSource, typename PointTarget> class IterativeClosestPoint {
+  public:
+    using SourcePtr = typename PointCloud<PointSource>::Ptr;
+    using TargetPtr = typename PointCloud<PointTarget>::Ptr;
+
+    explicit IterativeClosestPoint(std::shared_ptr<Context> ctx = Context::Default()) : ctx_(std::move(ctx))
+    {
+        rsreg_icp_params_default(&prm_);
+        final_ = Matrix4f::Identity();
+    }
+    void setMaximumIterations(int n) { prm_.max_iterations = n; }
+    void setMaxCorrespondenceDistance(double d)
+    {
+        if (d != prm_.max_correspondence_distance) target_dirty_ = true;  // the index cell size derives from it
+        prm_.max_correspondence_distance = d;
+    }
+    void setTransformationEpsilon(double e) { prm_.transformation_epsilon = e; }
+    void setTransformationRotationEpsilon(double e) { prm_.transformation_rotation_epsilon = e; }
+    void setEuclideanFitnessEpsilon(double e) { prm_.euclidean_fitness_epsilon = e; }
+    void setInputSource(const SourcePtr &cloud) { source_ = cloud; source_dirty_ = true; }
+    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; target_dirty_ = true; }  // PCL rebuilds its kd-tree here too
+    // engine knobs without a PCL counterpart
+    void setFixedIterationCount(bool on) { prm_.criteria_mode = on ? RSREG_CRITERIA_FIXED : RSREG_CRITERIA_PCL; }
+    void setPipelineMode(int mode) { prm_.pipeline_mode = mode; }
+
+    void align(PointCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
+    void align(PointCloud<PointSource> &output, const Matrix4f &guess)
+    {
+        if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
+        rsreg_ctx *c = ctx_->get();
+        if (target_dirty_) {
+            check(rsreg_icp_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
+                                       prm_.max_correspondence_distance), c);
+            target_dirty_ = false;
+        }
+        if (source_dirty_) {
+            check(rsreg_icp_set_source(c, source_->points.data(), source_->size(), sizeof(PointSource), source_->is_dense), c);
+            source_dirty_ = false;
+        }
+        PointCloud<PointSource> tmp;
+        detail::copy_aligned(*source_, tmp);
+        check(rsreg_icp_align(c, guess.data(), &prm_, &res_, tmp.points.data(), sizeof(PointSource)), c);
+        std::memcpy(final_.m, res_.transform, sizeof(final_.m));
+        output = std::move(tmp);
+    }
+    bool hasConverged() const { return res_.converged != 0; }
+    Matrix4f getFinalTransformation() const { return final_; }
+    int getConvergenceState() const { return res_.state; }
+    const rsreg_icp_result &result() const { return res_; }
+
+  private:
+    std::shared_ptr<Context> ctx_;
+    rsreg_icp_params prm_;
+    rsreg_icp_result res_{};
+    Matrix4f final_;
+    SourcePtr source_;
+    TargetPtr target_;
+    bool source_dirty_ = true, target_dirty_ = true;
+};
+
+// ---- pcl::NormalDistributionsTransform
+template <typename PointSource, typename PointTarget> class NormalDistributionsTransform {
+  public:
+    using SourcePtr = typename PointCloud<PointSource>::Ptr;
+    using TargetPtr = typename PointCloud<PointTarget>::Ptr;
+
+    explicit NormalDistributionsTransform(std::shared_ptr<Context> ctx = Context::Default()) : ctx_(std::move(ctx))
+    {
+        rsreg_ndt_params_default(&prm_);
+        final_ = Matrix4f::Identity();
+    }
+    void setTransformationEpsilon(double e) { prm_.transformation_epsilon = e; }
+    void setStepSize(double s) { prm_.step_size = s; }
+    void setResolution(float r)
+    {
+        if ((double)r != prm_.resolution) target_dirty_ = true;
+        prm_.resolution = r;
+    }
+    void setMaximumIterations(int n) { prm_.max_iterations = n; }
+    void setInputSource(const SourcePtr &cloud) { source_ = cloud; }
+    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; target_dirty_ = true; }
+
+    void align(PointCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
+    void align(PointCloud<PointSource> &output, const Matrix4f &guess)
+    {
+        if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
+        rsreg_ctx *c = ctx_->get();
+        if (target_dirty_) {
+            check(rsreg_ndt_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
+                                       prm_.resolution), c);
+            target_dirty_ = false;
+        }
+        PointCloud<PointSource> tmp;
+        detail::copy_aligned(*source_, tmp);
+        check(rsreg_ndt_align(c, source_->points.data(), source_->size(), sizeof(PointSource), source_->is_dense, guess.data(),
+                              &prm_, &res_, tmp.points.data(), sizeof(PointSource)), c);
+        std::memcpy(final_.m, res_.transform, sizeof(final_.m));
+        output = std::move(tmp);
+    }
+    bool hasConverged() const { return res_.converged != 0; }
+    Matrix4f getFinalTransformation() const { return final_; }
+    double getTransformationProbability() const { return res_.trans_probability; }
+    int getFinalNumIteration() const { return res_.iterations; }
+    const rsreg_ndt_result &result() const { return res_; }
+
+  private:
+    std::shared_ptr<Context> ctx_;
+    rsreg_ndt_params prm_;
+    rsreg_ndt_result res_{};
+    Matrix4f final_;
+    SourcePtr source_;
+    TargetPtr target_;
+    bool target_dirty_ = true;
+};
+
+// ---- pcl::ApproximateVoxelGrid (host, sequential: order-dependent by definition)
+template <typename PointT> class ApproximateVoxelGrid {
+  public:
+    void setLeafSize(float lx, float ly, float lz) { leaf_[0] = lx; leaf_[1] = ly; leaf_[2] = lz; }
+    void setInputCloud(const typename PointCloud<PointT>::Ptr &cloud) { input_ = cloud; }
+    void filter(PointCloud<PointT> &output)  // output may be *input (the reference filters in place)
+    {
+        if (!input_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputCloud not called");
+        std::vector<PointT> out(input_->size());
+        size_t n_out = 0;
+        check(rsreg_approx_voxel_grid(input_->points.data(), input_->size(), sizeof(PointT), leaf_, out.data(), &n_out));
+        out.resize(n_out);
+        output.points = std::move(out);
+        output.width = (uint32_t)n_out;
+        output.height = 1;
+        output.is_dense = false;
+    }
+  private:
+    float leaf_[3] = {1.f, 1.f, 1.f};  // PCL default: IncrementalICP never sets it (incremental_icp.hpp:36)
+    typename PointCloud<PointT>::Ptr input_;
+};
+
+// ---- pcl::transformPointCloud(in, out, Matrix4f); in and out may be the same object
+template <typename PointT>
+void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, const Matrix4f &T,
+                         const std::shared_ptr<Context> &ctx = Context::Default())
+{
+    std::vector<PointT> pts(in.size());
+    check(rsreg_transform_cloud(ctx->get(), in.points.data(), pts.data(), in.size(), sizeof(PointT), in.is_dense, T.data()),
+          ctx->get());
+    const uint32_t w = in.width, h = in.height;
+    const bool dense = in.is_dense;
+    out.points = std::move(pts);
+    out.width = w;
+    out.height = h;
+    out.is_dense = dense;
+}
+
+// ---- pcl::io: PCD files with FIELDS x y z rgb (ascii or binary), as the reference reads/writes
+namespace io {
+
+inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return -1;
+    std::string line, data_mode;
+    std::vector<std::string> fields, types;
+    std::vector<int> sizes;
+    size_t n = 0;
+    uint32_t width = 0, height = 1;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string key;
+        ss >> key;
+        if (key == "FIELDS") { std::string s; while (ss >> s) fields.push_back(s); }
+        else if (key == "SIZE") { int s; while (ss >> s) sizes.push_back(s); }
+        else if (key == "TYPE") { std::string s; while (ss >> s) types.push_back(s); }
+        else if (key == "WIDTH") ss >> width;
+        else if (key == "HEIGHT") ss >> height;
+        else if (key == "POINTS") ss >> n;
+        else if (key == "DATA") { ss >> data_mode; break; }
+    }
+    if (n == 0) n = (size_t)width * height;
+    int ix = -1, iy = -1, iz = -1, ic = -1;
+    for (size_t k = 0; k < fields.size(); ++k) {
+        if (fields[k] == "x") ix = (int)k;
+        else if (fields[k] == "y") iy = (int)k;
+        else if (fields[k] == "z") iz = (int)k;
+        else if (fields[k] == "rgb" || fields[k] == "rgba") ic = (int)k;
+    }
+    if (ix < 0 || iy < 0 || iz < 0) return -2;
+    cloud.points.assign(n, PointXYZRGB());
+    cloud.width = width;
+    cloud.height = height;
+    bool dense = true;
+    if (data_mode == "ascii") {
+        for (size_t i = 0; i < n; ++i) {
+            PointXYZRGB &p = cloud.points[i];
+            for (size_t k = 0; k < fields.size(); ++k) {
+                std::string tok;
+                f >> tok;
+                if ((int)k == ic) {
+                    if (types[k] == "F") { float v = std::stof(tok); std::memcpy(&p.rgba, &v, 4); }
+                    else p.rgba = (uint32_t)std::stoul(tok);
+                } else {
+                    const float v = std::stof(tok);
+                    if ((int)k == ix) p.x = v; else if ((int)k == iy) p.y = v; else if ((int)k == iz) p.z = v;
+                }
+            }
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) dense = false;
+        }
+    } else if (data_mode == "binary") {
+        size_t rec = 0;
+        std::vector<size_t> off(fields.size());
+        for (size_t k = 0; k < fields.size(); ++k) { off[k] = rec; rec += (size_t)sizes[k]; }
+        std::vector<char> buf(rec * n);
+        f.read(buf.data(), (std::streamsize)buf.size());
+        for (size_t i = 0; i < n; ++i) {
+            PointXYZRGB &p = cloud.points[i];
+            const char *r = buf.data() + i * rec;
+            std::memcpy(&p.x, r + off[ix], 4);
+            std::memcpy(&p.y, r + off[iy], 4);
+            std::memcpy(&p.z, r + off[iz], 4);
+            if (ic >= 0) std::memcpy(&p.rgba, r + off[ic], 4);
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) dense = false;
+        }
+    } else {
+        return -3;  // binary_compressed is not supported yet
+    }
+    cloud.is_dense = dense;
+    return 0;
+}
+
+inline int savePCDFileBinary(const std::string &path, const PointCloud<PointXYZRGB> &cloud)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return -1;
+    f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+      << "WIDTH " << cloud.width << "\nHEIGHT " << cloud.height << "\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << cloud.size()
+      << "\nDATA binary\n";
+    for (const PointXYZRGB &p : cloud.points) {
+        f.write(reinterpret_cast<const char *>(&p.x), 12);
+        f.write(reinterpret_cast<const char *>(&p.rgba), 4);
+    }
+    return f ? 0 : -1;
+}
+
+}  // namespace io
+}  // namespace rsreg

@@ -1,0 +1,216 @@
+// schemes.hpp — the reference's registration schemes on top of rsreg/pcl_compat.hpp.
+//
+// Same public surface as the reference:
+//   RegistrationScheme::registration(std::vector<cloud_ptr>&) -> cloud_ptr        src/types.hpp:14-20
+//   TwoPhaseRegistrationScheme: extract_features / global_registration             src/types.hpp:22-44
+//   IncrementalICP                                                                 src/incremental_icp.hpp:33-70
+//   ICPEdgeBasedRegistration  (static yaw or IMU Euler-angle guesses)              src/icp_edge_based_registration.hpp:10-136
+//   NDTEdgeBasedRegistration  (NDT guess, ICP refine)                              src/ndt_edge_based_registration.hpp:7-123
+// and the same observable behaviour: which clouds are filtered, which are aliased and
+// mutated (frame 0 IS the accumulating target), the hard-coded parameters, the order of
+// concatenation, frames whose ICP does not converge being skipped silently.
+//
+// Out of scope here: the RGB-Canny edge extractor.  `extract_features`
+// forwards to a user-supplied functor; the default hands the cloud through unchanged.
+#pragma once
+
+#include <cassert>
+#include <functional>
+#include <iostream>
+#include <utility>
+
+#include "pcl_compat.hpp"
+
+namespace rsreg {
+
+using rgb_point = PointXYZRGB;
+using rgb_point_cloud = PointCloud<rgb_point>;
+using rgb_point_cloud_pointer = rgb_point_cloud::Ptr;
+
+// src/utils.hpp:30-62 — only what the schemes use
+struct float3 {
+    float x, y, z;
+    float3 operator*(float t) const { return {x * t, y * t, z * t}; }
+    void add(float t1, float t2, float t3) { x += t1; y += t2; z += t3; }
+};
+
+class RegistrationScheme {
+  public:
+    virtual ~RegistrationScheme() = default;
+    virtual rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) = 0;
+    bool verbose = false;  // the reference prints progress lines to stdout
+};
+
+class TwoPhaseRegistrationScheme : public RegistrationScheme {
+  public:
+    using FeatureFn = std::function<rgb_point_cloud_pointer(rgb_point_cloud_pointer)>;
+    using PairList = std::vector<std::pair<rgb_point_cloud_pointer, rgb_point_cloud_pointer>>;
+
+    virtual rgb_point_cloud_pointer extract_features(rgb_point_cloud_pointer cloud)
+    {
+        if (feature_fn) return feature_fn(cloud);
+        return std::make_shared<rgb_point_cloud>(*cloud);  // stand-in for extract_edge_features
+    }
+    // given (feature cloud, original cloud) pairs, compute the merged global cloud
+    virtual rgb_point_cloud_pointer global_registration(PairList &clouds) = 0;
+
+    rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
+    {
+        PairList pairs;
+        for (auto &c : clouds) pairs.emplace_back(extract_features(c), c);   // phase 1
+        return global_registration(pairs);                                    // phase 2
+    }
+    FeatureFn feature_fn;
+};
+
+namespace detail {
+inline void reference_icp_parameters(IterativeClosestPoint<rgb_point, rgb_point> &icp)
+{
+    icp.setMaximumIterations(100);
+    icp.setMaxCorrespondenceDistance(0.01);
+    icp.setTransformationEpsilon(1);
+    icp.setEuclideanFitnessEpsilon(1000);
+}
+}  // namespace detail
+
+// Frame-to-model chain: every frame is registered against everything merged so far.
+class IncrementalICP : public RegistrationScheme {
+  public:
+    rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
+    {
+        ApproximateVoxelGrid<rgb_point> voxel;  // leaf never set: PCL's 1 m default applies
+        IterativeClosestPoint<rgb_point, rgb_point> icp;
+        detail::reference_icp_parameters(icp);
+        rgb_point_cloud_pointer model = clouds[0];  // aliases (and grows) the caller's frame 0
+        auto reduced = std::make_shared<rgb_point_cloud>();
+        for (size_t k = 1; k < clouds.size(); ++k) {
+            rgb_point_cloud aligned;
+            voxel.setInputCloud(clouds[k]);
+            voxel.filter(*reduced);
+            icp.setInputSource(reduced);
+            icp.setInputTarget(model);
+            icp.align(aligned);
+            if (!icp.hasConverged()) continue;
+            rgb_point_cloud moved;
+            transformPointCloud(*clouds[k], moved, icp.getFinalTransformation());
+            *model += moved;
+            transforms.push_back(icp.getFinalTransformation());
+        }
+        return model;
+    }
+    std::vector<Matrix4f> transforms;  // per merged frame (engine extra, for tests)
+};
+
+// Shared skeleton of the two edge-based schemes: a coarse aligner that takes an initial
+// guess, then an ICP refinement from the coarse result; the full clouds only get moved.
+class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
+  public:
+    EdgeBasedRegistrationBase() = default;
+    explicit EdgeBasedRegistrationBase(std::vector<float3> &input_thetas) : thetas(input_thetas), use_imu(true) {}
+    explicit EdgeBasedRegistrationBase(float usr_def_rads) : rads(usr_def_rads) {}
+
+    rgb_point_cloud_pointer global_registration(PairList &clouds) override
+    {
+        if (use_imu) assert(clouds.size() == thetas.size());
+        IterativeClosestPoint<rgb_point, rgb_point> icp;
+        detail::reference_icp_parameters(icp);
+        ApproximateVoxelGrid<rgb_point> voxel;
+        voxel.setLeafSize(0.01f, 0.01f, 0.01f);
+        configure_coarse();
+
+        rgb_point_cloud_pointer target = clouds[0].first;   // frame-0 features: filtered in place, then grown
+        auto merged = std::make_shared<rgb_point_cloud>();
+        *merged = *merged + *clouds[0].second;
+        voxel.setInputCloud(target);
+        voxel.filter(*target);
+        auto reduced = std::make_shared<rgb_point_cloud>();
+        float acc_rads = 0.f;
+        frame_transforms.clear();
+        for (size_t k = 1; k < clouds.size(); ++k) {
+            auto coarse_out = std::make_shared<rgb_point_cloud>();
+            rgb_point_cloud refined;
+            voxel.setInputCloud(clouds[k].first);
+            voxel.filter(*reduced);
+            Matrix4f guess;
+            if (use_imu) {
+                const float3 rel = thetas[0] * -1.0f;
+                thetas[k].add(rel.x, rel.y, rel.z);  // the reference mutates thetas in place
+                guess = imu_guess(thetas[k]);
+            } else {
+                acc_rads += rads;
+                guess = Matrix4f::RotationY(acc_rads);
+            }
+            const Matrix4f t_coarse = coarse_align(reduced, target, *coarse_out, guess);
+            icp.setInputSource(coarse_out);
+            icp.setInputTarget(target);
+            icp.align(refined);
+            if (!icp.hasConverged()) continue;   // frame dropped silently, like the reference
+            rgb_point_cloud moved;
+            transformPointCloud(*clouds[k].second, moved, t_coarse);
+            transformPointCloud(moved, moved, icp.getFinalTransformation());
+            *target = refined + *target;   // new points first
+            *merged = *merged + moved;
+            frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
+        }
+        return merged;
+    }
+    std::vector<std::pair<Matrix4f, Matrix4f>> frame_transforms;  // (coarse, refine) per merged frame
+
+  protected:
+    virtual void configure_coarse() = 0;
+    virtual Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
+                                  const Matrix4f &guess) = 0;
+    virtual Matrix4f imu_guess(const float3 &theta) const = 0;
+
+    std::vector<float3> thetas;
+    bool use_imu = false;
+    float rads = -0.523599f;
+};
+
+class ICPEdgeBasedRegistration : public EdgeBasedRegistrationBase {
+  public:
+    using EdgeBasedRegistrationBase::EdgeBasedRegistrationBase;
+  protected:
+    void configure_coarse() override { detail::reference_icp_parameters(coarse_); }
+    Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
+                          const Matrix4f &guess) override
+    {
+        coarse_.setInputSource(src);
+        coarse_.setInputTarget(tgt);
+        coarse_.align(out, guess);
+        return coarse_.getFinalTransformation();
+    }
+    // AngleAxis(theta.x, Z) * AngleAxis(-theta.y, Y) * AngleAxis(theta.z, X), no translation
+    Matrix4f imu_guess(const float3 &t) const override
+    {
+        return Matrix4f::RotationZ(t.x) * Matrix4f::RotationY(-t.y) * Matrix4f::RotationX(t.z);
+    }
+  private:
+    IterativeClosestPoint<rgb_point, rgb_point> coarse_;
+};
+
+class NDTEdgeBasedRegistration : public EdgeBasedRegistrationBase {
+  public:
+    using EdgeBasedRegistrationBase::EdgeBasedRegistrationBase;
+  protected:
+    void configure_coarse() override
+    {
+        ndt_.setTransformationEpsilon(0.01);
+        ndt_.setStepSize(0.1);
+        ndt_.setResolution(1.0f);
+        ndt_.setMaximumIterations(50);
+    }
+    Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
+                          const Matrix4f &guess) override
+    {
+        ndt_.setInputSource(src);
+        ndt_.setInputTarget(tgt);
+        ndt_.align(out, guess);
+        return ndt_.getFinalTransformation();
+    }
+    Matrix4f imu_guess(const float3 &t) const override { return Matrix4f::RotationY(-t.y); }
+  private:
+    NormalDistributionsTransform<rgb_point, rgb_point> ndt_;
+};
+
+}  // namespace rsreg

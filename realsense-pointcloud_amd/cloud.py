@@ -58,7 +58,10 @@ class PointCloud:
     def __add__(self, other):
         """pcl::PointCloud::operator+ (incremental_icp.hpp:64, icp_edge...hpp:57,119-120):
         concatenate, width = size, height = 1, is_dense = both dense."""
-        pts = np.concatenate([self.points, other.points])
+        na, nb = len(self.points), len(other.points)
+        pts = np.zeros(na + nb, POINT_DTYPE)  # (np.concatenate would repack the padded record layout)
+        pts[:na] = self.points
+        pts[na:] = other.points
         return PointCloud(pts, width=len(pts), height=1, is_dense=self.is_dense and other.is_dense)
 
 

@@ -1,0 +1,84 @@
+// scheme_runner — drives the C++ host layer (include/rsreg/*.hpp) from the command line so
+// that the Python GPU tests can compare it with the ctypes path and the CPU checker.
+//   scheme_runner <incremental|icp_edge|ndt_edge|icp_pair|ndt_pair> <out_prefix> <a.pcd> <b.pcd> [...]
+// Writes <out_prefix>.pcd (merged / aligned cloud) and <out_prefix>.txt (4x4 transforms, row-major).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "rsreg/schemes.hpp"
+
+using namespace rsreg;
+
+static void dump(FILE *f, const Matrix4f &T)
+{
+    for (int r = 0; r < 4; ++r) std::fprintf(f, "%.9g %.9g %.9g %.9g\n", T(r, 0), T(r, 1), T(r, 2), T(r, 3));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s <mode> <out_prefix> <pcd> <pcd> [...]\n", argv[0]);
+        return 2;
+    }
+    const std::string mode = argv[1], prefix = argv[2];
+    try {
+        std::vector<rgb_point_cloud_pointer> clouds;
+        for (int i = 3; i < argc; ++i) {
+            auto c = std::make_shared<rgb_point_cloud>();
+            if (io::loadPCDFile(argv[i], *c) != 0) {
+                std::fprintf(stderr, "cannot read %s\n", argv[i]);
+                return 3;
+            }
+            clouds.push_back(c);
+        }
+        FILE *f = std::fopen((prefix + ".txt").c_str(), "w");
+        rgb_point_cloud_pointer out;
+        if (mode == "incremental") {
+            IncrementalICP s;
+            out = s.registration(clouds);
+            for (auto &T : s.transforms) dump(f, T);
+        } else if (mode == "icp_edge" || mode == "ndt_edge") {
+            const float rads = -0.0261799f;  // -1.5 deg per frame: the synthetic "bench" preset's yaw
+            if (mode == "icp_edge") {
+                ICPEdgeBasedRegistration s(rads);
+                out = s.registration(clouds);
+                for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
+            } else {
+                NDTEdgeBasedRegistration s(rads);
+                out = s.registration(clouds);
+                for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
+            }
+        } else if (mode == "icp_pair") {   // incremental_icp.hpp:57-63 on one pair, reference parameters
+            IterativeClosestPoint<rgb_point, rgb_point> icp;
+            detail::reference_icp_parameters(icp);
+            icp.setInputSource(clouds[1]);
+            icp.setInputTarget(clouds[0]);
+            out = std::make_shared<rgb_point_cloud>();
+            icp.align(*out);
+            std::fprintf(f, "%d %d %d\n", (int)icp.hasConverged(), icp.result().iterations, icp.getConvergenceState());
+            dump(f, icp.getFinalTransformation());
+        } else if (mode == "ndt_pair") {
+            NormalDistributionsTransform<rgb_point, rgb_point> ndt;
+            ndt.setTransformationEpsilon(0.01);
+            ndt.setStepSize(0.1);
+            ndt.setResolution(1.0f);
+            ndt.setMaximumIterations(50);
+            ndt.setInputSource(clouds[1]);
+            ndt.setInputTarget(clouds[0]);
+            out = std::make_shared<rgb_point_cloud>();
+            ndt.align(*out, Matrix4f::RotationY(0.01f));
+            std::fprintf(f, "%d %d\n", (int)ndt.hasConverged(), ndt.getFinalNumIteration());
+            dump(f, ndt.getFinalTransformation());
+        } else {
+            std::fprintf(stderr, "unknown mode %s\n", mode.c_str());
+            return 2;
+        }
+        std::fclose(f);
+        io::savePCDFileBinary(prefix + ".pcd", *out);
+    } catch (const Error &e) {
+        std::fprintf(stderr, "rsreg error %d: %s\n", e.status, e.what());
+        return e.status == RSREG_ERR_NO_DEVICE ? 66 : 1;
+    }
+    return 0;
+}

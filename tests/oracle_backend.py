@@ -1,0 +1,79 @@
+"""A scheme backend that runs the building blocks on the CPU oracle (TEST INFRASTRUCTURE: lets
+tests drive the product's scheme logic with the checker instead of the HIP engine)."""
+import numpy as np
+
+import oracle
+import rsreg_amd
+from rsreg_amd.cloud import PointCloud
+
+
+class _OracleIcp:
+    def __init__(self):
+        self.o = oracle.IcpOracle()
+        self.params = oracle.IcpParams.reference()
+        self.src = self.tgt = None
+        self.result = None
+
+    def setInputSource(self, c):
+        self.src = c
+
+    def setInputTarget(self, c):
+        self.tgt = c
+
+    def align(self, guess=None):
+        self.o.set_target(np.ascontiguousarray(self.tgt.points))
+        self.o.set_source(np.ascontiguousarray(self.src.points))
+        self.result, xyz = self.o.align(guess, self.params, want_aligned=True)
+        out = self.src.points.copy()
+        out["x"], out["y"], out["z"], out["w"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 1.0
+        return PointCloud(out, self.src.width, self.src.height, self.src.is_dense)
+
+    def hasConverged(self):
+        return bool(self.result.converged)
+
+    def getFinalTransformation(self):
+        return self.result.T
+
+
+class _OracleNdt(_OracleIcp):
+    def __init__(self, centroid_mode=1):
+        self.o = oracle.NdtOracle()
+        self.o.set_centroid_mode(centroid_mode)
+        self.params = oracle.NdtParams.reference()
+        self.src = self.tgt = None
+        self.result = None
+
+    def align(self, guess=None):
+        self.o.set_target(np.ascontiguousarray(self.tgt.points), self.params.resolution)
+        self.result, xyz = self.o.align(np.ascontiguousarray(self.src.points), guess, self.params, want_aligned=True)
+        out = self.src.points.copy()
+        out["x"], out["y"], out["z"], out["w"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 1.0
+        return PointCloud(out, self.src.width, self.src.height, self.src.is_dense)
+
+
+class _OracleVoxel:
+    def __init__(self, leaf):
+        self.leaf = leaf or (1.0, 1.0, 1.0)
+        self.cloud = None
+
+    def setInputCloud(self, c):
+        self.cloud = c
+
+    def filter(self):
+        out = oracle.approx_voxel_grid(np.ascontiguousarray(self.cloud.points), self.leaf)
+        return PointCloud(out, width=len(out), height=1, is_dense=False)
+
+
+class OracleBackend:
+    def icp(self):
+        return _OracleIcp()
+
+    def ndt(self):
+        return _OracleNdt()
+
+    def voxel(self, leaf=None):
+        return _OracleVoxel(leaf)
+
+    def transform(self, cloud, T):
+        out = oracle.transform_cloud(np.ascontiguousarray(cloud.points), T, is_dense=cloud.is_dense)
+        return PointCloud(out, cloud.width, cloud.height, cloud.is_dense)

@@ -1,0 +1,159 @@
+"""GPU: the reference's registration schemes (IncrementalICP, ICPEdgeBasedRegistration,
+NDTEdgeBasedRegistration) run (a) through the Python host mirror over the C ABI, (b) through
+the header-only C++ host layer (include/rsreg/*.hpp, compiled with g++), and (c) with the same
+scheme logic over the CPU oracle.  All three must agree: transforms to 1e-5 / 1e-4 (NDT),
+merged clouds point for point."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RADS = -0.0261799  # -1.5 deg per frame: the yaw of the synthetic "bench" preset
+
+
+@pytest.fixture(scope="module")
+def env(rs):
+    from rsreg_amd import api, lib, schemes
+    lib.build()
+    if api.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return api, schemes
+
+
+@pytest.fixture(scope="module")
+def frames(rs):
+    """Three organized 50k frames (BASELINE configs[0] shape) + a subsampled 'feature' view."""
+    return [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
+
+
+def subsample(cloud):
+    """Stand-in for the out-of-scope edge extractor: every 2nd pixel of the valid points."""
+    import rsreg_amd
+    c = cloud.crop(0, 0, cloud.width, cloud.height, step=2)
+    pts = np.ascontiguousarray(c.points[c.points["z"] != 0])
+    return rsreg_amd.PointCloud(pts, width=len(pts), height=1, is_dense=False)
+
+
+@pytest.fixture(scope="module")
+def runner():
+    out = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "scheme_runner")
+    pkg = os.path.join(ROOT, "realsense-pointcloud_amd")
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "scheme_runner.cpp"),
+           "-o", exe, "-L", pkg, "-lrsreg", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def _read_transforms(path, skip_first_line=False):
+    rows = [l.split() for l in open(path).read().strip().splitlines()]
+    head = None
+    if skip_first_line:
+        head, rows = [int(v) for v in rows[0]], rows[1:]
+    arr = np.array(rows, dtype=np.float64).reshape(-1, 4, 4)
+    return head, arr
+
+
+def _same_cloud(a, b, atol):
+    assert len(a) == len(b)
+    np.testing.assert_allclose(a.xyz, b.xyz, atol=atol)
+    np.testing.assert_array_equal(a.points["rgba"], b.points["rgba"])
+
+
+def test_incremental_icp_matches_checker(env, frames):
+    api, schemes = env
+    from oracle_backend import OracleBackend
+    a = schemes.IncrementalICP().registration([f.copy() for f in frames])
+    sa = schemes.IncrementalICP(backend=OracleBackend())
+    b = sa.registration([f.copy() for f in frames])
+    _same_cloud(a, b, 2e-5)
+    assert a.height == 1 and a.width == len(a)
+
+
+@pytest.mark.parametrize("kind", ["icp", "ndt"])
+def test_edge_schemes_match_checker(env, frames, kind):
+    api, schemes = env
+    from oracle_backend import OracleBackend
+    cls = schemes.ICPEdgeBasedRegistration if kind == "icp" else schemes.NDTEdgeBasedRegistration
+    res = []
+    for backend in (None, OracleBackend()):
+        s = cls(rads=RADS, backend=backend)
+        s.feature_fn = subsample
+        merged = s.registration([f.copy() for f in frames])
+        res.append((merged, s.frame_transforms))
+    (ma, ta), (mb, tb) = res
+    assert len(ta) == len(tb)
+    tol = 1e-5 if kind == "icp" else 1e-4   # north-star bar: 1e-4 Frobenius
+    for (ca, ra), (cb, rb) in zip(ta, tb):
+        assert np.linalg.norm(ca - cb) < tol and np.linalg.norm(ra - rb) < tol
+    _same_cloud(ma, mb, 5e-5 if kind == "icp" else 5e-4)
+    assert len(ma) >= len(frames[0])
+
+
+def test_imu_guess_variant(env, frames):
+    api, schemes = env
+    from oracle_backend import OracleBackend
+    thetas = [(0.0, 0.0, 0.0), (0.001, 0.0262, -0.0005), (0.002, 0.0524, -0.001)]
+    out = []
+    for backend in (None, OracleBackend()):
+        s = schemes.ICPEdgeBasedRegistration(thetas=thetas, backend=backend)
+        s.feature_fn = subsample
+        out.append((s.registration([f.copy() for f in frames]), s.frame_transforms, s.thetas))
+    assert len(out[0][1]) == len(out[1][1])
+    for (ca, ra), (cb, rb) in zip(out[0][1], out[1][1]):
+        assert np.linalg.norm(ca - cb) < 1e-5 and np.linalg.norm(ra - rb) < 1e-5
+    np.testing.assert_allclose(np.array(out[0][2], dtype=np.float64), np.array(thetas))  # theta_0 is zero here
+
+
+def test_cpp_host_layer_matches_python_path(env, frames, runner, tmp_path, rs):
+    api, schemes = env
+    paths = []
+    for k, f in enumerate(frames):
+        p = str(tmp_path / ("frame-%d.pcd" % k))
+        rs.save_pcd(p, f)
+        paths.append(p)
+    # pair ICP with the reference's parameters
+    pre = str(tmp_path / "icp_pair")
+    subprocess.run([runner, "icp_pair", pre, paths[0], paths[1]], check=True)
+    head, T = _read_transforms(pre + ".txt", skip_first_line=True)
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(reference=True)
+    icp.setInputSource(frames[1])
+    icp.setInputTarget(frames[0])
+    aligned = icp.align()
+    assert head == [int(icp.hasConverged()), icp.result.iterations, icp.result.state]
+    np.testing.assert_allclose(T[0], icp.getFinalTransformation(), atol=1e-7)
+    got = rs.load_pcd(pre + ".pcd")
+    np.testing.assert_array_equal(got.xyz, aligned.xyz)
+    np.testing.assert_array_equal(got.points["rgba"], aligned.points["rgba"])
+    # pair NDT
+    pre = str(tmp_path / "ndt_pair")
+    subprocess.run([runner, "ndt_pair", pre, paths[0], paths[1]], check=True)
+    head, T = _read_transforms(pre + ".txt", skip_first_line=True)
+    ndt = api.NormalDistributionsTransform()
+    ndt.params = api.ndt_params(reference=True)
+    ndt.setInputSource(frames[1])
+    ndt.setInputTarget(frames[0])
+    ndt.align(schemes.rot_y(0.01))
+    assert head == [int(ndt.hasConverged()), ndt.result.iterations]
+    np.testing.assert_allclose(T[0], ndt.getFinalTransformation(), atol=2e-6)
+    # whole schemes
+    for mode, cls in (("incremental", schemes.IncrementalICP), ("icp_edge", schemes.ICPEdgeBasedRegistration),
+                      ("ndt_edge", schemes.NDTEdgeBasedRegistration)):
+        pre = str(tmp_path / mode)
+        subprocess.run([runner, mode, pre] + paths, check=True)
+        s = cls() if mode == "incremental" else cls(rads=RADS)
+        merged = s.registration([f.copy() for f in frames])
+        got = rs.load_pcd(pre + ".pcd")
+        assert len(got) == len(merged)
+        np.testing.assert_allclose(got.xyz, merged.xyz, atol=2e-5)
+        _, T = _read_transforms(pre + ".txt")
+        ref = s.transforms if mode == "incremental" else [t for pair in s.frame_transforms for t in pair]
+        assert len(T) == len(ref)
+        for a, b in zip(T, ref):
+            np.testing.assert_allclose(a, b, atol=2e-6)

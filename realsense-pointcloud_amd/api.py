@@ -126,6 +126,7 @@ class IterativeClosestPoint:
         self._src = self._tgt = None
         self._tgt_dirty = True
         self._src_dirty = True
+        self._quiet_search = False   # run_sharded_icp: skip the per-iteration D2H of the correspondences
         self.result = None
 
     # setters the reference calls (incremental_icp.hpp:46-49)
@@ -161,19 +162,36 @@ class IterativeClosestPoint:
         self._tgt = cloud
         self._tgt_dirty = True  # PCL rebuilds the kd-tree whenever the target is set
 
+    # clouds already resident in HBM (e.g. torch tensors): (device pointer, count, stride)
+    def setInputSourceDevice(self, ptr, n, stride):
+        self._src = ("device", int(ptr), int(n), int(stride))
+        self._src_dirty = True
+
+    def setInputTargetDevice(self, ptr, n, stride):
+        self._tgt = ("device", int(ptr), int(n), int(stride))
+        self._tgt_dirty = True
+
     def _sync_inputs(self):
         L, h = _l.lib(), self.ctx.h
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
         if self._tgt_dirty:
-            keep, p, n, s = _records(self._tgt)
-            dense = int(getattr(self._tgt, "is_dense", False))
-            _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
+            if isinstance(self._tgt, tuple):
+                _, p, n, s = self._tgt
+                _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
+            else:
+                keep, p, n, s = _records(self._tgt)
+                dense = int(getattr(self._tgt, "is_dense", False))
+                _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
             self._tgt_dirty = False
         if self._src_dirty:
-            keep, p, n, s = _records(self._src)
-            dense = int(getattr(self._src, "is_dense", False))
-            _l.check(L.rsreg_icp_set_source(h, p, n, s, dense), h)
+            if isinstance(self._src, tuple):
+                _, p, n, s = self._src
+                _l.check(L.rsreg_icp_set_source_device(h, p, n, s, 0), h)
+            else:
+                keep, p, n, s = _records(self._src)
+                dense = int(getattr(self._src, "is_dense", False))
+                _l.check(L.rsreg_icp_set_source(h, p, n, s, dense), h)
             self._n_src = n
             self._src_dirty = False
 
@@ -206,7 +224,10 @@ class IterativeClosestPoint:
         _l.check(_l.lib().rsreg_icp_begin(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params)),
                  self.ctx.h)
 
-    def search(self):
+    def search(self, want_output=True):
+        if not want_output:
+            _l.check(_l.lib().rsreg_icp_search(self.ctx.h, None, None), self.ctx.h)
+            return None
         idx = np.empty(self._n_src, np.int32)
         d2 = np.empty(self._n_src, np.float32)
         _l.check(_l.lib().rsreg_icp_search(self.ctx.h, idx.ctypes.data, d2.ctypes.data), self.ctx.h)

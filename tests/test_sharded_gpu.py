@@ -1,0 +1,92 @@
+"""GPU: the N-rank path with the HIP engine.  (1) two processes share the one GPU of the box,
+each holds one source block, the 17 sums travel over torch.distributed/gloo; the result must
+equal the single-process engine's.  (2) the native RCCL transport (rsreg_comm_*) on a one-rank
+communicator: init, all-reduce inside rsreg_icp_align, destroy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import rsreg_amd
+    from rsreg_amd import api, sharded, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tgt = synth.render_frame(0, "50k", "bench")
+    src = synth.render_frame(1, "50k", "bench")
+    guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    lo, hi = sharded.shard_range(len(src), rank, world)
+
+    def allreduce(v):
+        t = torch.from_numpy(v.copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    icp = api.IterativeClosestPoint(api.Context(0))
+    icp.params = api.icp_params(max_iterations=6, criteria_mode=1, max_correspondence_distance=0.05)
+    icp.setInputSource(np.ascontiguousarray(src.points[lo:hi]))
+    icp.setInputTarget(tgt)
+    r = sharded.run_sharded_icp(icp, allreduce, guess)
+    np.save(os.path.join(out_dir, "T_rank%d.npy" % rank), api._rowmajor(r.transform))
+    np.save(os.path.join(out_dir, "meta_rank%d.npy" % rank), np.array([r.iterations, r.state, r.converged, r.n_correspondences]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_matches_single_process(tmp_path, rs):
+    import torch.multiprocessing as mp
+    from rsreg_amd import api, lib, synth
+    lib.build()
+    if api.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    tgt = synth.render_frame(0, "50k", "bench")
+    src = synth.render_frame(1, "50k", "bench")
+    guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=6, criteria_mode=1, max_correspondence_distance=0.05)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    icp.align(guess)
+    T0, T1 = np.load(tmp_path / "T_rank0.npy"), np.load(tmp_path / "T_rank1.npy")
+    np.testing.assert_array_equal(T0, T1)
+    assert np.linalg.norm(T0 - icp.getFinalTransformation()) < 1e-6
+    m0, m1 = np.load(tmp_path / "meta_rank0.npy"), np.load(tmp_path / "meta_rank1.npy")
+    np.testing.assert_array_equal(m0, m1)
+    assert tuple(m0) == (icp.result.iterations, icp.result.state, icp.result.converged, icp.result.n_correspondences)
+
+
+def test_native_rccl_transport_single_rank(rs):
+    from rsreg_amd import api, lib, synth
+    lib.build()
+    ctx = api.Context(0)
+    ctx.comm_init(api.comm_unique_id(), 0, 1)
+    v = ctx.allreduce_f64(np.arange(17, dtype=np.float64))
+    np.testing.assert_array_equal(v, np.arange(17))
+    tgt = synth.render_frame(0, "50k", "parity")
+    src = synth.render_frame(1, "50k", "parity")
+    a = api.IterativeClosestPoint(ctx)
+    a.params = api.icp_params(reference=True)
+    a.setInputSource(src)
+    a.setInputTarget(tgt)
+    a.align()
+    b = api.IterativeClosestPoint(api.Context(0))
+    b.params = api.icp_params(reference=True)
+    b.setInputSource(src)
+    b.setInputTarget(tgt)
+    b.align()
+    np.testing.assert_array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    assert lib.lib().rsreg_comm_destroy(ctx.h) == 0

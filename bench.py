@@ -175,6 +175,21 @@ def main():
     alg_bytes = (32 if a.pipeline == 1 else 24) * n_src + 16 * n_unique
     avg_ms = ms_nn / max(n_launch, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside
+    # this process, so the number comes from the committed rocprofv3 passes of this same
+    # command (profiles/*_traffic.json, collected per MI355X_MICROARCH.md's HBM section)
+    traffic = None
+    try:
+        tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+        if tj:
+            t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
+            w = t.get("workload", {})
+            kern = "k_icp_fused" if a.pipeline == 1 else "k_nn_search"
+            if (w.get("size") == a.size and w.get("iterations") == a.iterations and w.get("max_dist") == a.max_dist
+                    and w.get("pipeline") == ("fused" if a.pipeline == 1 else "staged") and world == 1 and kern in t["kernels"]):
+                traffic = t["kernels"][kern]["traffic_bytes_corrected"]
+    except Exception:  # noqa: BLE001
+        traffic = None
     out = {
         "metric": "point-pairs/sec per ICP iteration",
         "value": value,
@@ -198,7 +213,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_icp_fused" if a.pipeline == 1 else "k_nn_search",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
             "launches": n_launch,
         },
         "breakdown_ms_per_step": {

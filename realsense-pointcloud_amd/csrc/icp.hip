@@ -17,6 +17,7 @@
 
 #include "icp_kernels.hpp"
 #include "icp_tile_kernel.hpp"
+#include "icp_dense.hpp"
 
 using namespace rsreg;
 
@@ -154,6 +155,115 @@ int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, floa
     return RSREG_OK;
 }
 
+float prune2_of(double max_dist)
+{
+    // squared search radius as a float that is never below the f64 gate PCL compares with
+    const double gate2 = max_dist * max_dist;
+    if (!(gate2 < (double)FLT_MAX)) return INFINITY;
+    float f = (float)gate2;
+    if ((double)f < gate2) f = std::nextafter(f, INFINITY);
+    return f;
+}
+
+DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
+{
+    const GridParams &p = ctx->grid;
+    DenseDev g;
+    g.ox = p.origin[0]; g.oy = p.origin[1]; g.oz = p.origin[2];
+    g.inv_cell = p.inv_cell; g.cell = p.cell;
+    g.nx = p.dims[0]; g.ny = p.dims[1]; g.nz = p.dims[2];
+    g.sx = p.dims[0] + 2;
+    g.sxy = (p.dims[0] + 2) * (p.dims[1] + 2);
+    g.max_ring = p.max_ring;
+    g.prune2 = prune2_of(max_dist);
+    g.start = ctx->d_dense.as<uint32_t>();
+    g.pts = ctx->d_tgt_sorted.as<float4>();
+    g.n_pts = p.n_points;
+    g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
+    return g;
+}
+
+long long dense_cell_budget()
+{
+    static const long long v = [] {
+        if (const char *f = std::getenv("RSREG_FORCE_HASH"))
+            if (f[0] == '1') return 0ll;
+        if (const char *e = std::getenv("RSREG_DENSE_MAX_CELLS")) return std::atoll(e);
+        return 1ll << 28;   // 1 GiB of cell starts at most (out of 288 GB)
+    }();
+    return v;
+}
+
+// Dense-table index (icp_dense.hpp).  The grid geometry (ctx->grid) is already decided.
+int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, hipEvent_t ev0,
+                hipEvent_t ev1)
+{
+    hipStream_t st = ctx->stream;
+    GridParams &gp = ctx->grid;
+    gp.dense = 1;
+    const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
+    const size_t misc_bytes = 16 * sizeof(uint32_t);
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
+    k_dense_fill_sentinels<<<div_up(nfin + 4, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), nfin + 4);
+    RSREG_HIP(ctx, hipGetLastError());
+    const DenseDev g = dense_dev(ctx, max_dist);
+    auto *keys = ctx->d_keys.as<unsigned long long>();
+    auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
+    auto *vals = ctx->d_vals.as<uint32_t>();
+    auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
+    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
+    uint32_t *table = ctx->d_dense.as<uint32_t>();
+    RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4, st));
+    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 8, 0, 8 * 4, st));
+    k_dense_keys<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    int id_bits = 1;
+    while ((1ull << id_bits) <= total) ++id_bits;   // all-ones (non-finite) stays above every valid id
+    const unsigned end_bit = (unsigned)std::min(64, 16 + id_bits);
+    size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    const uint32_t nbf = div_up(nfin, kBlock);
+    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, pos, ctx->d_tgt_sorted.as<float4>(), table,
+                                            d_misc + 8);
+    RSREG_HIP(ctx, hipGetLastError());
+    // counts -> first sorted point of every cell (in place), entry [total] = number of points
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+    if (ctx->profiling) (void)hipEventRecord(ev1, st);
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    gp.n_cells = h_misc[8];
+    gp.n_points = h_misc[10];
+    gp.n_bricks = 0;
+    rsreg_grid_info &gi = ctx->grid_info;
+    for (int k = 0; k < 3; ++k) { gi.origin[k] = gp.origin[k]; gi.dims[k] = gp.dims[k]; }
+    gi.cell_size = gp.cell;
+    gi.n_unique_points = gp.n_points;
+    gi.n_cells = gp.n_cells;
+    gi.max_points_per_cell = h_misc[9];
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
+    }
+    ctx->have_target = true;
+    return RSREG_OK;
+}
+
 // Builds the grid from records already in HBM (d_pts/stride); keeps no pointer to them.
 int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, double refine = 1.0)
 {
@@ -222,6 +332,10 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         if (rings < (double)(max_dim + 1)) max_ring = std::max(1, (int)rings);
     }
     gp.max_ring = max_ring;
+    {
+        const long long padded = (long long)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
+        if (padded <= dense_cell_budget()) return build_dense(ctx, d_pts, n, stride, max_dist, nfin, ev0, ev1);
+    }
 
     // ---- sort by (brick, cell in brick, xyz hash)
     RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
@@ -325,6 +439,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_seed.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_perm.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
@@ -395,6 +510,21 @@ bool criteria_has_converged(IcpState &s)
     return false;
 }
 
+int *seed_ptr(rsreg_ctx *ctx)
+{
+    static const bool off = std::getenv("RSREG_NO_SEED") && std::getenv("RSREG_NO_SEED")[0] == '1';
+    return off ? nullptr : ctx->d_seed.as<int>();
+}
+
+// diagnostic: per-wave start/end stamps of the last fused launch, dumped at rsreg_icp_end
+unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
+{
+    static const bool on = std::getenv("RSREG_WAVE_TIMES") != nullptr;
+    if (!on) return nullptr;
+    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 16) != hipSuccess) return nullptr;
+    return ctx->d_brick.as<unsigned long long>();
+}
+
 bool use_tile_kernel()
 {
     // The LDS-staged tile kernel is exact but, with fixed 128-point tiles, not yet faster than
@@ -421,13 +551,18 @@ int launch_search(rsreg_ctx *ctx)
     if (n) {
         ScopedEvents ev(ctx, &ctx->ev_nn);
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
-        if (use_tile_kernel())
+        if (ctx->grid.dense)
+            k_nn_search_dense<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n,
+                                                                             dense_dev(ctx, s.prm.max_correspondence_distance), gate2,
+                                                                             ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
+                                                                             seed_ptr(ctx));
+        else if (use_tile_kernel())
             k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(Mat4f::identity()), 0, g,
                                                                       gate2, ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
-                                                                      1, nullptr, 0, tile_stats(ctx));
+                                                                      1, nullptr, 0, tile_stats(ctx), seed_ptr(ctx));
         else
             k_nn_search<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, g, gate2,
-                                                                       ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>());
+                                                                       ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), seed_ptr(ctx));
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
     }
@@ -474,15 +609,21 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
-        if (use_tile_kernel())
+        if (ctx->grid.dense)
+            k_icp_fused_dense<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
+                ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
+                dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
+                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wave_times_ptr(ctx, n));
+        else if (use_tile_kernel())
             k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
                                                                      s.pending_transform ? 1 : 0, g, gate2, ctx->d_corr_pos.as<int>(),
                                                                      ctx->d_corr_d2.as<float>(), want_corr ? 1 : 0,
-                                                                     ctx->d_partials.as<double>(), 1, tile_stats(ctx));
+                                                                     ctx->d_partials.as<double>(), 1, tile_stats(ctx), seed_ptr(ctx));
         else
             k_icp_fused<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, g, gate2,
-                want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>());
+                want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(),
+                seed_ptr(ctx));
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
     }
@@ -602,8 +743,8 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rsreg_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
-                      &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
@@ -723,6 +864,7 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     ctx->ev_reduce.clear();
     ctx->ev_transform.clear();
     const uint32_t n = (uint32_t)ctx->n_source;
+    if (n) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_seed.ptr, 0xff, (size_t)n * 4, ctx->stream));  // no seeds yet
     if (n) {
         const int apply = s.final_t.is_identity() ? 0 : 1;
         k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t),
@@ -799,6 +941,17 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
+        if (ctx->grid.dense && n) {
+            const size_t nw = (n + 63) / 64;
+            std::vector<unsigned long long> h(2 * nw);
+            (void)hipMemcpy(h.data(), ctx->d_brick.ptr, h.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = std::fopen(wt_path, "wb")) {
+                std::fwrite(h.data(), 8, h.size(), f);
+                std::fclose(f);
+            }
+        }
+    }
     if (uint32_t *st = tile_stats(ctx)) {
         uint32_t h[9] = {0};
         (void)hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);

@@ -579,19 +579,28 @@ __device__ __forceinline__ void nn_far_global(const GridDev &g, const QueryGeom 
 // close as the current best (or the gate) is visited; cells and bricks are skipped only on a
 // conservative geometric lower bound, so the result equals a brute-force scan including the
 // lowest-index tie-break.
-__device__ __forceinline__ Best nn_query(const GridDev &g, float qx, float qy, float qz)
+//
+// seed_pos: a target point known from the previous iteration (or -1).  Its distance is a valid
+// upper bound on the nearest distance, so the search starts with a tight limit and usually
+// ends inside the query's own cell; exactness is unaffected (the seed is just a candidate).
+__device__ __forceinline__ Best nn_query(const GridDev &g, float qx, float qy, float qz, int seed_pos = -1)
 {
     Best b{~0ull, -1, FLT_MAX};
     if (g.dx <= 0) return b;
     const QueryGeom qg = query_geom(g, qx, qy, qz);
     float limit2 = g.prune2;  // nothing farther than this can be accepted or improve the best
+    if (seed_pos >= 0) {
+        const float4 t = g.pts[seed_pos];
+        consider(b, l2_simple(qx, qy, qz, t.x, t.y, t.z), __float_as_uint(t.w), (uint32_t)seed_pos);
+        limit2 = fminf(limit2, b.d2);
+    }
     nn_near_global(g, qg, qx, qy, qz, b, limit2);
     nn_far_global(g, qg, qx, qy, qz, b, limit2);
     return b;
 }
 
 __global__ __launch_bounds__(kBlock) void k_nn_search(const float4 *cur, uint32_t n, GridDev g, double gate2,
-                                                      int *corr_pos, float *corr_d2)
+                                                      int *corr_pos, float *corr_d2, int *seed)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -599,7 +608,8 @@ __global__ __launch_bounds__(kBlock) void k_nn_search(const float4 *cur, uint32_
     int pos = -1;
     float d2 = 0.0f;
     if (q.w != 0.0f) {
-        const Best b = nn_query(g, q.x, q.y, q.z);
+        const Best b = nn_query(g, q.x, q.y, q.z, seed ? seed[i] : -1);
+        if (seed) seed[i] = b.pos;
         if (b.pos >= 0 && !((double)b.d2 > gate2)) {  // PCL: if (distance > max_dist_sqr) continue;
             pos = b.pos;
             d2 = b.d2;
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials,
 // apply the previous increment, search, gate, accumulate.  Writes the transformed source back
 // (next iteration starts from it, like PCL's in-place transformCloud).
 __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g,
-                                                     double gate2, int *corr_pos, float *corr_d2, double *partials)
+                                                     double gate2, int *corr_pos, float *corr_d2, double *partials, int *seed)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int pos = -1;
@@ -704,7 +714,8 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
                 q = make_float4(t.x, t.y, t.z, 1.0f);
                 cur[i] = q;
             }
-            const Best b = nn_query(g, q.x, q.y, q.z);
+            const Best b = nn_query(g, q.x, q.y, q.z, seed ? seed[i] : -1);
+            if (seed) seed[i] = b.pos;
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
                 d2 = b.d2;

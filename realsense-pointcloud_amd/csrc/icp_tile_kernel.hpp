@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 // correspondences; accumulate: reduce the 17 sums of the accepted pairs into partials.
 __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g, double gate2,
                                                     int *corr_pos, float *corr_d2, int write_corr, double *partials,
-                                                    int accumulate, uint32_t *stats)
+                                                    int accumulate, uint32_t *stats, int *seed)
 {
     __shared__ TileShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -292,6 +292,12 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
     if (valid) {
         float limit2 = g.prune2;
         int inner = 1;
+        const int seed_pos = seed ? seed[i] : -1;
+        if (seed_pos >= 0) {
+            const float4 t = g.pts[seed_pos];
+            consider(b, l2_simple(q.x, q.y, q.z, t.x, t.y, t.z), __float_as_uint(t.w), (uint32_t)seed_pos);
+            limit2 = fminf(limit2, b.d2);
+        }
         if (staged && !(g.dbg & 4)) {
             const float cell2 = g.cell * g.cell;
             // ring 0 (own cell: it usually holds the nearest point), then rings 1..H, stopping
@@ -331,6 +337,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
             nn_near_global(g, qg, q.x, q.y, q.z, b, limit2);
         }
         if (!(g.dbg & 1)) nn_far_global(g, qg, q.x, q.y, q.z, b, limit2, inner);
+        if (seed) seed[i] = b.pos;
     }
 
     // ---- I. gate, outputs, sums

@@ -72,6 +72,7 @@ struct GridParams {
     uint32_t n_cells;      // occupied cells
     uint32_t n_bricks;     // occupied 4x4x4-cell bricks
     int max_ring;          // rings (cells) needed to cover the correspondence gate
+    int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos)
 };
 
 struct BrickEntry {          // 32 B, one hash-table slot
@@ -112,6 +113,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_tgt_sorted;   // float4 {x,y,z,bits(orig index)}, cell-sorted, de-duplicated
     rsreg::DevBuf d_table;        // BrickEntry[table_mask+1]
     rsreg::DevBuf d_cellpos;      // uint32[n_cells+1]: first sorted point of each occupied cell
+    rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     size_t n_target_raw = 0;
@@ -125,6 +127,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_cur;          // float4 current (transformed) source
     rsreg::DevBuf d_corr_pos;     // int32: position in d_tgt_sorted, -1 = none
     rsreg::DevBuf d_corr_d2;      // float
+    rsreg::DevBuf d_seed;         // int32: nearest target found in the previous iteration (-1 none)
     rsreg::DevBuf d_partials;     // double[blocks][17]
     rsreg::DevBuf d_sums;         // double[17]
     rsreg::PinnedBuf h_sums;      // pinned double[64]

@@ -1,0 +1,57 @@
+"""CPU: BASELINE configs[0] — `--registration test 3` on three ~50k-point .pcd files through the
+CPU path (plumbing, no GPU): dataset/test-{0,1,2}.pcd -> NDTEdgeBasedRegistration ->
+dataset/test-registration (reference src/main.cpp:76-87,204-211).  The scheme logic is the
+product's (realsense-pointcloud_amd/schemes.py); the numeric building blocks here are the CPU
+oracle's, plugged in as a backend; the edge extractor (out of scope) is a subsample stand-in."""
+import numpy as np
+
+
+def test_registration_test_3_plumbing(tmp_path, orc, rs):
+    from oracle_backend import OracleBackend
+    from rsreg_amd import schemes
+    dataset = tmp_path / "dataset"
+    dataset.mkdir()
+    for k in range(3):
+        rs.save_pcd(str(dataset / ("test-%d.pcd" % k)), rs.synth.render_frame(k, "50k", "bench"))
+    clouds = [rs.load_pcd(str(dataset / ("test-%d.pcd" % k))) for k in range(3)]
+    assert all(len(c) == 50000 and c.height == 200 and c.width == 250 for c in clouds)
+
+    def features(cloud):
+        c = cloud.crop(0, 0, cloud.width, cloud.height, step=2)
+        pts = np.ascontiguousarray(c.points[c.points["z"] != 0])
+        return rs.PointCloud(pts, width=len(pts), height=1, is_dense=False)
+
+    scheme = schemes.NDTEdgeBasedRegistration(rads=-0.0261799, backend=OracleBackend())
+    scheme.feature_fn = features
+    merged = scheme.registration(clouds)
+    assert len(scheme.frame_transforms) == 2          # both frames converged and were merged
+    assert len(merged) == 150000 and merged.height == 1
+    out = str(dataset / "test-registration")
+    rs.save_pcd(out, merged)
+    back = rs.load_pcd(out)
+    np.testing.assert_array_equal(back.xyz, merged.xyz)
+    np.testing.assert_array_equal(back.points["rgba"], merged.points["rgba"])
+    # frame 1 moved towards frame 0's coordinates
+    gt = rs.synth.ground_truth(1, 0, "bench")
+    t_coarse, t_icp = scheme.frame_transforms[0]
+    assert np.linalg.norm(t_icp @ t_coarse - gt) < np.linalg.norm(np.eye(4) - gt)
+
+
+def test_pcd_fixture_formats(tmp_path, rs):
+    """ASCII PCDs with the colour as F and as U (the two layouts of the reference's example files)."""
+    pts = np.zeros(3, rs.POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"], pts["w"] = [0.93773, 0.90805, 0.81915], [0.33763, 0.35641, 0.32], 0.0, 1.0
+    pts["rgba"] = [4281353262, 4281353262, 255]
+    c = rs.PointCloud(pts, width=3, height=1)
+    p_bin, p_asc = str(tmp_path / "b.pcd"), str(tmp_path / "a.pcd")
+    rs.save_pcd(p_bin, c, binary=True)
+    rs.save_pcd(p_asc, c, binary=False)
+    for p in (p_bin, p_asc):
+        back = rs.load_pcd(p)
+        np.testing.assert_array_equal(back.points["rgba"], pts["rgba"])
+        np.testing.assert_allclose(back.xyz, c.xyz, rtol=1e-7)
+    u = str(tmp_path / "u.pcd")
+    open(u, "w").write("VERSION .7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\n"
+                       "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA ascii\n0.93773 0.33333 0 4281353262\n0.90805 0.32222 0 4281353262\n")
+    back = rs.load_pcd(u)
+    assert len(back) == 2 and (back.points["rgba"] == 4281353262).all() and abs(back.points["x"][1] - 0.90805) < 1e-7

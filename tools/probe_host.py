@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Dev probe: wall time of each host-side call of one pair registration (1M, reference params)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rsreg_amd  # noqa: E402
+from rsreg_amd import api, lib, synth  # noqa: E402
+
+size = sys.argv[1] if len(sys.argv) > 1 else "N1M"
+tgt, src = synth.render_frame(0, size, "parity"), synth.render_frame(1, size, "parity")
+ctx = api.Context(0)
+L = lib.lib()
+prm = api.icp_params(reference=True)
+res = lib.IcpResult()
+out = src.points.copy()
+n, stride = len(src), src.points.dtype.itemsize
+
+
+def t(fn, reps=5):
+    fn()
+    a = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - a) / reps * 1e3
+
+
+print("set_target(host)   %.3f ms" % t(lambda: lib.check(L.rsreg_icp_set_target(ctx.h, tgt.points.ctypes.data, n, stride, 0, 0.01), ctx.h)))
+print("set_source(host)   %.3f ms" % t(lambda: lib.check(L.rsreg_icp_set_source(ctx.h, src.points.ctypes.data, n, stride, 0), ctx.h)))
+print("align (no output)  %.3f ms" % t(lambda: lib.check(L.rsreg_icp_align(ctx.h, None, C.byref(prm), C.byref(res), None, 0), ctx.h)))
+print("align (+aligned)   %.3f ms" % t(lambda: lib.check(L.rsreg_icp_align(ctx.h, None, C.byref(prm), C.byref(res), out.ctypes.data, stride), ctx.h)))
+T = np.ascontiguousarray(np.eye(4, dtype=np.float32))
+print("transform_cloud    %.3f ms" % t(lambda: lib.check(L.rsreg_transform_cloud(ctx.h, src.points.ctypes.data, out.ctypes.data, n, stride, 0, T.ctypes.data), ctx.h)))
+print("numpy copy 32MB    %.3f ms" % t(lambda: src.points.copy()))

@@ -114,7 +114,7 @@ double cell_cap_from_env()
         double v = std::atof(e);
         if (v > 0) return v;
     }
-    return 0.0125;  // metres; ~2-4 D435i pixel pitches at 1-2 m
+    return 0.014;  // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
 int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
@@ -145,7 +145,12 @@ int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, floa
     RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, misc_bytes, hipMemcpyHostToDevice, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));  // h_misc is reused as the read-back buffer
     if (n > 0) {
-        k_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, d_misc);
+        const uint32_t nb = std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024);
+        RSREG_HIP(ctx, ctx->d_comm.reserve(1024 * 8 * sizeof(uint32_t) + 64 * sizeof(double)));
+        uint32_t *partial = reinterpret_cast<uint32_t *>(ctx->d_comm.as<char>() + 64 * sizeof(double));
+        k_bbox<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, partial);
+        RSREG_HIP(ctx, hipGetLastError());
+        k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, d_misc);
         RSREG_HIP(ctx, hipGetLastError());
     }
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
@@ -209,8 +214,10 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
-    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
-    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_brick.reserve(((size_t)nfin + 2) * 4));
     RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4));
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
     k_dense_fill_sentinels<<<div_up(nfin + 4, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), nfin + 4);
@@ -220,7 +227,9 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
-    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
+    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n;
+    uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n;
+    uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
     uint32_t *table = ctx->d_dense.as<uint32_t>();
     RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4, st));
     RSREG_HIP(ctx, hipMemsetAsync(d_misc + 8, 0, 8 * 4, st));
@@ -236,11 +245,14 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     const uint32_t nbf = div_up(nfin, kBlock);
-    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep);
+    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, pos, ctx->d_tgt_sorted.as<float4>(), table,
-                                            d_misc + 8);
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, pos, cid, ctx->d_tgt_sorted.as<float4>(),
+                                            cellslot, cellpos, d_misc + 8);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
     RSREG_HIP(ctx, hipGetLastError());
     // counts -> first sorted point of every cell (in place), entry [total] = number of points
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
@@ -255,7 +267,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     gi.cell_size = gp.cell;
     gi.n_unique_points = gp.n_points;
     gi.n_cells = gp.n_cells;
-    gi.max_points_per_cell = h_misc[9];
+    gi.max_points_per_cell = 0;   // dense mode: computed on demand by rsreg_icp_grid_info
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -328,7 +340,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     const int max_dim = std::max(gp.dims[0], std::max(gp.dims[1], gp.dims[2]));
     int max_ring = max_dim + 1;
     if (std::isfinite(max_dist) && max_dist >= 0) {
-        const double rings = std::ceil(max_dist / (double)gp.cell + 2.0 * kCellMargin);
+        const double rings = std::ceil(max_dist / (double)gp.cell + kCellMargin);   // smallest R with (R - margin) * cell >= gate
         if (rings < (double)(max_dim + 1)) max_ring = std::max(1, (int)rings);
     }
     gp.max_ring = max_ring;
@@ -428,23 +440,28 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     return RSREG_OK;
 }
 
-// Loads the source and orders it spatially (brick-major cell order in its own grid): lanes
-// of a wave then query neighbouring cells, which is what makes the search cache-friendly.
-// d_perm maps the sorted position back to the caller's index.
+// Loads the source: orders it spatially (Morton order of a few-mm grid, so the lanes of a wave
+// query neighbouring cells) and merges exact copies of a point into one weighted point (the
+// RealSense (0,0,0) pixels are ~11 % of a frame: they are searched once, not 10^5 times).
+// d_perm: sorted position -> caller's index; d_uniq_of: sorted position -> distinct point.
 int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
 {
     if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
     hipStream_t st = ctx->stream;
+    RSREG_HIP(ctx, ctx->d_src_all.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_seed.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_perm.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
     RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     ctx->n_source = n;
+    ctx->n_work = 0;
     ctx->have_source = false;
     ctx->icp.active = 0;
     if (n) {
@@ -460,18 +477,37 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
         RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
         RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
+        RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
+        RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
         auto *keys = ctx->d_keys.as<unsigned long long>();
         auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
         auto *vals = ctx->d_vals.as<uint32_t>();
         uint32_t *perm = ctx->d_perm.as<uint32_t>();
+        uint32_t *keep = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
+        uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+        uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
         const uint32_t nb = div_up((uint32_t)n, kBlock);
         k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, keys, vals);
         RSREG_HIP(ctx, hipGetLastError());
-        size_t tmp_bytes = 0;
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, perm, n, 0, 64, st));
-        RSREG_HIP(ctx, ctx->d_tmp.reserve(tmp_bytes + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, tmp_bytes, keys, keys2, vals, perm, n, 0, 64, st));
-        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
+        size_t sort_bytes = 0, scan_bytes = 0;
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr);
+        RSREG_HIP(ctx, hipGetLastError());
+        k_source_flag<<<nb, kBlock, 0, st>>>(keys2, ctx->d_src_all.as<float4>(), (uint32_t)n, keep);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+        k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
+                                               ctx->d_uniq_of.as<uint32_t>(), d_misc + 12);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc + 12, 4, hipMemcpyDeviceToHost, st));
+        RSREG_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t nu = h_misc[0];
+        ctx->n_work = nu;
+        k_source_weights<<<div_up(nu, kBlock), kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), ctx->d_first.as<uint32_t>(), nu,
+                                                                ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
     }
     ctx->have_source = true;
@@ -546,7 +582,7 @@ uint32_t *tile_stats(rsreg_ctx *ctx)
 int launch_search(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
-    const uint32_t n = (uint32_t)ctx->n_source;
+    const uint32_t n = (uint32_t)ctx->n_work;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     if (n) {
         ScopedEvents ev(ctx, &ctx->ev_nn);
@@ -587,7 +623,7 @@ int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 
 int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
-    const uint32_t n = (uint32_t)ctx->n_source;
+    const uint32_t n = (uint32_t)ctx->n_work;
     {
         ScopedEvents ev(ctx, &ctx->ev_reduce);
         k_cov_reduce<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
@@ -604,7 +640,7 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
 int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
 {
     IcpState &s = ctx->icp;
-    const uint32_t n = (uint32_t)ctx->n_source;
+    const uint32_t n = (uint32_t)ctx->n_work;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
@@ -641,7 +677,7 @@ int apply_pending_transform(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
     if (!s.pending_transform) return RSREG_OK;
-    const uint32_t n = (uint32_t)ctx->n_source;
+    const uint32_t n = (uint32_t)ctx->n_work;
     if (n) {
         ScopedEvents ev(ctx, &ctx->ev_transform);
         k_transform<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc));
@@ -744,7 +780,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     rsreg_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
-                      &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
+                      &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
@@ -863,7 +899,7 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     ctx->ev_nn.clear();
     ctx->ev_reduce.clear();
     ctx->ev_transform.clear();
-    const uint32_t n = (uint32_t)ctx->n_source;
+    const uint32_t n = (uint32_t)ctx->n_work;
     if (n) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_seed.ptr, 0xff, (size_t)n * 4, ctx->stream));  // no seeds yet
     if (n) {
         const int apply = s.final_t.is_identity() ? 0 : 1;
@@ -889,7 +925,7 @@ int rsreg_icp_search(rsreg_ctx *ctx, int32_t *index_out, float *sqr_dist_out)
         float *d_d2 = reinterpret_cast<float *>(d_idx + n);
         k_export_corr<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
             ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), ctx->d_perm.as<uint32_t>(),
-            (uint32_t)n, d_idx, d_d2);
+            ctx->d_uniq_of.as<uint32_t>(), (uint32_t)n, d_idx, d_d2);
         RSREG_HIP(ctx, hipGetLastError());
         if (index_out) RSREG_HIP(ctx, hipMemcpyAsync(index_out, d_idx, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (sqr_dist_out) RSREG_HIP(ctx, hipMemcpyAsync(sqr_dist_out, d_d2, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -935,15 +971,15 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         if (out_stride < 12) return RSREG_ERR_INVALID_ARG;
         RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
         RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
-        k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), (uint32_t)n, to_mat34(s.final_t),
+        k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, to_mat34(s.final_t),
                                                                                 ctx->d_perm.as<uint32_t>(), ctx->d_tmp.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
-        if (ctx->grid.dense && n) {
-            const size_t nw = (n + 63) / 64;
+        if (ctx->grid.dense && ctx->n_work) {
+            const size_t nw = (ctx->n_work + 63) / 64;
             std::vector<unsigned long long> h(2 * nw);
             (void)hipMemcpy(h.data(), ctx->d_brick.ptr, h.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = std::fopen(wt_path, "wb")) {
@@ -1016,6 +1052,18 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
 {
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
+    static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
+    if (want_max && ctx->grid.dense && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
+        const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);
+        uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;
+        uint32_t h = 0;
+        RSREG_HIP(ctx, hipMemsetAsync(d, 0, 4, ctx->stream));
+        k_dense_max_count<<<2048, kBlock, 0, ctx->stream>>>(ctx->d_dense.as<uint32_t>(), total, d);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->grid_info.max_points_per_cell = h;
+    }
     *info = ctx->grid_info;
     return RSREG_OK;
 }

@@ -57,19 +57,25 @@ __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t s
     vals[i] = i;
 }
 
-// keep[i]: not a value-equal duplicate of its predecessor in the same (cell, hash) run
+// keep[i]: not a value-equal duplicate of its predecessor in the same (cell, hash) run;
+// cstart[i]: first point of a cell (always kept)
 __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long *keys, const uint32_t *vals, const char *pts,
-                                                       size_t stride, uint32_t nfin, uint32_t *keep)
+                                                       size_t stride, uint32_t nfin, uint32_t *keep, uint32_t *cstart)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
-    uint32_t kp = 1;
-    if (i > 0 && keys[i] == keys[i - 1]) {
-        const float *a = rec_xyz(pts, stride, vals[i]);
-        const float *b = rec_xyz(pts, stride, vals[i - 1]);
-        if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) kp = 0;
+    uint32_t kp = 1, cs = 1;
+    if (i > 0) {
+        const unsigned long long k = keys[i], kprev = keys[i - 1];
+        cs = (k >> 16) != (kprev >> 16);
+        if (k == kprev) {
+            const float *a = rec_xyz(pts, stride, vals[i]);
+            const float *b = rec_xyz(pts, stride, vals[i - 1]);
+            if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) kp = 0;
+        }
     }
     keep[i] = kp;
+    cstart[i] = cs;
 }
 
 // far-away sentinels behind the last sorted point: a 4-wide candidate read may run past it
@@ -79,11 +85,13 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill_sentinels(float4 *sorted,
     if (i < n) sorted[i] = make_float4(1e30f, 1e30f, 1e30f, __uint_as_float(0xffffffffu));
 }
 
-// histogram of the kept points per cell + the sorted point array; stats[0] occupied cells,
-// stats[1] max points per cell
+// the sorted point array, and for every occupied cell (in sorted order) its table slot and the
+// position of its first point; pos / cid = exclusive scans of keep / cstart.
+// stats[0] = occupied cells, stats[2] = kept points
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long long *keys, const uint32_t *vals, const char *pts,
                                                           size_t stride, uint32_t nfin, const uint32_t *keep,
-                                                          const uint32_t *pos, float4 *sorted, uint32_t *table,
+                                                          const uint32_t *cstart, const uint32_t *pos, const uint32_t *cid,
+                                                          float4 *sorted, uint32_t *cellslot, uint32_t *cellpos,
                                                           uint32_t *stats)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,11 +100,37 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         const uint32_t v = vals[i];
         const float *p = rec_xyz(pts, stride, v);
         sorted[pos[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(v));
-        const uint32_t old = atomicAdd(&table[(uint32_t)(keys[i] >> 16)], 1u);
-        if (old == 0) atomicAdd(&stats[0], 1u);
-        atomicMax(&stats[1], old + 1);
     }
-    if (i == nfin - 1) stats[2] = pos[i] + keep[i];
+    if (cstart[i]) {
+        cellslot[cid[i]] = (uint32_t)(keys[i] >> 16);
+        cellpos[cid[i]] = pos[i];
+    }
+    if (i == nfin - 1) {
+        const uint32_t nu = pos[i] + keep[i], nc = cid[i] + cstart[i];
+        stats[0] = nc;
+        stats[2] = nu;
+        cellpos[nc] = nu;   // sentinel
+    }
+}
+
+// table[slot of occupied cell c] = its point count (the exclusive scan of the table then gives
+// the first point of EVERY cell, empty ones included); plain stores, no atomics
+__global__ __launch_bounds__(kBlock) void k_dense_counts(const uint32_t *cellslot, const uint32_t *cellpos, const uint32_t *stats,
+                                                         uint32_t *table)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= stats[0]) return;
+    table[cellslot[c]] = cellpos[c + 1] - cellpos[c];
+}
+
+// largest cell population, from the finished table (introspection only: rsreg_icp_grid_info)
+__global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *table, size_t total, uint32_t *out)
+{
+    uint32_t v = 0;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x)
+        v = max(v, table[c + 1] - table[c]);
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -143,123 +177,178 @@ __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts
 
 __device__ __forceinline__ float key_d2(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
 
-// Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
-__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos)
-{
-    Best out{~0ull, -1, FLT_MAX};
-    if (g.nx <= 0) return out;
-    // 32-bit offsets into the two arrays (wave-uniform descriptors, one VALU per address)
-    const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(g.pts), 0, (g.n_pts + 4) * 16, 0x00020000);
-    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(g.start), 0, g.table_bytes, 0x00020000);
+struct DQuery {      // a query and where it sits in the grid
+    float qx, qy, qz;
+    float ux, uy, uz;
+    int cx, cy, cz;
+};
 
-    const float ux = cell_pos(qx, g.ox, g.inv_cell), uy = cell_pos(qy, g.oy, g.inv_cell), uz = cell_pos(qz, g.oz, g.inv_cell);
-    const int cx = min(max((int)fminf(fmaxf(floorf(ux), -4.0f), 70000.0f), 0), g.nx - 1);
-    const int cy = min(max((int)fminf(fmaxf(floorf(uy), -4.0f), 70000.0f), 0), g.ny - 1);
-    const int cz = min(max((int)fminf(fmaxf(floorf(uz), -4.0f), 70000.0f), 0), g.nz - 1);
-    const float cell2 = g.cell * g.cell;
-    float limit2 = g.prune2;
-    DBest b{0x7f800000ull << 32, 0xffffffffu};
+struct DRes {        // the two arrays behind 32-bit offsets (wave-uniform descriptors)
+    __amdgpu_buffer_rsrc_t pts, tab;
+};
+
+__device__ __forceinline__ DRes dense_res(const DenseDev &g)
+{
+    DRes r;
+    r.pts = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(g.pts), 0, (g.n_pts + 4) * 16, 0x00020000);
+    r.tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(g.start), 0, g.table_bytes, 0x00020000);
+    return r;
+}
+
+__device__ __forceinline__ DQuery dense_query(const DenseDev &g, float qx, float qy, float qz)
+{
+    DQuery q;
+    q.qx = qx; q.qy = qy; q.qz = qz;
+    q.ux = cell_pos(qx, g.ox, g.inv_cell);
+    q.uy = cell_pos(qy, g.oy, g.inv_cell);
+    q.uz = cell_pos(qz, g.oz, g.inv_cell);
+    q.cx = min(max((int)fminf(fmaxf(floorf(q.ux), -4.0f), 70000.0f), 0), g.nx - 1);
+    q.cy = min(max((int)fminf(fmaxf(floorf(q.uy), -4.0f), 70000.0f), 0), g.ny - 1);
+    q.cz = min(max((int)fminf(fmaxf(floorf(q.uz), -4.0f), 70000.0f), 0), g.nz - 1);
+    return q;
+}
+
+__device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int seed_pos, DBest &b, float &limit2)
+{
     if (seed_pos >= 0) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(pts, (uint32_t)seed_pos * 16u, 0, 0);
-        dconsider(b, qx, qy, qz, t, (uint32_t)seed_pos * 16u);
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs.pts, (uint32_t)seed_pos * 16u, 0, 0);
+        dconsider(b, q.qx, q.qy, q.qz, t, (uint32_t)seed_pos * 16u);
         limit2 = fminf(limit2, key_d2(b.key));
     }
-    const int base = (int)dense_cell_id(g, cx, cy, cz);
+}
 
+// rings 0 and 1
+__device__ __forceinline__ void dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2)
+{
+    const float qx = q.qx, qy = q.qy, qz = q.qz;
+    const float cell2 = g.cell * g.cell;
+    const int base = (int)dense_cell_id(g, q.cx, q.cy, q.cz);
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
     {
-        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(tab, (uint32_t)base * 4u, 0, 0);
-        dscan_range(b, pts, se.x * 16u, se.y * 16u, qx, qy, qz);
+        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
+        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qx, qy, qz);
         limit2 = fminf(limit2, key_d2(b.key));
     }
-
     // ---- ring 1: only the cells whose box can still hold something closer.  A neighbour at
     // offset (dx,dy,dz) needs every non-zero axis offset's face to be within the limit, so when
     // no face passes (the common case) the whole ring is skipped with six compares.
-    const float lim_c = limit2 / cell2;   // limit in squared cell units (conservative enough: the gaps carry the margin)
-    float gx0 = axis_gap(ux, cx - 1, cx - 1), gx2 = axis_gap(ux, cx + 1, cx + 1);
-    float gy0 = axis_gap(uy, cy - 1, cy - 1), gy2 = axis_gap(uy, cy + 1, cy + 1);
-    float gz0 = axis_gap(uz, cz - 1, cz - 1), gz2 = axis_gap(uz, cz + 1, cz + 1);
+    const float lim_c = limit2 / cell2;   // limit in squared cell units (the gaps carry the safety margin)
+    float gx0 = axis_gap(q.ux, q.cx - 1, q.cx - 1), gx2 = axis_gap(q.ux, q.cx + 1, q.cx + 1);
+    float gy0 = axis_gap(q.uy, q.cy - 1, q.cy - 1), gy2 = axis_gap(q.uy, q.cy + 1, q.cy + 1);
+    float gz0 = axis_gap(q.uz, q.cz - 1, q.cz - 1), gz2 = axis_gap(q.uz, q.cz + 1, q.cz + 1);
     gx0 *= gx0; gx2 *= gx2; gy0 *= gy0; gy2 *= gy2; gz0 *= gz0; gz2 *= gz2;
-    const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis (clamped queries: still a valid lower bound)
+    const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis: 0 is always a valid lower bound
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
-    if (any_face) {
-        uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
+    if (!any_face) return;
+    uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
 #pragma unroll
-        for (int j = 0; j < 27; ++j) {
-            if (j == 13) continue;
-            const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
-            const float lb = (dx == 0 ? gx0 : (dx == 1 ? gx1 : gx2)) + (dy == 0 ? gy0 : (dy == 1 ? gy1 : gy2)) +
-                             (dz == 0 ? gz0 : (dz == 1 ? gz1 : gz2));
-            mask |= (lb <= lim_c) ? (1u << j) : 0u;
+    for (int j = 0; j < 27; ++j) {
+        if (j == 13) continue;
+        const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
+        const float lb = (dx == 0 ? gx0 : (dx == 1 ? gx1 : gx2)) + (dy == 0 ? gy0 : (dy == 1 ? gy1 : gy2)) +
+                         (dz == 0 ? gz0 : (dz == 1 ? gz1 : gz2));
+        mask |= (lb <= lim_c) ? (1u << j) : 0u;
+    }
+    uint32_t po = 0, pe = 0;
+    for (;;) {   // flat: each iteration takes the next plausible cell and/or scores 4 candidates
+        if (po >= pe) {
+            if (!mask) break;
+            const int j = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const int dz = j / 9, dy = (j - dz * 9) / 3, dx = j - dz * 9 - dy * 3;
+            const float lb2 = (sel3(gx0, gx1, gx2, dx) + sel3(gy0, gy1, gy2, dy) + sel3(gz0, gz1, gz2, dz)) * cell2;
+            if (lb2 <= limit2) {   // the limit may have tightened since the mask was built
+                const int idx = base + (dz - 1) * g.sxy + (dy - 1) * g.sx + (dx - 1);
+                const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)idx * 4u, 0, 0);
+                po = se.x * 16u;
+                pe = se.y * 16u;
+            }
         }
-        uint32_t po = 0, pe = 0;
-        for (;;) {   // flat: each iteration takes the next plausible cell and/or scores 4 candidates
-            if (po >= pe) {
-                if (!mask) break;
-                const int j = __ffs((int)mask) - 1;
-                mask &= mask - 1;
-                const int dz = j / 9, dy = (j - dz * 9) / 3, dx = j - dz * 9 - dy * 3;
-                const float lb2 = (sel3(gx0, gx1, gx2, dx) + sel3(gy0, gy1, gy2, dy) + sel3(gz0, gz1, gz2, dz)) * cell2;
-                if (lb2 <= limit2) {   // the limit may have tightened since the mask was built
-                    const int idx = base + (dz - 1) * g.sxy + (dy - 1) * g.sx + (dx - 1);
-                    const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(tab, (uint32_t)idx * 4u, 0, 0);
-                    po = se.x * 16u;
-                    pe = se.y * 16u;
-                }
-            }
-            if (po < pe) {
-                dscan4(b, pts, po, qx, qy, qz);
-                po += 64;
-                limit2 = fminf(limit2, key_d2(b.key));
-            }
+        if (po < pe) {
+            dscan4(b, rs.pts, po, qx, qy, qz);
+            po += 64;
+            limit2 = fminf(limit2, key_d2(b.key));
         }
     }
+}
 
-    // ---- farther rings: row by row (a row's cells cx-r..cx+r are one contiguous run), nearest
-    // ring first, until everything unvisited is provably farther than the best
+// does this query still need rings >= 2 after rings 0-1 ?
+__device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
+{
+    const float reach = (1.0f - kCellMargin) * g.cell;   // ring 1 proves everything up to here
+    return g.max_ring >= 2 && limit2 > reach * reach;
+}
+
+// Rings >= 2: row by row (the cells of one (y, z) row are one contiguous run of points), nearest
+// ring first, until everything unvisited is provably farther than the best.  Inside a row only
+// the x-extent the remaining budget allows is read.
+__device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2)
+{
+    const float qx = q.qx, qy = q.qy, qz = q.qz;
+    const float cell2 = g.cell * g.cell, inv_cell2 = 1.0f / cell2;
     for (int r = 2; r <= g.max_ring; ++r) {
         const float reach = ((float)(r - 1) - kCellMargin) * g.cell;   // all of ring r-1 is done
         if (limit2 <= reach * reach) break;
         for (int dz = -r; dz <= r; ++dz) {
-            const int z = cz + dz;
+            const int z = q.cz + dz;
             if (z < 0 || z >= g.nz) continue;
-            const float az = axis_gap(uz, z, z), gz = az * az;
+            const float az = axis_gap(q.uz, z, z), gz = az * az;
             if (gz * cell2 > limit2) continue;
             for (int dy = -r; dy <= r; ++dy) {
-                const int y = cy + dy;
+                const int y = q.cy + dy;
                 if (y < 0 || y >= g.ny) continue;
-                const float ay = axis_gap(uy, y, y), gyz = ay * ay + gz;
-                if (gyz * cell2 > limit2) continue;
+                const float ay = axis_gap(q.uy, y, y), gyz = ay * ay + gz;
+                const float rem = limit2 * inv_cell2 - gyz;   // budget left for the x gap, squared cells
+                if (rem < 0.0f) continue;
                 const int row = (int)dense_cell_id(g, 0, y, z);
                 const bool face = (abs(dz) == r) || (abs(dy) == r);
-                if (face) {   // whole row cx-r .. cx+r
-                    const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
-                    const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(tab, (uint32_t)(row + xa) * 4u, 0, 0);
-                    const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
-                    dscan_range(b, pts, s * 16u, e * 16u, qx, qy, qz);
+                if (face) {   // cells cx-r .. cx+r of this row, clipped to what the budget reaches
+                    const int reach_x = (int)fminf(sqrtf(rem) + 1.0f + kCellMargin, (float)r);   // generous by one cell
+                    const int xa = max(q.cx - reach_x, 0), xb = min(q.cx + reach_x, g.nx - 1);
+                    const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
+                    const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
+                    dscan_range(b, rs.pts, s * 16u, e * 16u, qx, qy, qz);
                     limit2 = fminf(limit2, key_d2(b.key));
                 } else {      // only the two end cells belong to ring r
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const int x = s ? cx + r : cx - r;
+                        const int x = s ? q.cx + r : q.cx - r;
                         if (x < 0 || x >= g.nx) continue;
-                        const float ax = axis_gap(ux, x, x);
-                        if ((ax * ax + gyz) * cell2 > limit2) continue;
-                        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(tab, (uint32_t)(row + x) * 4u, 0, 0);
-                        dscan_range(b, pts, se.x * 16u, se.y * 16u, qx, qy, qz);
+                        const float ax = axis_gap(q.ux, x, x);
+                        if (ax * ax > rem) continue;
+                        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)(row + x) * 4u, 0, 0);
+                        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qx, qy, qz);
                         limit2 = fminf(limit2, key_d2(b.key));
                     }
                 }
             }
         }
     }
+}
+
+__device__ __forceinline__ Best dense_result(const DBest &b)
+{
+    Best out{~0ull, -1, FLT_MAX};
     if (b.off != 0xffffffffu) {
         out.key = b.key;
         out.pos = (int)(b.off >> 4);
         out.d2 = key_d2(b.key);
     }
     return out;
+}
+
+// Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
+__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos)
+{
+    if (g.nx <= 0) return Best{~0ull, -1, FLT_MAX};
+    const DRes rs = dense_res(g);
+    const DQuery q = dense_query(g, qx, qy, qz);
+    float limit2 = g.prune2;
+    DBest b{0x7f800000ull << 32, 0xffffffffu};
+    dense_seed(rs, q, seed_pos, b, limit2);
+    dense_near(g, rs, q, b, limit2);
+    if (dense_needs_far(g, limit2)) dense_far(g, rs, q, b, limit2);
+    return dense_result(b);
 }
 
 __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, uint32_t n, DenseDev g, double gate2,
@@ -299,7 +388,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t
         if (q.w != 0.0f) {
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
-                q = make_float4(t.x, t.y, t.z, 1.0f);
+                q = make_float4(t.x, t.y, t.z, q.w);
                 cur[i] = q;
             }
             const Best b = nn_query_dense(g, q.x, q.y, q.z, seed ? seed[i] : -1);
@@ -320,7 +409,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
         const float4 t = g.pts[pos];
-        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2);
+        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
 }

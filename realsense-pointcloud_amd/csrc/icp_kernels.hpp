@@ -143,14 +143,21 @@ __device__ __forceinline__ const float *rec_xyz(const char *base, size_t stride,
 }
 
 // ------------------------------------------------------------------------------ grid build
-// bbox[0..2] = min (ordered uint), bbox[3..5] = max, bbox[6] = number of finite points
-__global__ __launch_bounds__(kBlock) void k_bbox(const char *pts, size_t stride, uint32_t n, uint32_t *bbox)
+// per block: partial[0..2] = min (ordered uint), [3..5] = max, [6] = number of finite points
+__global__ __launch_bounds__(kBlock) void k_bbox(const char *pts, size_t stride, uint32_t n, uint32_t *partial)
 {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     uint32_t cnt = 0;
+    const bool vec = (stride % 16 == 0) && ((reinterpret_cast<size_t>(pts) & 15) == 0);   // PointXYZRGB records: one 16-B load
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *p = rec_xyz(pts, stride, i);
-        const float x = p[0], y = p[1], z = p[2];
+        float x, y, z;
+        if (vec) {
+            const float4 v = *reinterpret_cast<const float4 *>(pts + (size_t)i * stride);
+            x = v.x; y = v.y; z = v.z;
+        } else {
+            const float *p = rec_xyz(pts, stride, i);
+            x = p[0]; y = p[1]; z = p[2];
+        }
         if (finite3(x, y, z)) {
             mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
             mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
@@ -172,18 +179,46 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const char *pts, size_t stride,
         scnt[wave] = cnt;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // one set of atomics per block
+    if (threadIdx.x == 0) {  // one partial per block: same-address atomics from 1024 blocks cost ~80 us
         for (int w = 1; w < kBlock / 64; ++w) {
             for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], smn[w][k]); mx[k] = fmaxf(mx[k], smx[w][k]); }
             cnt += scnt[w];
         }
-        if (cnt) {
-            for (int k = 0; k < 3; ++k) {
-                atomicMin(&bbox[k], float_ordered(mn[k]));
-                atomicMax(&bbox[3 + k], float_ordered(mx[k]));
-            }
-            atomicAdd(&bbox[6], cnt);
+        uint32_t *out = partial + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 3; ++k) { out[k] = float_ordered(mn[k]); out[3 + k] = float_ordered(mx[k]); }
+        out[6] = cnt;
+    }
+}
+
+// one block: combine the per-block partials of k_bbox into bbox[0..6]
+__global__ __launch_bounds__(kBlock) void k_bbox_final(const uint32_t *partial, uint32_t nblocks, uint32_t *bbox)
+{
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0, 0, 0}, cnt = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        const uint32_t *p = partial + (size_t)b * 8;
+        if (p[6]) {
+            for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], p[k]); mx[k] = max(mx[k], p[3 + k]); }
+            cnt += p[6];
         }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], __shfl_down(mn[k], off)); mx[k] = max(mx[k], __shfl_down(mx[k], off)); }
+        cnt += __shfl_down(cnt, off);
+    }
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k) { sm[wave][k] = mn[k]; sm[wave][3 + k] = mx[k]; }
+        sm[wave][6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], sm[w][k]); mx[k] = max(mx[k], sm[w][3 + k]); }
+            cnt += sm[w][6];
+        }
+        for (int k = 0; k < 3; ++k) { bbox[k] = mn[k]; bbox[3 + k] = mx[k]; }
+        bbox[6] = cnt;
     }
 }
 
@@ -334,6 +369,50 @@ __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_
     if (cur) cur[j] = s;
 }
 
+// keep[j]: sorted source point j is not an exact copy of its predecessor (same Morton key, same
+// xyz).  Invalid points are never merged (they carry weight 0 anyway).
+__global__ __launch_bounds__(kBlock) void k_source_flag(const unsigned long long *keys, const float4 *src_all, uint32_t n,
+                                                        uint32_t *keep)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t kp = 1;
+    if (j > 0 && keys[j] == keys[j - 1]) {
+        const float4 a = src_all[j], b = src_all[j - 1];
+        if (a.w != 0.0f && b.w != 0.0f && a.x == b.x && a.y == b.y && a.z == b.z) kp = 0;
+    }
+    keep[j] = kp;
+}
+
+// pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id
+__global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all, uint32_t n, const uint32_t *keep,
+                                                          const uint32_t *pos, uint32_t *first, uint32_t *uniq_of,
+                                                          uint32_t *count)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t u = keep[j] ? pos[j] : pos[j] - 1;
+    uniq_of[j] = u;
+    if (keep[j]) first[u] = j;
+    if (j == n - 1) {
+        count[0] = u + 1;
+        first[u + 1] = n;
+    }
+}
+
+// src[u] = {xyz, weight = number of copies (0: invalid point)}; cur = copy
+__global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all, const uint32_t *first, uint32_t nu, float4 *src,
+                                                           float4 *cur)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nu) return;
+    const uint32_t j = first[u];
+    float4 s = src_all[j];
+    s.w = s.w != 0.0f ? (float)(first[u + 1] - j) : 0.0f;
+    src[u] = s;
+    cur[u] = s;
+}
+
 __global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, uint32_t n, Mat34 guess, int apply_guess,
                                                            float4 *cur)
 {
@@ -342,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, ui
     float4 s = src[i];
     if (s.w != 0.0f && apply_guess) {
         const float3 t = xform(guess, s.x, s.y, s.z);
-        s = make_float4(t.x, t.y, t.z, 1.0f);
+        s = make_float4(t.x, t.y, t.z, s.w);
     }
     cur[i] = s;
 }
@@ -354,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_transform(float4 *cur, uint32_t n, M
     float4 s = cur[i];
     if (s.w != 0.0f) {
         const float3 t = xform(T, s.x, s.y, s.z);
-        cur[i] = make_float4(t.x, t.y, t.z, 1.0f);
+        cur[i] = make_float4(t.x, t.y, t.z, s.w);
     }
 }
 
@@ -626,15 +705,18 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// accumulate one accepted pair (p = source, q = target) into the 17 sums
-__device__ __forceinline__ void accum_pair(double *a, float px, float py, float pz, float qx, float qy, float qz, float d2)
+// accumulate one accepted pair (p = source, q = target) into the 17 sums; w = how many
+// identical source points this one stands for (exact duplicates are searched once)
+__device__ __forceinline__ void accum_pair(double *a, float px, float py, float pz, float qx, float qy, float qz, float d2,
+                                           float w)
 {
+    const double W = (double)w;
     const double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
-    a[0] += 1.0;
-    for (int k = 0; k < 3; ++k) { a[1 + k] += P[k]; a[4 + k] += Q[k]; }
+    a[0] += W;
+    for (int k = 0; k < 3; ++k) { a[1 + k] += W * P[k]; a[4 + k] += W * Q[k]; }
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) a[7 + r * 3 + c] += Q[r] * P[c];
-    a[16] += (double)d2;
+        for (int c = 0; c < 3; ++c) a[7 + r * 3 + c] += W * (Q[r] * P[c]);
+    a[16] += W * (double)d2;
 }
 
 constexpr int kTile = 128;         // source points per workgroup in the iteration kernels: 2 waves
@@ -672,7 +754,7 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const i
         if (pos >= 0) {
             const float4 p = cur[i];
             const float4 q = tgt[pos];
-            accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i]);
+            accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i], p.w);
         }
     }
     tile_reduce_store(a, partials, gridDim.x);
@@ -711,7 +793,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
         if (q.w != 0.0f) {
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
-                q = make_float4(t.x, t.y, t.z, 1.0f);
+                q = make_float4(t.x, t.y, t.z, q.w);
                 cur[i] = q;
             }
             const Best b = nn_query(g, q.x, q.y, q.z, seed ? seed[i] : -1);
@@ -728,21 +810,23 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
         const float4 t = g.pts[pos];
-        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2);
+        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
 }
 
 // corr (sorted source order, position in the sorted target) -> caller's order and indices
 __global__ __launch_bounds__(kBlock) void k_export_corr(const int *corr_pos, const float *corr_d2, const float4 *tgt,
-                                                        const uint32_t *perm, uint32_t n, int *index_out, float *d2_out)
+                                                        const uint32_t *perm, const uint32_t *uniq_of, uint32_t n,
+                                                        int *index_out, float *d2_out)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;   // sorted position of an ORIGINAL source point
     if (j >= n) return;
-    const int pos = corr_pos[j];
+    const uint32_t u = uniq_of[j];
+    const int pos = corr_pos[u];
     const uint32_t o = perm ? perm[j] : j;
     index_out[o] = pos >= 0 ? (int)__float_as_uint(tgt[pos].w) : -1;
-    d2_out[o] = corr_d2[j];
+    d2_out[o] = corr_d2[u];
 }
 
 }  // namespace rsreg

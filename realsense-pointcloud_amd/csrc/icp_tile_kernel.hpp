@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
     const bool valid = (i < n) && q.w != 0.0f && g.dx > 0;
     if ((i < n) && q.w != 0.0f && apply_t) {
         const float3 t = xform(T, q.x, q.y, q.z);
-        q = make_float4(t.x, t.y, t.z, 1.0f);
+        q = make_float4(t.x, t.y, t.z, q.w);
         cur[i] = q;
     }
     QueryGeom qg{0.f, 0.f, 0.f, 0, 0, 0};
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
         for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
         if (pos >= 0) {
             const float4 t = g.pts[pos];
-            accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2);
+            accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
         }
         tile_reduce_store(a, partials, gridDim.x);
     }

@@ -120,10 +120,14 @@ struct rsreg_ctx {
 
     // ---- ICP source
     bool have_source = false;
-    size_t n_source = 0;
+    size_t n_source = 0;          // source points handed in
+    size_t n_work = 0;            // distinct source points the iteration works on (exact copies merged)
+    rsreg::DevBuf d_src_all;      // float4 {x,y,z,valid} of every source point, spatially sorted
+    rsreg::DevBuf d_uniq_of;      // uint32: sorted position -> distinct point id
+    rsreg::DevBuf d_first;        // uint32[n_work+1]: first sorted position of each distinct point
     rsreg::DevBuf d_src_raw;      // packed xyz as handed in
     rsreg::DevBuf d_perm;         // uint32: spatially sorted position -> caller's index
-    rsreg::DevBuf d_src;          // float4 {x,y,z,valid}, spatially sorted
+    rsreg::DevBuf d_src;          // float4 {x,y,z,weight} of the distinct points, spatially sorted
     rsreg::DevBuf d_cur;          // float4 current (transformed) source
     rsreg::DevBuf d_corr_pos;     // int32: position in d_tgt_sorted, -1 = none
     rsreg::DevBuf d_corr_d2;      // float

@@ -168,11 +168,14 @@ def main():
 
     pairs = float(n_src_total) * a.iterations * a.steps
     value = pairs / elapsed
-    # roofline of the dominant kernel (k_icp_fused in pipeline 1, k_nn_search in pipeline 0):
-    # algorithmic bytes per launch, DESIGN.md §5: fused 32*N_src + 16*N_tgt_unique,
-    # staged NN 24*N_src + 16*N_tgt_unique (per rank)
+    # roofline of the dominant kernel (fused search+sums in pipeline 1, plain search in pipeline 0;
+    # the _dense variants run when the target index is the dense cell-start table):
+    # algorithmic bytes per launch, DESIGN.md §5: fused 32*N_src' + 16*N_tgt', staged 24*N_src' + 16*N_tgt'
+    # (per rank; N' = distinct points actually resident -- exact copies are merged on load)
     n_unique = int(gi.n_unique_points)
-    alg_bytes = (32 if a.pipeline == 1 else 24) * n_src + 16 * n_unique
+    n_distinct = int(gi.n_source_distinct) or n_src
+    kern = ("k_icp_fused" if a.pipeline == 1 else "k_nn_search") + ("_dense" if gi.index_kind == 1 else "")
+    alg_bytes = (32 if a.pipeline == 1 else 24) * n_distinct + 16 * n_unique
     avg_ms = ms_nn / max(n_launch, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside
@@ -184,7 +187,6 @@ def main():
         if tj:
             t = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
             w = t.get("workload", {})
-            kern = "k_icp_fused" if a.pipeline == 1 else "k_nn_search"
             if (w.get("size") == a.size and w.get("iterations") == a.iterations and w.get("max_dist") == a.max_dist
                     and w.get("pipeline") == ("fused" if a.pipeline == 1 else "staged") and world == 1 and kern in t["kernels"]):
                 traffic = t["kernels"][kern]["traffic_bytes_corrected"]
@@ -211,7 +213,7 @@ def main():
             "step": "grid build + source load + %d iterations, inputs resident in HBM" % a.iterations,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_icp_fused" if a.pipeline == 1 else "k_nn_search",
+            "bound": "hbm", "kernel": kern,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
             "launches": n_launch,
@@ -220,8 +222,9 @@ def main():
             "grid_build": ms_build / a.steps, "nn_kernel": ms_nn / a.steps, "reduce_transform": ms_red / a.steps,
             "iteration_rate_pairs_per_s": float(n_src_total) * a.iterations * a.steps / max((ms_nn + ms_red) * 1e-3, 1e-12),
         },
-        "grid": {"cell_size": float(gi.cell_size), "n_cells": int(gi.n_cells), "n_unique_points": n_unique,
-                 "max_points_per_cell": int(gi.max_points_per_cell)},
+        "grid": {"kind": "dense cell-start table" if gi.index_kind == 1 else "brick hash", "cell_size": float(gi.cell_size),
+                 "n_cells": int(gi.n_cells), "n_unique_points": n_unique, "n_source_distinct": n_distinct,
+                 "index_bytes": int(gi.index_bytes)},
     }
 
     if not a.no_cpu_baseline:

@@ -259,6 +259,9 @@ typedef struct rsreg_grid_info {
     uint32_t n_cells;           /* occupied cells                                           */
     uint32_t max_points_per_cell;
     double ms_build;            /* device time of the last build (profiling on)             */
+    uint32_t index_kind;        /* 1 = dense cell-start table, 0 = brick hash (huge extents) */
+    uint32_t n_source_distinct; /* distinct source points the iterations work on (0: no source) */
+    uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
 } rsreg_grid_info;
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
 

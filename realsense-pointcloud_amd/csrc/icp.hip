@@ -268,6 +268,9 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     gi.n_unique_points = gp.n_points;
     gi.n_cells = gp.n_cells;
     gi.max_points_per_cell = 0;   // dense mode: computed on demand by rsreg_icp_grid_info
+    gi.index_kind = 1;
+    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) +
+                     ((uint64_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2) + 1) * sizeof(uint32_t);
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -418,6 +421,8 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     gi.n_unique_points = n_unique;
     gi.n_cells = n_cells;
     gi.max_points_per_cell = h_misc[10];
+    gi.index_kind = 0;
+    gi.index_bytes = (uint64_t)n_unique * sizeof(float4) + (uint64_t)slots * sizeof(BrickEntry) + ((uint64_t)n_cells + 1) * 4;
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -1065,6 +1070,7 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
         ctx->grid_info.max_points_per_cell = h;
     }
     *info = ctx->grid_info;
+    info->n_source_distinct = ctx->have_source ? (uint32_t)ctx->n_work : 0u;
     return RSREG_OK;
 }
 

@@ -76,6 +76,7 @@ class GridInfo(C.Structure):
         ("origin", C.c_float * 3), ("cell_size", C.c_float), ("dims", C.c_int32 * 3),
         ("n_target_points", C.c_uint32), ("n_unique_points", C.c_uint32), ("n_cells", C.c_uint32),
         ("max_points_per_cell", C.c_uint32), ("ms_build", C.c_double),
+        ("index_kind", C.c_uint32), ("n_source_distinct", C.c_uint32), ("index_bytes", C.c_uint64),
     ]
 
 

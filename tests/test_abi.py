@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.IcpParams) == 48
     assert C.sizeof(L.NdtParams) == 40
     assert C.sizeof(L.IcpResult) == 64 + 16 + 8 + 8 + 17 * 8 + 4 * 8 + 8
-    assert C.sizeof(L.GridInfo) == 56
+    assert C.sizeof(L.GridInfo) == 72
 
 
 def test_reference_presets(rs, L):

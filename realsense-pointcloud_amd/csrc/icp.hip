@@ -185,6 +185,7 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.pts = ctx->d_tgt_sorted.as<float4>();
     g.n_pts = p.n_points;
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
+    g.nbr = ctx->d_nbr.as<uint32_t>();
     return g;
 }
 
@@ -219,6 +220,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
     RSREG_HIP(ctx, ctx->d_brick.reserve(((size_t)nfin + 2) * 4));
     RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_nbr.reserve((total + 2) * 4));
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
     k_dense_fill_sentinels<<<div_up(nfin + 4, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), nfin + 4);
     RSREG_HIP(ctx, hipGetLastError());
@@ -256,6 +258,10 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, hipGetLastError());
     // counts -> first sorted point of every cell (in place), entry [total] = number of points
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+    // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
+    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_nbr.ptr, 0, (total + 2) * 4, st));
+    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, ctx->d_nbr.as<uint32_t>());
+    RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
@@ -269,8 +275,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     gi.n_cells = gp.n_cells;
     gi.max_points_per_cell = 0;   // dense mode: computed on demand by rsreg_icp_grid_info
     gi.index_kind = 1;
-    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) +
-                     ((uint64_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2) + 1) * sizeof(uint32_t);
+    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t);
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -562,7 +567,7 @@ unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
 {
     static const bool on = std::getenv("RSREG_WAVE_TIMES") != nullptr;
     if (!on) return nullptr;
-    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 16) != hipSuccess) return nullptr;
+    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 128) != hipSuccess) return nullptr;
     return ctx->d_brick.as<unsigned long long>();
 }
 
@@ -650,11 +655,14 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
-        if (ctx->grid.dense)
-            k_icp_fused_dense<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
+        if (ctx->grid.dense) {
+            unsigned long long *wt = wave_times_ptr(ctx, n);
+            auto kern = wt ? k_icp_fused_dense<true> : k_icp_fused_dense<false>;
+            kern<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
-                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wave_times_ptr(ctx, n));
+                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt);
+        }
         else if (use_tile_kernel())
             k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
                                                                      s.pending_transform ? 1 : 0, g, gate2, ctx->d_corr_pos.as<int>(),
@@ -784,7 +792,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rsreg_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
@@ -985,7 +993,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
         if (ctx->grid.dense && ctx->n_work) {
             const size_t nw = (ctx->n_work + 63) / 64;
-            std::vector<unsigned long long> h(2 * nw);
+            std::vector<unsigned long long> h(16 * nw);
             (void)hipMemcpy(h.data(), ctx->d_brick.ptr, h.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = std::fopen(wt_path, "wb")) {
                 std::fwrite(h.data(), 8, h.size(), f);

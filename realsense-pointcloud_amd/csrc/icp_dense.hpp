@@ -32,6 +32,7 @@ struct DenseDev {
     const float4 *pts;       // sorted target points followed by 4 far-away sentinels
     uint32_t n_pts;          // sorted target points (without the sentinels)
     uint32_t table_bytes;
+    const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
 };
 
 __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int y, int z)
@@ -133,49 +134,73 @@ __global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *tabl
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
+// nbr[n] |= bit(offset of c seen from n) for the 27 cells n around every occupied cell c
+__global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, const uint32_t *stats, int sx, int sxy, uint32_t *nbr)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= stats[0]) return;
+    const int slot = (int)cellslot[c];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
+        atomicOr(&nbr[slot - ((dz - 1) * sxy + (dy - 1) * sx + (dx - 1))], 1u << j);
+    }
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float sel3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
 
-// running best as one 64-bit key (distance bits << 32 | original index) + the byte offset of
-// the winning point; starts at "+inf, no point" so that sentinel points can never win
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+
+// running best: squared distance, original index (the tie-break) and the byte offset of the
+// winning point; starts at "+inf, no point" so that the far-away sentinel points never win
 struct DBest {
-    unsigned long long key;
+    float d;
+    uint32_t idx;
     uint32_t off;
 };
 
-__device__ __forceinline__ void dconsider(DBest &b, float qx, float qy, float qz, const u32x4 &t, uint32_t off)
+// FLANN L2_Simple in its own order ((dx^2 + dy^2) + dz^2, nothing fused); x and y go through
+// the packed f32 pipe straight out of the loaded register pair
+__device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u32x4 &t, uint32_t off)
 {
-    const float d = l2_simple(qx, qy, qz, __uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z));
-    const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | t.w;
-    if (k < b.key) {
-        b.key = k;
-        b.off = off;
-    }
+    const f32x2 txy = {__uint_as_float(t.x), __uint_as_float(t.y)};
+    const f32x2 dxy = qxy - txy;
+    const f32x2 sq = dxy * dxy;
+    const float dz = __fsub_rn(qz, __uint_as_float(t.z));
+    const float d = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
+    const bool better = (d < b.d) | ((d == b.d) & (t.w < b.idx));
+    b.d = better ? d : b.d;
+    b.idx = better ? t.w : b.idx;
+    b.off = better ? off : b.off;
 }
 
 // score 4 consecutive points starting at byte offset `po` (reading past the end of a cell
 // only meets more real target points, or the far-away sentinels behind the last one)
-__device__ __forceinline__ void dscan4(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, float qx, float qy, float qz)
+__device__ __forceinline__ void dscan4(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, f32x2 qxy, float qz)
 {
     const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(pts, po, 0, 0);
     const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 16, 0, 0);
     const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 32, 0, 0);
     const u32x4 t3 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 48, 0, 0);
-    dconsider(b, qx, qy, qz, t0, po);
-    dconsider(b, qx, qy, qz, t1, po + 16);
-    dconsider(b, qx, qy, qz, t2, po + 32);
-    dconsider(b, qx, qy, qz, t3, po + 48);
+    dconsider(b, qxy, qz, t0, po);
+    dconsider(b, qxy, qz, t1, po + 16);
+    dconsider(b, qxy, qz, t2, po + 32);
+    dconsider(b, qxy, qz, t3, po + 48);
 }
 
-__device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, float qx, float qy,
-                                            float qz)
+__device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, f32x2 qxy, float qz)
 {
-    for (; po < pe; po += 64) dscan4(b, pts, po, qx, qy, qz);
+    for (; po < pe; po += 64) dscan4(b, pts, po, qxy, qz);
 }
 
-__device__ __forceinline__ float key_d2(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
+struct DDiag {       // diagnostic launches only: per-lane step counts and two clock stamps
+    uint32_t own = 0, r1_cells = 0, r1_scans = 0, far_rows = 0, far_scans = 0;
+    unsigned long long t_near = 0, t_far = 0;
+};
 
 struct DQuery {      // a query and where it sits in the grid
     float qx, qy, qz;
@@ -183,8 +208,8 @@ struct DQuery {      // a query and where it sits in the grid
     int cx, cy, cz;
 };
 
-struct DRes {        // the two arrays behind 32-bit offsets (wave-uniform descriptors)
-    __amdgpu_buffer_rsrc_t pts, tab;
+struct DRes {        // the arrays behind 32-bit offsets (wave-uniform descriptors)
+    __amdgpu_buffer_rsrc_t pts, tab, nbr;
 };
 
 __device__ __forceinline__ DRes dense_res(const DenseDev &g)
@@ -192,6 +217,7 @@ __device__ __forceinline__ DRes dense_res(const DenseDev &g)
     DRes r;
     r.pts = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(g.pts), 0, (g.n_pts + 4) * 16, 0x00020000);
     r.tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(g.start), 0, g.table_bytes, 0x00020000);
+    r.nbr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(g.nbr), 0, g.table_bytes, 0x00020000);
     return r;
 }
 
@@ -212,22 +238,27 @@ __device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int 
 {
     if (seed_pos >= 0) {
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs.pts, (uint32_t)seed_pos * 16u, 0, 0);
-        dconsider(b, q.qx, q.qy, q.qz, t, (uint32_t)seed_pos * 16u);
-        limit2 = fminf(limit2, key_d2(b.key));
+        dconsider(b, f32x2{q.qx, q.qy}, q.qz, t, (uint32_t)seed_pos * 16u);
+        limit2 = fminf(limit2, b.d);
     }
 }
 
-// rings 0 and 1
-__device__ __forceinline__ void dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2)
+// rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
+template <bool kDiag = false>
+__device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
+                                               DDiag *dg = nullptr)
 {
-    const float qx = q.qx, qy = q.qy, qz = q.qz;
+    const f32x2 qxy = {q.qx, q.qy};
+    const float qz = q.qz;
     const float cell2 = g.cell * g.cell;
     const int base = (int)dense_cell_id(g, q.cx, q.cy, q.cz);
+    const uint32_t occ = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
     {
         const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
-        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qx, qy, qz);
-        limit2 = fminf(limit2, key_d2(b.key));
+        if (kDiag) dg->own = (se.y - se.x + 3) / 4;
+        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qxy, qz);
+        limit2 = fminf(limit2, b.d);
     }
     // ---- ring 1: only the cells whose box can still hold something closer.  A neighbour at
     // offset (dx,dy,dz) needs every non-zero axis offset's face to be within the limit, so when
@@ -239,7 +270,7 @@ __device__ __forceinline__ void dense_near(const DenseDev &g, const DRes &rs, co
     gx0 *= gx0; gx2 *= gx2; gy0 *= gy0; gy2 *= gy2; gz0 *= gz0; gz2 *= gz2;
     const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis: 0 is always a valid lower bound
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
-    if (!any_face) return;
+    if (!any_face || !(occ & ~(1u << 13))) return occ;
     uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
@@ -249,10 +280,12 @@ __device__ __forceinline__ void dense_near(const DenseDev &g, const DRes &rs, co
                          (dz == 0 ? gz0 : (dz == 1 ? gz1 : gz2));
         mask |= (lb <= lim_c) ? (1u << j) : 0u;
     }
+    mask &= occ;         // empty cells are never opened
     uint32_t po = 0, pe = 0;
     for (;;) {   // flat: each iteration takes the next plausible cell and/or scores 4 candidates
         if (po >= pe) {
             if (!mask) break;
+            if (kDiag) ++dg->r1_cells;
             const int j = __ffs((int)mask) - 1;
             mask &= mask - 1;
             const int dz = j / 9, dy = (j - dz * 9) / 3, dx = j - dz * 9 - dy * 3;
@@ -265,11 +298,13 @@ __device__ __forceinline__ void dense_near(const DenseDev &g, const DRes &rs, co
             }
         }
         if (po < pe) {
-            dscan4(b, rs.pts, po, qx, qy, qz);
+            if (kDiag) ++dg->r1_scans;
+            dscan4(b, rs.pts, po, qxy, qz);
             po += 64;
-            limit2 = fminf(limit2, key_d2(b.key));
+            limit2 = fminf(limit2, b.d);
         }
     }
+    return occ;
 }
 
 // does this query still need rings >= 2 after rings 0-1 ?
@@ -282,9 +317,12 @@ __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
 // Rings >= 2: row by row (the cells of one (y, z) row are one contiguous run of points), nearest
 // ring first, until everything unvisited is provably farther than the best.  Inside a row only
 // the x-extent the remaining budget allows is read.
-__device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2)
+template <bool kDiag = false>
+__device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
+                                          DDiag *dg = nullptr)
 {
-    const float qx = q.qx, qy = q.qy, qz = q.qz;
+    const f32x2 qxy = {q.qx, q.qy};
+    const float qz = q.qz;
     const float cell2 = g.cell * g.cell, inv_cell2 = 1.0f / cell2;
     for (int r = 2; r <= g.max_ring; ++r) {
         const float reach = ((float)(r - 1) - kCellMargin) * g.cell;   // all of ring r-1 is done
@@ -301,14 +339,16 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
                 const float rem = limit2 * inv_cell2 - gyz;   // budget left for the x gap, squared cells
                 if (rem < 0.0f) continue;
                 const int row = (int)dense_cell_id(g, 0, y, z);
+                        if (kDiag) ++dg->far_rows;
                 const bool face = (abs(dz) == r) || (abs(dy) == r);
                 if (face) {   // cells cx-r .. cx+r of this row, clipped to what the budget reaches
                     const int reach_x = (int)fminf(sqrtf(rem) + 1.0f + kCellMargin, (float)r);   // generous by one cell
                     const int xa = max(q.cx - reach_x, 0), xb = min(q.cx + reach_x, g.nx - 1);
                     const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
                     const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
-                    dscan_range(b, rs.pts, s * 16u, e * 16u, qx, qy, qz);
-                    limit2 = fminf(limit2, key_d2(b.key));
+                    if (kDiag) dg->far_scans += (e - s + 3) / 4;
+                    dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, qz);
+                    limit2 = fminf(limit2, b.d);
                 } else {      // only the two end cells belong to ring r
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -317,8 +357,9 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
                         const float ax = axis_gap(q.ux, x, x);
                         if (ax * ax > rem) continue;
                         const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)(row + x) * 4u, 0, 0);
-                        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qx, qy, qz);
-                        limit2 = fminf(limit2, key_d2(b.key));
+                        if (kDiag) dg->far_scans += (se.y - se.x + 3) / 4;
+                        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qxy, qz);
+                        limit2 = fminf(limit2, b.d);
                     }
                 }
             }
@@ -330,24 +371,28 @@ __device__ __forceinline__ Best dense_result(const DBest &b)
 {
     Best out{~0ull, -1, FLT_MAX};
     if (b.off != 0xffffffffu) {
-        out.key = b.key;
+        out.key = ((unsigned long long)__float_as_uint(b.d) << 32) | b.idx;
         out.pos = (int)(b.off >> 4);
-        out.d2 = key_d2(b.key);
+        out.d2 = b.d;
     }
     return out;
 }
 
 // Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
-__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos)
+template <bool kDiag = false>
+__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos, DDiag *dg = nullptr)
 {
     if (g.nx <= 0) return Best{~0ull, -1, FLT_MAX};
     const DRes rs = dense_res(g);
     const DQuery q = dense_query(g, qx, qy, qz);
     float limit2 = g.prune2;
-    DBest b{0x7f800000ull << 32, 0xffffffffu};
+    DBest b{__uint_as_float(0x7f800000u), 0xffffffffu, 0xffffffffu};
     dense_seed(rs, q, seed_pos, b, limit2);
-    dense_near(g, rs, q, b, limit2);
-    if (dense_needs_far(g, limit2)) dense_far(g, rs, q, b, limit2);
+    dense_near<kDiag>(g, rs, q, b, limit2, dg);
+    if (kDiag) dg->t_near = wall_clock64();
+    const bool far = dense_needs_far(g, limit2);
+    if (far) dense_far<kDiag>(g, rs, q, b, limit2, dg);
+    if (kDiag) dg->t_far = wall_clock64();
     return dense_result(b);
 }
 
@@ -372,14 +417,17 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
 }
 
 // One ICP iteration in one pass over the dense index: apply the previous increment, search,
-// gate, accumulate (same contract and summation order as k_icp_fused).
+// gate, accumulate (same contract and summation order as k_icp_fused).  kDiag: the diagnostic
+// instantiation (RSREG_WAVE_TIMES) also writes 8 clock stamps per wave.
+template <bool kDiag>
 __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long t_start = 0;
-    if (wave_times) t_start = wall_clock64();
+    unsigned long long t_start = 0, t_search = 0;
+    DDiag dg;
+    if (kDiag) t_start = wall_clock64();
     int pos = -1;
     float d2 = 0.0f;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -391,7 +439,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t
                 q = make_float4(t.x, t.y, t.z, q.w);
                 cur[i] = q;
             }
-            const Best b = nn_query_dense(g, q.x, q.y, q.z, seed ? seed[i] : -1);
+            const Best b = nn_query_dense<kDiag>(g, q.x, q.y, q.z, seed ? seed[i] : -1, &dg);
             if (seed) seed[i] = b.pos;
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
@@ -400,11 +448,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t
         }
         if (corr_pos) { corr_pos[i] = pos; corr_d2[i] = d2; }
     }
-    if (wave_times && (threadIdx.x & 63) == 0) {   // diagnostic build of the launch only (RSREG_WAVE_TIMES)
-        const uint32_t w = i >> 6;
-        wave_times[2 * w] = t_start;
-        wave_times[2 * w + 1] = wall_clock64();
-    }
+    if (kDiag) t_search = wall_clock64();
     double a[RSREG_NUM_SUMS];
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
@@ -412,6 +456,27 @@ __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t
         accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
+    if (kDiag) {
+        // per wave: start, end of rings 0-1 (latest lane), end of far rings, end of search, end,
+        // then max-over-lanes | sum-over-lanes (<< 32) of the step counts
+        unsigned long long near_end = dg.t_near, far_end = dg.t_far;
+        uint32_t mx[5] = {dg.own, dg.r1_cells, dg.r1_scans, dg.far_rows, dg.far_scans}, sm[5];
+        for (int k = 0; k < 5; ++k) sm[k] = mx[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            near_end = max(near_end, (unsigned long long)__shfl_down((long long)near_end, off));
+            far_end = max(far_end, (unsigned long long)__shfl_down((long long)far_end, off));
+            for (int k = 0; k < 5; ++k) {
+                mx[k] = max(mx[k], (uint32_t)__shfl_down((int)mx[k], off));
+                sm[k] += (uint32_t)__shfl_down((int)sm[k], off);
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *w = wave_times + 16ull * (i >> 6);
+            w[0] = t_start; w[1] = near_end; w[2] = far_end; w[3] = t_search; w[4] = wall_clock64();
+            for (int k = 0; k < 5; ++k) w[5 + k] = (unsigned long long)mx[k] | ((unsigned long long)sm[k] << 32);
+            for (int k = 10; k < 16; ++k) w[k] = 0;
+        }
+    }
 }
 
 }  // namespace rsreg

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Dev probe: where the waves of the fused search kernel spend their time (GPU only).
+Runs one pair with RSREG_WAVE_TIMES set (the diagnostic instantiation of k_icp_fused_dense
+stamps every wave) and prints the per-phase distribution of the last launch."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+path = os.path.join(tempfile.gettempdir(), "rsreg_wave_times.bin")
+os.environ["RSREG_WAVE_TIMES"] = path
+import rsreg_amd  # noqa: E402
+from rsreg_amd import api, synth  # noqa: E402
+
+size = sys.argv[1] if len(sys.argv) > 1 else "N1M"
+preset = sys.argv[2] if len(sys.argv) > 2 else "bench"
+gate = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+tgt, src = synth.render_frame(0, size, preset), synth.render_frame(1, size, preset)
+guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+icp = api.IterativeClosestPoint(api.Context(0, profiling=True))
+icp.params = api.icp_params(max_iterations=iters, criteria_mode=1, max_correspondence_distance=gate)
+icp.setInputSource(src)
+icp.setInputTarget(tgt)
+icp.align(guess)
+w = np.fromfile(path, dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+t0 = w[:, 0].min()
+span = (w[:, 4].max() - t0) / 100.0
+print("waves %d, kernel span %.1f us (launch avg by events %.1f us)" % (len(w), span, icp.result.ms_nn / icp.result.n_nn_launches * 1e3))
+ph = {"rings 0-1 (+load, seed)": w[:, 1] - w[:, 0], "far rings": w[:, 2] - w[:, 1], "store/wait": w[:, 3] - w[:, 2],
+      "terms + block reduce": w[:, 4] - w[:, 3], "whole wave": w[:, 4] - w[:, 0]}
+for k, v in ph.items():
+    v = v / 100.0
+    print("%-26s mean %7.2f us  p50 %7.2f  p90 %7.2f  p99 %7.2f  max %7.2f   share of wave time %.1f %%"
+          % (k, v.mean(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(),
+             100.0 * v.sum() / (w[:, 4] - w[:, 0]).sum() * 100.0 / 100.0))
+names = ["own-cell steps", "ring-1 cells", "ring-1 scan steps", "far rows", "far scan steps"]
+dur = (w[:, 4] - w[:, 0]) / 100.0
+heavy = dur >= np.percentile(dur, 99)
+for k, nm in enumerate(names):
+    mx, sm = (w[:, 5 + k] & 0xffffffff), (w[:, 5 + k] >> 32)
+    print("%-18s wave-max: mean %6.1f p90 %5d p99 %5d max %5d | lane-mean %6.2f | in the slowest 1 %% of waves: wave-max mean %6.1f, lane-mean %6.2f"
+          % (nm, mx.mean(), np.percentile(mx, 90), np.percentile(mx, 99), mx.max(), sm.mean() / 64.0, mx[heavy].mean(), sm[heavy].mean() / 64.0))
+far = (w[:, 2] - w[:, 1]) > 20   # > 0.2 us spent in far rings
+print("waves entering far rings: %.1f %%" % (100.0 * far.mean()))
+start = (w[:, 0] - t0) / 100.0
+print("wave start times: p50 %.1f us p90 %.1f us max %.1f us" % (np.percentile(start, 50), np.percentile(start, 90), start.max()))

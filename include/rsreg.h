@@ -69,7 +69,11 @@ typedef enum rsreg_criteria_mode {
 /* Which kernels one ICP iteration is built from. Results are bit-identical across modes. */
 typedef enum rsreg_pipeline_mode {
     RSREG_PIPELINE_STAGED = 0, /* nn_search -> cov_reduce -> transform_reject (3 kernels)   */
-    RSREG_PIPELINE_FUSED = 1   /* one fused transform+NN+reject+sums kernel per iteration  */
+    RSREG_PIPELINE_FUSED = 1,  /* one fused transform+NN+reject+sums kernel per iteration  */
+    RSREG_PIPELINE_DEVICE_LOOP = 2 /* FUSED, and with RSREG_CRITERIA_FIXED the 3x3 solve and the
+                                  composition also run on the device: all iterations are queued
+                                  without a host round trip (same arithmetic, same result);
+                                  with the PCL criteria it behaves as FUSED */
 } rsreg_pipeline_mode;
 
 /*

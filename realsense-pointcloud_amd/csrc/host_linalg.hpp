@@ -11,16 +11,23 @@
 #include <cmath>
 #include <cstring>
 
+// the 3x3 pieces also run on the device (the device-resident ICP loop, icp.hip k_icp_solve):
+// same source, same operation order, f64 +,-,*,/,sqrt only, so both sides give the same bits
+#if defined(__HIPCC__)
+#define RSREG_HD __host__ __device__
+#else
+#define RSREG_HD
+#endif
+
 namespace rsreg {
 
 // Column-major 4x4 float transform (memcpy-compatible with Eigen::Matrix4f).
 struct Mat4f {
     float m[16];
-    static Mat4f identity()
+    RSREG_HD static Mat4f identity()
     {
         Mat4f r;
-        std::memset(r.m, 0, sizeof(r.m));
-        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+        for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
         return r;
     }
     bool is_identity() const
@@ -28,18 +35,21 @@ struct Mat4f {
         Mat4f i = identity();
         return std::memcmp(i.m, m, sizeof(m)) == 0;
     }
-    float &operator()(int r, int c) { return m[c * 4 + r]; }
-    float operator()(int r, int c) const { return m[c * 4 + r]; }
+    RSREG_HD float &operator()(int r, int c) { return m[c * 4 + r]; }
+    RSREG_HD float operator()(int r, int c) const { return m[c * 4 + r]; }
 };
 
 // c = a * b in f32 with the fixed evaluation order ((a0 b0 + a1 b1) + a2 b2) + a3 b3, no FMA.
 // The same order is part of the parity spec (oracle/icp_oracle.c orc_mat4_mul).
-inline Mat4f mul(const Mat4f &a, const Mat4f &b)
+RSREG_HD inline Mat4f mul(const Mat4f &a, const Mat4f &b)
 {
+#pragma clang fp contract(off)
     Mat4f r;
+#pragma unroll
     for (int j = 0; j < 4; ++j)
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
-            volatile float s = a.m[i] * b.m[j * 4];
+            float s = a.m[i] * b.m[j * 4];
             s = s + a.m[4 + i] * b.m[j * 4 + 1];
             s = s + a.m[8 + i] * b.m[j * 4 + 2];
             s = s + a.m[12 + i] * b.m[j * 4 + 3];
@@ -54,7 +64,7 @@ template <int N> struct SvdResult {
 };
 
 // One-sided Jacobi: rotate column pairs of W = A*V until mutually orthogonal.
-template <int N> inline void jacobi_svd(const double *A, SvdResult<N> &out)
+template <int N> RSREG_HD inline void jacobi_svd(const double *A, SvdResult<N> &out)
 {
     double W[N * N], V[N * N];
     for (int i = 0; i < N * N; ++i) W[i] = A[i];
@@ -74,8 +84,8 @@ template <int N> inline void jacobi_svd(const double *A, SvdResult<N> &out)
                 if (apq == 0.0 || apq * apq <= 1e-32 * app * aqq) continue;
                 rotated = true;
                 const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
                 for (int k = 0; k < N; ++k) {
                     const double wp = W[k * N + p], wq = W[k * N + q];
                     W[k * N + p] = c * wp - s * wq;
@@ -92,7 +102,7 @@ template <int N> inline void jacobi_svd(const double *A, SvdResult<N> &out)
     for (int j = 0; j < N; ++j) {
         double nn = 0;
         for (int k = 0; k < N; ++k) nn += W[k * N + j] * W[k * N + j];
-        norm[j] = std::sqrt(nn);
+        norm[j] = sqrt(nn);
         ord[j] = j;
     }
     for (int a = 0; a + 1 < N; ++a)
@@ -127,12 +137,123 @@ template <int N> inline void jacobi_svd(const double *A, SvdResult<N> &out)
             for (int i = 0; i < N; ++i) nn += v[i] * v[i];
             if (nn > bestn) { bestn = nn; for (int i = 0; i < N; ++i) best[i] = v[i]; }
         }
-        const double inv = 1.0 / std::sqrt(bestn);
+        const double inv = 1.0 / sqrt(bestn);
         for (int i = 0; i < N; ++i) out.U[i * N + k] = best[i] * inv;
     }
 }
 
-inline double det3(const double *M)
+// jacobi_svd<3> written so that every array index is a compile-time constant (the loops over
+// p, q, k unroll; orderings go through pick3): on the device all of it then lives in registers.
+// Same operations in the same order as the generic template above.
+RSREG_HD inline double pick3(double a0, double a1, double a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
+
+RSREG_HD inline void jacobi_svd3(const double *A, SvdResult<3> &out)
+{
+#pragma clang fp contract(off)
+    constexpr int N = 3;
+    double W[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) W[i] = A[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p + 1 < N; ++p)
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                double app = 0, aqq = 0, apq = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    app += W[k * N + p] * W[k * N + p];
+                    aqq += W[k * N + q] * W[k * N + q];
+                    apq += W[k * N + p] * W[k * N + q];
+                }
+                if (apq == 0.0 || apq * apq <= 1e-32 * app * aqq) continue;
+                rotated = true;
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const double wp = W[k * N + p], wq = W[k * N + q];
+                    W[k * N + p] = c * wp - s * wq;
+                    W[k * N + q] = s * wp + c * wq;
+                    const double vp = V[k * N + p], vq = V[k * N + q];
+                    V[k * N + p] = c * vp - s * vq;
+                    V[k * N + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double norm[3];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double nn = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) nn += W[k * N + j] * W[k * N + j];
+        norm[j] = sqrt(nn);
+    }
+    // the generic exchange sort on ord[], descending, with its three compare-exchanges spelled out
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (pick3(norm[0], norm[1], norm[2], o1) > pick3(norm[0], norm[1], norm[2], o0)) { const int t = o0; o0 = o1; o1 = t; }
+    if (pick3(norm[0], norm[1], norm[2], o2) > pick3(norm[0], norm[1], norm[2], o0)) { const int t = o0; o0 = o2; o2 = t; }
+    if (pick3(norm[0], norm[1], norm[2], o2) > pick3(norm[0], norm[1], norm[2], o1)) { const int t = o1; o1 = o2; o2 = t; }
+    const double smax = pick3(norm[0], norm[1], norm[2], o0);
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int j = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        const double nj = pick3(norm[0], norm[1], norm[2], j);
+        out.s[k] = nj;
+#pragma unroll
+        for (int i = 0; i < N; ++i) out.V[i * N + k] = pick3(V[i * N], V[i * N + 1], V[i * N + 2], j);
+        if (nj > 0 && nj > 1e-13 * smax) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) out.U[i * N + k] = pick3(W[i * N], W[i * N + 1], W[i * N + 2], j) / nj;
+            rank = k + 1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) out.U[i * N + k] = 0.0;
+        }
+    }
+    // complete U with unit vectors orthogonalised against the columns found so far
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k < rank) continue;
+        double best[3] = {0, 0, 0}, bestn = -1;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            double v[3];
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = i == e ? 1.0 : 0.0;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+                    if (m >= k) continue;
+                    double d = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) d += v[i] * out.U[i * N + m];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) v[i] -= d * out.U[i * N + m];
+                }
+            double nn = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) nn += v[i] * v[i];
+            if (nn > bestn) {
+                bestn = nn;
+#pragma unroll
+                for (int i = 0; i < N; ++i) best[i] = v[i];
+            }
+        }
+        const double inv = 1.0 / sqrt(bestn);
+#pragma unroll
+        for (int i = 0; i < N; ++i) out.U[i * N + k] = best[i] * inv;
+    }
+}
+
+RSREG_HD inline double det3(const double *M)
 {
     return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
            M[2] * (M[3] * M[7] - M[4] * M[6]);
@@ -159,8 +280,9 @@ template <int N> inline void svd_solve(const double *A, const double *b, double 
 
 // Eigen::umeyama(src, dst, with_scaling = false) from the 17 sums of an ICP iteration
 // (layout: include/rsreg.h RSREG_NUM_SUMS).  Returns false when n < 1.
-inline bool umeyama_from_sums(const double *sums, Mat4f &T)
+RSREG_HD inline bool umeyama_from_sums(const double *sums, Mat4f &T)
 {
+#pragma clang fp contract(off)
     const double n = sums[0];
     if (!(n >= 1.0)) return false;
     double mu_p[3], mu_q[3], sigma[9];
@@ -168,18 +290,23 @@ inline bool umeyama_from_sums(const double *sums, Mat4f &T)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = sums[7 + i * 3 + j] / n - mu_q[i] * mu_p[j];
     SvdResult<3> r;
-    jacobi_svd<3>(sigma, r);
+    jacobi_svd3(sigma, r);
     double S[3] = {1, 1, 1};
     if (det3(r.U) * det3(r.V) < 0) S[2] = -1;
     double R[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             double v = 0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) v += r.U[i * 3 + k] * S[k] * r.V[j * 3 + k];
             R[i * 3 + j] = v;
         }
     T = Mat4f::identity();
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) T(i, j) = float(R[i * 3 + j]);
         T(i, 3) = float(mu_q[i] - (R[i * 3] * mu_p[0] + R[i * 3 + 1] * mu_p[1] + R[i * 3 + 2] * mu_p[2]));
     }

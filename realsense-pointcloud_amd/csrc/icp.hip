@@ -647,10 +647,11 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
 }
 
 // fused pass: applies the pending increment (if any), searches, gates and reduces
-int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
+int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop = false)
 {
     IcpState &s = ctx->icp;
     const uint32_t n = (uint32_t)ctx->n_work;
+    const IcpDevState *dev = device_loop ? ctx->d_icp_state.as<IcpDevState>() : nullptr;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
@@ -661,7 +662,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
             kern<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
-                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt);
+                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev);
         }
         else if (use_tile_kernel())
             k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
@@ -672,7 +673,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
             k_icp_fused<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, g, gate2,
                 want_corr ? ctx->d_corr_pos.as<int>() : nullptr, ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(),
-                seed_ptr(ctx));
+                seed_ptr(ctx), dev);
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
     }
@@ -683,7 +684,53 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr)
         RSREG_HIP(ctx, hipGetLastError());
     }
     s.have_search = want_corr;
+    if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass
+        if (ctx->nranks > 1) {
+            int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
+            if (rc) return rc;
+        }
+        ScopedEvents ev(ctx, &ctx->ev_reduce);
+        k_icp_solve<<<1, 64, 0, ctx->stream>>>(ctx->d_sums.as<double>(), ctx->d_icp_state.as<IcpDevState>());
+        RSREG_HIP(ctx, hipGetLastError());
+        return RSREG_OK;
+    }
     return fetch_sums(ctx, sums, true);
+}
+
+// RSREG_PIPELINE_DEVICE_LOOP with fixed-count criteria: every iteration is queued up front, the
+// 136-byte state comes back once at the end.  Same kernels, same arithmetic as the host loop.
+int run_device_loop(rsreg_ctx *ctx)
+{
+    IcpState &s = ctx->icp;
+    RSREG_HIP(ctx, ctx->d_icp_state.reserve(sizeof(IcpDevState)));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(1024));
+    IcpDevState *h = ctx->h_sums.as<IcpDevState>();
+    std::memset(h, 0, sizeof(IcpDevState));
+    h->t_inc = to_mat34(Mat4f::identity());
+    h->final_t = s.final_t;
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState), hipMemcpyHostToDevice, ctx->stream));
+    const int iters = std::max(1, s.prm.max_iterations);
+    for (int it = 0; it < iters; ++it) {
+        int rc = launch_fused(ctx, nullptr, false, true);
+        if (rc) return rc;
+    }
+    RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_icp_state.ptr, sizeof(IcpDevState), hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(s.sums_last, h->sums_last, sizeof(s.sums_last));
+    s.ncorr = h->ncorr;
+    s.final_t = h->final_t;
+    s.iterations = h->iterations;
+    s.cur_mse = h->cur_mse;
+    s.pending_transform = h->apply != 0;
+    for (int c = 0; c < 4; ++c) { s.t_inc(0, c) = h->t_inc.r0[c]; s.t_inc(1, c) = h->t_inc.r1[c]; s.t_inc(2, c) = h->t_inc.r2[c]; }
+    if (h->stopped) {
+        s.state = RSREG_CONV_NO_CORRESPONDENCES;
+        s.converged = 0;
+    } else {
+        s.state = RSREG_CONV_ITERATIONS;
+        s.converged = 1;
+    }
+    return RSREG_OK;
 }
 
 int apply_pending_transform(rsreg_ctx *ctx)
@@ -794,7 +841,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
-                      &ctx->d_partials, &ctx->d_sums, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
+                      &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
@@ -1045,7 +1092,13 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     if (rc) return rc;
     int done = 0;
     double sums[RSREG_NUM_SUMS];
-    const bool fused = params->pipeline_mode == RSREG_PIPELINE_FUSED;
+    const bool fused = params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP;
+    if (params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
+        !(!ctx->grid.dense && use_tile_kernel())) {
+        rc = run_device_loop(ctx);
+        if (rc) return rc;
+        done = 1;
+    }
     while (!done) {
         if (fused) {
             rc = launch_fused(ctx, sums, false);

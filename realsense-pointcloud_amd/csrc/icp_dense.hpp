@@ -422,9 +422,13 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
 template <bool kDiag>
 __global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
-                                                           int *seed, unsigned long long *wave_times)
+                                                           int *seed, unsigned long long *wave_times, const IcpDevState *dev)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dev) {   // device-resident loop: the increment comes from the previous k_icp_solve
+        T = dev->t_inc;
+        apply_t = dev->apply;
+    }
     unsigned long long t_start = 0, t_search = 0;
     DDiag dg;
     if (kDiag) t_start = wall_clock64();

@@ -51,7 +51,21 @@ struct Mat34 {  // rows of the 3x4 part of a column-major Mat4f, passed by value
     float r0[4], r1[4], r2[4];
 };
 
-inline Mat34 to_mat34(const Mat4f &T)
+// State of the device-resident loop (RSREG_PIPELINE_DEVICE_LOOP): what update_from_sums keeps
+// on the host, kept in HBM so that iteration k+1 can be queued before iteration k has run.
+struct IcpDevState {
+    Mat34 t_inc;                 // increment the next pass applies to the source
+    int apply;                   // 0 until the first solve
+    int iterations;              // completed solves
+    int stopped;                 // an iteration had < 3 correspondences: frozen from there on
+    int pad;
+    Mat4f final_t;
+    double sums_last[RSREG_NUM_SUMS];
+    double cur_mse;
+    unsigned long long ncorr;
+};
+
+RSREG_HD inline Mat34 to_mat34(const Mat4f &T)
 {
     Mat34 m;
     for (int c = 0; c < 4; ++c) { m.r0[c] = T(0, c); m.r1[c] = T(1, c); m.r2[c] = T(2, c); }
@@ -782,9 +796,14 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials,
 // apply the previous increment, search, gate, accumulate.  Writes the transformed source back
 // (next iteration starts from it, like PCL's in-place transformCloud).
 __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g,
-                                                     double gate2, int *corr_pos, float *corr_d2, double *partials, int *seed)
+                                                     double gate2, int *corr_pos, float *corr_d2, double *partials, int *seed,
+                                                     const IcpDevState *dev)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dev) {   // device-resident loop: the increment comes from the previous k_icp_solve
+        T = dev->t_inc;
+        apply_t = dev->apply;
+    }
     int pos = -1;
     float d2 = 0.0f;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -813,6 +832,27 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
         accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
+}
+
+// One thread: Umeyama from the 17 sums, compose, count -- update_from_sums with fixed-count criteria
+__global__ void k_icp_solve(const double *sums, IcpDevState *st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || st->stopped) return;
+    double s[RSREG_NUM_SUMS];
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) st->sums_last[k] = s[k] = sums[k];
+    st->ncorr = (unsigned long long)(s[0] + 0.5);
+    if (st->ncorr < 3) {
+        st->stopped = 1;
+        st->apply = 0;
+        return;
+    }
+    Mat4f t;
+    umeyama_from_sums(s, t);
+    st->t_inc = to_mat34(t);
+    st->apply = 1;
+    st->final_t = mul(t, st->final_t);
+    st->iterations++;
+    st->cur_mse = s[16] / s[0];
 }
 
 // corr (sorted source order, position in the sorted target) -> caller's order and indices

@@ -135,6 +135,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_seed;         // int32: nearest target found in the previous iteration (-1 none)
     rsreg::DevBuf d_partials;     // double[blocks][17]
     rsreg::DevBuf d_sums;         // double[17]
+    rsreg::DevBuf d_icp_state;    // IcpDevState of the device-resident loop
     rsreg::PinnedBuf h_sums;      // pinned double[64]
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     rsreg::IcpState icp;

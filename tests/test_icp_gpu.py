@@ -63,7 +63,7 @@ def test_kat_recovers_known_transform(api, rs, golden):
     np.testing.assert_array_equal(out.points["rgba"], g["src"]["rgba"])
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_golden_fixed_iterations_and_pcl_criteria(api, rs, golden, pipeline):
     g = golden("crop_parity")
     icp = api.IterativeClosestPoint()
@@ -133,7 +133,7 @@ def test_vs_oracle_reference_params(api, orc, frames, size):
     assert gi.n_target_points == len(tgt) and gi.n_unique_points < gi.n_target_points  # (0,0,0) pixels collapse
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_vs_oracle_bench_mode_30_iterations(api, orc, frames, rs, pipeline):
     """BASELINE configs[1] shape: 2 x 300k, 30 fixed iterations, 5 cm gate."""
     src, tgt = frames[("N300", "bench")]
@@ -159,33 +159,62 @@ def test_vs_oracle_bench_mode_30_iterations(api, orc, frames, rs, pipeline):
     assert np.linalg.norm(icp.getFinalTransformation() - gt) < np.linalg.norm(guess - gt)
 
 
-def test_fused_and_staged_pipelines_are_bit_identical(api, frames):
+def test_pipelines_are_bit_identical(api, frames):
+    """Staged kernels, the fused kernel, and the device-resident loop (3x3 solve on the GPU) add
+    the same numbers in the same order and run the same f64 solve: identical bits."""
     src, tgt = frames[("50k", "parity")]
+    for gate, iters in ((0.02, 6), (0.01, 4)):
+        out = []
+        for pipeline in (0, 1, 2):
+            icp = api.IterativeClosestPoint()
+            icp.params = api.icp_params(max_iterations=iters, criteria_mode=1, pipeline_mode=pipeline,
+                                        max_correspondence_distance=gate)
+            icp.setInputSource(src)
+            icp.setInputTarget(tgt)
+            icp.align()
+            r = icp.result
+            out.append((bytes(r.transform), bytes(r.sums_last), r.n_correspondences, r.iterations, r.state, r.converged, r.mse))
+        assert out[0] == out[1] == out[2], gate
+
+
+def test_device_loop_edge_cases(api, rs, frames):
+    src, tgt = frames[("50k", "parity")]
+    # (a) clouds too far apart: no correspondences in the first iteration -> same outcome as the host loop
+    far = rs.synth.small_transform(0.0, (5.0, 0.0, 0.0)).astype(np.float32)
     out = []
-    for pipeline in (0, 1):
+    for pipeline in (1, 2):
         icp = api.IterativeClosestPoint()
-        icp.params = api.icp_params(max_iterations=6, criteria_mode=1, pipeline_mode=pipeline,
-                                    max_correspondence_distance=0.02)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=0.01)
         icp.setInputSource(src)
         icp.setInputTarget(tgt)
-        icp.align()
-        out.append((np.array(icp.result.transform), np.array(icp.result.sums_last), icp.result.n_correspondences))
-    # same pairs, same arithmetic; only the grouping of the f64 partial sums may differ
-    # (gate wider than a cell: the fused pipeline keeps near and far pairs in separate slabs)
-    np.testing.assert_allclose(out[0][0], out[1][0], atol=1e-7)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12)
-    assert out[0][2] == out[1][2]
-    # with the reference's gate (one ring) the two pipelines are bit-identical
-    out = []
-    for pipeline in (0, 1):
-        icp = api.IterativeClosestPoint()
-        icp.params = api.icp_params(max_iterations=4, criteria_mode=1, pipeline_mode=pipeline,
-                                    max_correspondence_distance=0.01)
-        icp.setInputSource(src)
-        icp.setInputTarget(tgt)
-        icp.align()
-        out.append((bytes(icp.result.transform), bytes(icp.result.sums_last)))
+        icp.align(far)
+        r = icp.result
+        out.append((bytes(r.transform), r.iterations, r.state, r.converged, r.n_correspondences))
     assert out[0] == out[1]
+    assert out[0][1:4] == (0, 5, 0)          # RSREG_CONV_NO_CORRESPONDENCES, not converged
+    # (b) with PCL's criteria the mode falls back to the host loop (the stop decision is the host's)
+    out = []
+    for pipeline in (1, 2):
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(reference=True)
+        icp.params.pipeline_mode = pipeline
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        icp.align()
+        r = icp.result
+        out.append((bytes(r.transform), r.iterations, r.state, r.converged))
+    assert out[0] == out[1] and out[0][1] == 1
+    # (c) the aligned cloud and max_iterations = 1
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=1, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=0.01)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    aligned = icp.align()
+    T = icp.getFinalTransformation().astype(np.float64)
+    xyz = np.stack([src.points["x"], src.points["y"], src.points["z"]], 1).astype(np.float64)
+    want = xyz @ T[:3, :3].T + T[:3, 3]
+    got = np.stack([aligned.points["x"], aligned.points["y"], aligned.points["z"]], 1)
+    np.testing.assert_allclose(got, want, atol=1e-5)
 
 
 def test_run_to_run_determinism(api, frames):

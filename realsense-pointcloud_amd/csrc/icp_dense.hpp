@@ -314,54 +314,64 @@ __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
     return g.max_ring >= 2 && limit2 > reach * reach;
 }
 
-// Rings >= 2: row by row (the cells of one (y, z) row are one contiguous run of points), nearest
-// ring first, until everything unvisited is provably farther than the best.  Inside a row only
-// the x-extent the remaining budget allows is read.
+// Everything beyond rings 0-1, row by row: the cells of one (y, z) row are one contiguous run of
+// points, so a row costs two table loads whatever its x-extent.  Rows are taken by their
+// Chebyshev distance rho from the query's row, nearest first, each ONCE: of a row only the
+// x-extent the remaining budget (limit - gap_yz) reaches is read, and the search stops as soon
+// as every unvisited row is provably farther than the best.  The nine central rows
+// (rho <= 1) have had their cells cx-1..cx+1 searched already: only their two outer parts remain.
+template <bool kDiag = false>
+__device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs, const DQuery &q, int dy, int dz, bool central,
+                                              float inv_cell2, f32x2 qxy, DBest &b, float &limit2, DDiag *dg)
+{
+    const int y = q.cy + dy, z = q.cz + dz;
+    if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
+    const float ay = axis_gap(q.uy, y, y), az = axis_gap(q.uz, z, z);
+    const float rem = limit2 * inv_cell2 - (ay * ay + az * az);   // budget left for the x gap, squared cells
+    if (rem < 0.0f) return;
+    if (kDiag) ++dg->far_rows;
+    const int row = (int)dense_cell_id(g, 0, y, z);
+    // cells cx-kl .. cx+kr are the ones whose x gap fits the budget (gap = fx + k - 1 to the left, k - fx to the right)
+    const float sr = sqrtf(rem) + kCellMargin + 1e-4f, fx = q.ux - (float)q.cx;
+    const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), (float)g.max_ring), kr = (int)fminf(fmaxf(sr + fx, 0.0f), (float)g.max_ring);
+    const int xa = max(q.cx - kl, 0), xb = min(q.cx + kr, g.nx - 1);
+    if (!central) {
+        const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
+        const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
+        if (kDiag) dg->far_scans += (e - s + 3) / 4;
+        dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, q.qz);
+    } else {
+        // [xa, cx-2] and [cx+2, xb]; an empty part reads the same table entry twice
+        const int l1 = min(q.cx - 1, xb + 1), r0 = max(q.cx + 2, xa);
+        const uint32_t s0 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + min(xa, l1)) * 4u, 0, 0);
+        const uint32_t e0 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + l1) * 4u, 0, 0);
+        const uint32_t s1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + min(r0, xb + 1)) * 4u, 0, 0);
+        const uint32_t e1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
+        if (kDiag) dg->far_scans += (e0 - s0 + 3) / 4 + (e1 - s1 + 3) / 4;
+        dscan_range(b, rs.pts, s0 * 16u, e0 * 16u, qxy, q.qz);
+        dscan_range(b, rs.pts, s1 * 16u, e1 * 16u, qxy, q.qz);
+    }
+    limit2 = fminf(limit2, b.d);
+}
+
 template <bool kDiag = false>
 __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
                                           DDiag *dg = nullptr)
 {
     const f32x2 qxy = {q.qx, q.qy};
-    const float qz = q.qz;
-    const float cell2 = g.cell * g.cell, inv_cell2 = 1.0f / cell2;
-    for (int r = 2; r <= g.max_ring; ++r) {
-        const float reach = ((float)(r - 1) - kCellMargin) * g.cell;   // all of ring r-1 is done
-        if (limit2 <= reach * reach) break;
-        for (int dz = -r; dz <= r; ++dz) {
-            const int z = q.cz + dz;
-            if (z < 0 || z >= g.nz) continue;
-            const float az = axis_gap(q.uz, z, z), gz = az * az;
-            if (gz * cell2 > limit2) continue;
-            for (int dy = -r; dy <= r; ++dy) {
-                const int y = q.cy + dy;
-                if (y < 0 || y >= g.ny) continue;
-                const float ay = axis_gap(q.uy, y, y), gyz = ay * ay + gz;
-                const float rem = limit2 * inv_cell2 - gyz;   // budget left for the x gap, squared cells
-                if (rem < 0.0f) continue;
-                const int row = (int)dense_cell_id(g, 0, y, z);
-                        if (kDiag) ++dg->far_rows;
-                const bool face = (abs(dz) == r) || (abs(dy) == r);
-                if (face) {   // cells cx-r .. cx+r of this row, clipped to what the budget reaches
-                    const int reach_x = (int)fminf(sqrtf(rem) + 1.0f + kCellMargin, (float)r);   // generous by one cell
-                    const int xa = max(q.cx - reach_x, 0), xb = min(q.cx + reach_x, g.nx - 1);
-                    const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
-                    const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
-                    if (kDiag) dg->far_scans += (e - s + 3) / 4;
-                    dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, qz);
-                    limit2 = fminf(limit2, b.d);
-                } else {      // only the two end cells belong to ring r
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int x = s ? q.cx + r : q.cx - r;
-                        if (x < 0 || x >= g.nx) continue;
-                        const float ax = axis_gap(q.ux, x, x);
-                        if (ax * ax > rem) continue;
-                        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)(row + x) * 4u, 0, 0);
-                        if (kDiag) dg->far_scans += (se.y - se.x + 3) / 4;
-                        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qxy, qz);
-                        limit2 = fminf(limit2, b.d);
-                    }
-                }
+    const float inv_cell2 = 1.0f / (g.cell * g.cell);
+    for (int rho = 0; rho <= g.max_ring; ++rho) {
+        if (rho >= 2) {   // a row at distance rho is at least rho - 1 cells away on one axis
+            const float reach = ((float)(rho - 1) - kCellMargin) * g.cell;
+            if (limit2 <= reach * reach) break;
+        }
+        const bool central = rho <= 1;
+        for (int dz = -rho; dz <= rho; ++dz) {
+            if (dz == -rho || dz == rho) {
+                for (int dy = -rho; dy <= rho; ++dy) dense_far_row<kDiag>(g, rs, q, dy, dz, central, inv_cell2, qxy, b, limit2, dg);
+            } else {
+                dense_far_row<kDiag>(g, rs, q, -rho, dz, central, inv_cell2, qxy, b, limit2, dg);
+                dense_far_row<kDiag>(g, rs, q, rho, dz, central, inv_cell2, qxy, b, limit2, dg);
             }
         }
     }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["icp.hip", "ndt.hip", "comm.cpp", "voxel_host.cpp"]
-HEADERS = ["icp_kernels.hpp", "rsreg_ctx.hpp", "host_linalg.hpp", "ndt_kernels.hpp"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
 UNIQUE_ID_BYTES = 128
 

@@ -47,4 +47,15 @@ for k, nm in enumerate(names):
 far = (w[:, 2] - w[:, 1]) > 20   # > 0.2 us spent in far rings
 print("waves entering far rings: %.1f %%" % (100.0 * far.mean()))
 start = (w[:, 0] - t0) / 100.0
+end = (w[:, 4] - t0) / 100.0
+print("slowest 1 %% of waves: start p10 %.1f p50 %.1f p90 %.1f us, end p50 %.1f max %.1f us; their share of all wave time %.1f %%"
+      % (np.percentile(start[heavy], 10), np.percentile(start[heavy], 50), np.percentile(start[heavy], 90),
+         np.percentile(end[heavy], 50), end[heavy].max(), 100.0 * dur[heavy].sum() / dur.sum()))
+for lo, hi in ((0, 25), (25, 50), (50, 100), (100, 150), (150, 1e9)):
+    sel = (end >= lo) & (end < hi)
+    print("waves ending in [%g, %g) us: %5d" % (lo, hi, sel.sum()))
+busy = np.zeros(int(end.max()) + 2)
+for a, b in zip(start.astype(int), end.astype(int)):
+    busy[a:b + 1] += 1
+print("resident waves at t = 10/50/100/125/150/175 us:", [int(busy[min(t, len(busy) - 1)]) for t in (10, 50, 100, 125, 150, 175)])
 print("wave start times: p50 %.1f us p90 %.1f us max %.1f us" % (np.percentile(start, 50), np.percentile(start, 90), start.max()))

@@ -89,8 +89,6 @@ GridDev grid_dev(const rsreg_ctx *ctx, double max_dist)
         if ((double)f < gate2) f = std::nextafter(f, INFINITY);
         g.prune2 = f;
     }
-    static const int dbg = std::getenv("RSREG_DEBUG") ? std::atoi(std::getenv("RSREG_DEBUG")) : 0;
-    g.dbg = dbg;
     g.bricks = ctx->d_table.as<BrickEntry>();
     g.cellpos = ctx->d_cellpos.as<uint32_t>();
     g.pts = ctx->d_tgt_sorted.as<float4>();

@@ -41,7 +41,6 @@ struct GridDev {
     int max_ring;            // rings (in cells) that cover the correspondence gate
     float prune2;            // squared search radius as float, rounded up (+inf: unbounded)
     int halo;                // rings of cells the LDS tile stages around its queries (1..3)
-    int dbg;                 // timing experiments only (RSREG_DEBUG), 0 in production
     const BrickEntry *bricks;
     const uint32_t *cellpos;
     const float4 *pts;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
         staged = n_pts <= kTilePts;
         __syncthreads();
     }
-    if (staged && !(g.dbg & 8)) {
+    if (staged) {
         // ---- G. stage the points with a flat, balanced copy.  own[p] = staged cell of staged
         // point p: heads are scattered at each cell's first offset, a running maximum fills
         // the rest (cell ids grow with the offset).
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
             consider(b, l2_simple(q.x, q.y, q.z, t.x, t.y, t.z), __float_as_uint(t.w), (uint32_t)seed_pos);
             limit2 = fminf(limit2, b.d2);
         }
-        if (staged && !(g.dbg & 4)) {
+        if (staged) {
             const float cell2 = g.cell * g.cell;
             // ring 0 (own cell: it usually holds the nearest point), then rings 1..H, stopping
             // as soon as everything unvisited is provably farther than the best so far
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
                 if (limit2 <= reach * reach) break;
             }
             inner = H;
-        } else if (!staged && !(g.dbg & 2)) {
+        } else {
             nn_near_global(g, qg, q.x, q.y, q.z, b, limit2);
         }
-        if (!(g.dbg & 1)) nn_far_global(g, qg, q.x, q.y, q.z, b, limit2, inner);
+        nn_far_global(g, qg, q.x, q.y, q.z, b, limit2, inner);
         if (seed) seed[i] = b.pos;
     }
 

@@ -37,9 +37,10 @@ def parse():
     ap.add_argument("--size", default="N1M", choices=["50k", "N300", "N1M"])
     ap.add_argument("--iterations", type=int, default=30)
     ap.add_argument("--max-dist", type=float, default=0.05)
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="0 staged kernels, 1 fused kernel + host 3x3 solve per iteration, 2 fused kernel + device-resident loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
     return ap.parse_args()
 
@@ -81,7 +82,7 @@ def main():
     n_src = hi - lo
     stride = tgt.points.dtype.itemsize
 
-    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=True)
+    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=not a.no_events)
     transport = "none"
     if world > 1:
         # native transport: RCCL all-reduce of the 17 sums on the ctx stream inside rsreg_icp_align.

@@ -127,7 +127,8 @@ typedef struct rsreg_icp_result {
     /* device-time breakdown of this call (ms, HIP events on the ctx stream); 0 if profiling off */
     double ms_total;
     double ms_nn;               /* dominant kernel: NN search (or the fused kernel)         */
-    double ms_reduce;
+    double ms_reduce;           /* staged: the sums kernels; fused: all time between consecutive search
+                                   kernels (final reduce + host round trip or device solve)            */
     double ms_transform;
     int32_t n_nn_launches;
     int32_t reserved1;

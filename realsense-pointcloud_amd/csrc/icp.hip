@@ -676,18 +676,23 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
         s.n_nn_launches++;
     }
     s.pending_transform = false;
-    {
-        ScopedEvents ev(ctx, &ctx->ev_reduce);
-        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
-        RSREG_HIP(ctx, hipGetLastError());
-    }
+    // (no events of their own for what follows: in the fused pipelines ms_reduce is the time
+    // between consecutive search kernels, read off the search kernels' events)
     s.have_search = want_corr;
+    if (device_loop && ctx->nranks == 1) {   // final reduce + solve in one launch
+        auto *st = ctx->d_icp_state.as<IcpDevState>();
+        k_final_reduce_solve<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>(),
+                                                                          st, reinterpret_cast<unsigned int *>(st + 1));
+        RSREG_HIP(ctx, hipGetLastError());
+        return RSREG_OK;
+    }
+    k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
+    RSREG_HIP(ctx, hipGetLastError());
     if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass
         if (ctx->nranks > 1) {
             int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
             if (rc) return rc;
         }
-        ScopedEvents ev(ctx, &ctx->ev_reduce);
         k_icp_solve<<<1, 64, 0, ctx->stream>>>(ctx->d_sums.as<double>(), ctx->d_icp_state.as<IcpDevState>());
         RSREG_HIP(ctx, hipGetLastError());
         return RSREG_OK;
@@ -700,13 +705,13 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
 int run_device_loop(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
-    RSREG_HIP(ctx, ctx->d_icp_state.reserve(sizeof(IcpDevState)));
+    RSREG_HIP(ctx, ctx->d_icp_state.reserve(sizeof(IcpDevState) + 16));   // + the reduce kernel's ticket
     RSREG_HIP(ctx, ctx->h_sums.reserve(1024));
     IcpDevState *h = ctx->h_sums.as<IcpDevState>();
-    std::memset(h, 0, sizeof(IcpDevState));
+    std::memset(h, 0, sizeof(IcpDevState) + 16);
     h->t_inc = to_mat34(Mat4f::identity());
     h->final_t = s.final_t;
-    RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState), hipMemcpyHostToDevice, ctx->stream));
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState) + 16, hipMemcpyHostToDevice, ctx->stream));
     const int iters = std::max(1, s.prm.max_iterations);
     for (int it = 0; it < iters; ++it) {
         int rc = launch_fused(ctx, nullptr, false, true);
@@ -1075,6 +1080,12 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         if (ctx->profiling) {
             result->ms_nn = sum_events(ctx, ctx->ev_nn);
             result->ms_reduce = sum_events(ctx, ctx->ev_reduce);
+            if (ctx->ev_reduce.empty())   // fused pipelines: everything between two consecutive search kernels
+                for (size_t k = 0; k + 1 < ctx->ev_nn.size(); ++k) {
+                    float t = 0;
+                    if (hipEventElapsedTime(&t, ctx->ev_pool[ctx->ev_nn[k].second], ctx->ev_pool[ctx->ev_nn[k + 1].first]) == hipSuccess)
+                        result->ms_reduce += t;
+                }
             result->ms_transform = sum_events(ctx, ctx->ev_transform);
             result->ms_total = result->ms_nn + result->ms_reduce + result->ms_transform;
         }

@@ -833,10 +833,10 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
     tile_reduce_store(a, partials, gridDim.x);
 }
 
-// One thread: Umeyama from the 17 sums, compose, count -- update_from_sums with fixed-count criteria
-__global__ void k_icp_solve(const double *sums, IcpDevState *st)
+// Umeyama from the 17 sums, compose, count -- update_from_sums with fixed-count criteria (one thread)
+__device__ __forceinline__ void icp_solve_step(const double *sums, IcpDevState *st)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || st->stopped) return;
+    if (st->stopped) return;
     double s[RSREG_NUM_SUMS];
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) st->sums_last[k] = s[k] = sums[k];
     st->ncorr = (unsigned long long)(s[0] + 0.5);
@@ -852,6 +852,39 @@ __global__ void k_icp_solve(const double *sums, IcpDevState *st)
     st->final_t = mul(t, st->final_t);
     st->iterations++;
     st->cur_mse = s[16] / s[0];
+}
+
+__global__ void k_icp_solve(const double *sums, IcpDevState *st)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) icp_solve_step(sums, st);
+}
+
+// k_final_reduce and k_icp_solve in one launch (single-GPU device loop): the block that finishes
+// last has all 17 sums in front of it and runs the solve; `ticket` returns to 0 for the next launch
+__global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *partials, uint32_t nblocks, double *sums,
+                                                               IcpDevState *st, unsigned int *ticket)
+{
+    __shared__ double shf[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *src = partials + (size_t)blockIdx.x * nblocks;
+    double v = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) v += src[b];
+    v = wave_sum(v);
+    if (lane == 0) shf[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = shf[0];
+        for (int w = 1; w < kBlock / 64; ++w) t += shf[w];
+        __hip_atomic_store(&sums[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            double all[RSREG_NUM_SUMS];
+            for (int k = 0; k < RSREG_NUM_SUMS; ++k) all[k] = __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *ticket = 0;
+            icp_solve_step(all, st);
+        }
+    }
 }
 
 // corr (sorted source order, position in the sorted target) -> caller's order and indices

@@ -495,13 +495,17 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
         const uint32_t nb = div_up((uint32_t)n, kBlock);
-        k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, keys, vals);
+        // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
+        int axis_bits = 1;
+        while (axis_bits < 16 && (double)(1u << axis_bits) <= extent / (double)cell + 2.0) ++axis_bits;
+        const unsigned sort_bits = 3u * (unsigned)axis_bits + 1u;
+        k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), keys, vals);
         RSREG_HIP(ctx, hipGetLastError());
         size_t sort_bytes = 0, scan_bytes = 0;
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, 64, st));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr);
         RSREG_HIP(ctx, hipGetLastError());
         k_source_flag<<<nb, kBlock, 0, st>>>(keys2, ctx->d_src_all.as<float4>(), (uint32_t)n, keep);

@@ -355,13 +355,14 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long v)
 // Spatial sort key of a source point: Morton (Z-order) code of its cell in the source's own
 // grid, so that any run of consecutive points is a compact patch in all three dimensions.
 __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t stride, uint32_t n, float ox, float oy,
-                                                        float oz, float inv_cell, unsigned long long *keys, uint32_t *vals)
+                                                        float oz, float inv_cell, unsigned long long invalid_key,
+                                                        unsigned long long *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = rec_xyz(raw, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    unsigned long long key = kEmptyKey;
+    unsigned long long key = invalid_key;   // one bit above every Morton code: non-finite points sort last
     if (finite3(x, y, z))
         key = spread3((unsigned)cell_coord(x, ox, inv_cell)) | spread3((unsigned)cell_coord(y, oy, inv_cell)) << 1 |
               spread3((unsigned)cell_coord(z, oz, inv_cell)) << 2;

@@ -259,6 +259,18 @@ def main():
             lib.check(L.rsreg_icp_align(ctx.h, g.ctypes.data, C.byref(prm2), C.byref(res2), None, 0), ctx.h)
             out["transform_error_vs_cpu_frobenius"] = float(np.linalg.norm(api._rowmajor(res2.transform) - r.T))
         out["speedup_vs_cpu_port"] = value / cpu_value
+        # the same sample with the queries of an iteration spread over the host's cores (OpenMP over queries;
+        # the tree build stays serial, as in FLANN) -- what a multi-threaded PCL-like port would reach
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        if threads > 1:
+            p.num_threads = threads
+            tc = time.perf_counter()
+            o.set_target(tgt.points, dedup=True)
+            o.set_source(src.points)
+            o.align(guess, p)
+            omp_s = time.perf_counter() - tc
+            out["cpu_baseline_all_cores"] = {"value": float(n_src_total) * a.cpu_iterations / omp_s, "unit": "point-pairs/s",
+                                             "cores": threads, "kind": "port", "seconds": omp_s}
     if world == 1:
         # PCIe-inclusive rate (never `value`): the same pair handed over as HOST buffers, as the
         # reference's call surface does (clouds in host memory in, 4x4 out)

@@ -14,6 +14,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -23,7 +24,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0]
+        k = re.sub(r"<.*>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()
         if k.startswith("rsreg::"):
             agg[k[len("rsreg::"):]].append(float(r["Counter_Value"]))
     return agg

@@ -3,13 +3,14 @@
 import collections
 import csv
 import glob
+import re
 import sys
 
 path = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
 want = sys.argv[2] if len(sys.argv) > 2 else "rsreg"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(path)):
-    k = r["Kernel_Name"].split("(")[0]
+    k = re.sub(r"<.*>", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").strip()
     if want in k:
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--max-dist", type=float, default=0.05)
     ap.add_argument("--pipeline", type=int, default=2,
                     help="0 staged kernels, 1 fused kernel + host 3x3 solve per iteration, 2 fused kernel + device-resident loop")
+    ap.add_argument("--shard-block", type=int, default=256, help="N > 1: source points per block, blocks dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
@@ -75,11 +76,12 @@ def main():
     src = synth.render_frame(1, a.size, "bench")
     guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
     n_src_total, n_tgt = len(src), len(tgt)
-    lo = (n_src_total * rank) // world
-    hi = (n_src_total * (rank + 1)) // world
+    from rsreg_amd import sharded
+
+    mine = sharded.shard_blocks(n_src_total, rank, world, a.shard_block)   # all points when world == 1
     d_tgt = torch.from_numpy(tgt.points.view(np.uint8).reshape(-1)).cuda()
-    d_src = torch.from_numpy(np.ascontiguousarray(src.points[lo:hi]).view(np.uint8).reshape(-1)).cuda()
-    n_src = hi - lo
+    d_src = torch.from_numpy(np.ascontiguousarray(src.points[mine]).view(np.uint8).reshape(-1)).cuda()
+    n_src = len(mine)
     stride = tgt.points.dtype.itemsize
 
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=not a.no_events)
@@ -114,8 +116,6 @@ def main():
     gi = lib.GridInfo()
 
     if transport == "torch-distributed":
-        from rsreg_amd import sharded
-
         stepper = api.IterativeClosestPoint(ctx)
         stepper.params = prm
         stepper._quiet_search = True
@@ -212,7 +212,8 @@ def main():
             "n_src": n_src_total, "n_tgt": n_tgt, "iterations": a.iterations, "max_corr_dist": a.max_dist,
             "criteria": "fixed",
             "pipeline": ["staged", "fused, 3x3 solve on the host each iteration", "fused, device-resident loop (3x3 solve on the GPU)"][a.pipeline],
-            "sharding": "source blocks x%d, all-reduce of 17 f64 per iteration (%s)" % (world, transport) if world > 1 else "none",
+            "sharding": "source blocks of %d points dealt round-robin to %d ranks, all-reduce of 17 f64 per iteration (%s)"
+                        % (a.shard_block, world, transport) if world > 1 else "none",
             "step": "grid build + source load + %d iterations, inputs resident in HBM" % a.iterations,
         },
         "roofline": {

@@ -1,4 +1,4 @@
-"""One cloud pair registered by N ranks: the source is cut into N contiguous blocks, the target
+"""One cloud pair registered by N ranks: the source is cut into blocks dealt to the ranks, the target
 (and its index) is replicated, and the only exchange per iteration is the sum of the 17
 per-block sums (BASELINE configs[3]).  Every rank then runs the same host
 Umeyama/SVD on identical numbers, so all ranks hold the same transform without a broadcast.
@@ -17,6 +17,18 @@ def shard_range(n, rank, world):
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
     return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def shard_blocks(n, rank, world, block=256):
+    """Indices of rank `rank` when n items are cut into blocks of `block` consecutive items and
+    the blocks are dealt round-robin.  Same exchange as `shard_range` (the sums do not care which
+    points a rank holds), but every rank gets an even sample of the scene: the slow waves of a
+    launch (queries on near, densely sampled surfaces) are spread over all ranks instead of
+    landing on the one that owns that part of the image."""
+    if world < 1 or not (0 <= rank < world) or block < 1:
+        raise ValueError("bad rank/world/block")
+    idx = np.arange(n, dtype=np.int64)
+    return idx[(idx // block) % world == rank]
 
 
 def run_sharded_icp(stepper, allreduce, guess=None, max_steps=100000):

@@ -98,6 +98,22 @@ def test_shard_range_partitions_exactly(rs):
         sharded.shard_range(10, 2, 2)
 
 
+def test_shard_blocks_partition_exactly(rs):
+    from rsreg_amd import sharded
+    for n in (0, 1, 7, 1000, 307200, 1000000):
+        for world in (1, 2, 3, 8):
+            for block in (1, 64, 256):
+                parts = [sharded.shard_blocks(n, r, world, block) for r in range(world)]
+                allidx = np.sort(np.concatenate(parts)) if n else np.zeros(0, np.int64)
+                assert np.array_equal(allidx, np.arange(n))
+                if n >= world * block * 8:
+                    sizes = [len(p) for p in parts]
+                    assert max(sizes) - min(sizes) <= block
+    assert np.array_equal(sharded.shard_blocks(10, 0, 1), np.arange(10))
+    with pytest.raises(ValueError):
+        sharded.shard_blocks(10, 2, 2)
+
+
 def test_two_rank_icp_over_gloo_matches_single_process(tmp_path, orc, rs):
     import torch.multiprocessing as mp
     from rsreg_amd import lib

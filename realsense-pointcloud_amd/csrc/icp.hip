@@ -622,7 +622,7 @@ extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int c
 
 int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
-    if (global && ctx->nranks > 1) {
+    if (global && ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
         int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
         if (rc) return rc;
     }
@@ -683,7 +683,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     // (no events of their own for what follows: in the fused pipelines ms_reduce is the time
     // between consecutive search kernels, read off the search kernels' events)
     s.have_search = want_corr;
-    if (device_loop && ctx->nranks == 1) {   // final reduce + solve in one launch
+    if (device_loop && !ctx->comm) {   // final reduce + solve in one launch
         auto *st = ctx->d_icp_state.as<IcpDevState>();
         k_final_reduce_solve<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>(),
                                                                           st, reinterpret_cast<unsigned int *>(st + 1));
@@ -693,7 +693,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
     if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass
-        if (ctx->nranks > 1) {
+        if (ctx->comm) {
             int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
             if (rc) return rc;
         }

@@ -89,4 +89,12 @@ def test_native_rccl_transport_single_rank(rs):
     b.setInputTarget(tgt)
     b.align()
     np.testing.assert_array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    # the device-resident loop with the all-reduce between its reduce and solve kernels
+    out = []
+    for icp in (a, b):
+        for pipeline in (1, 2):
+            icp.params = api.icp_params(max_iterations=5, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=0.01)
+            icp.align()
+            out.append((bytes(icp.result.transform), bytes(icp.result.sums_last), icp.result.iterations, icp.result.state))
+    assert out[0] == out[1] == out[2] == out[3]
     assert lib.lib().rsreg_comm_destroy(ctx.h) == 0

@@ -55,3 +55,25 @@ def test_pcd_fixture_formats(tmp_path, rs):
                        "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA ascii\n0.93773 0.33333 0 4281353262\n0.90805 0.32222 0 4281353262\n")
     back = rs.load_pcd(u)
     assert len(back) == 2 and (back.points["rgba"] == 4281353262).all() and abs(back.points["x"][1] - 0.90805) < 1e-7
+
+
+def test_reference_example_pcd_files(rs):
+    """The two ASCII .pcd files the reference ships (examples/visualizer/example.pcd and
+    exampleTemp.pcd, copied as data fixtures): `rgb` stored as a float value (TYPE F) and as an
+    unsigned integer (TYPE U).  Checked against a plain text parse of the same files."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, n, rgb_type in (("pcd_example_rgb_f.pcd", 213, "F"), ("pcd_example_rgb_u.pcd", 10, "U")):
+        path = os.path.join(here, name)
+        c = rs.load_pcd(path)
+        lines = open(path).read().split("\n")
+        data = [l.split() for l in lines[lines.index("DATA ascii") + 1:] if l.strip()]
+        assert len(c) == len(data) == n and (c.width, c.height) == (n, 1)
+        xyz = np.array([[float(v) for v in r[:3]] for r in data], np.float32)
+        for k, f in enumerate("xyz"):
+            np.testing.assert_array_equal(c.points[f], xyz[:, k])
+        if rgb_type == "F":   # PCL keeps the float's bit pattern in the rgb/rgba union
+            want = np.array([float(r[3]) for r in data], np.float32).view(np.uint32)
+        else:
+            want = np.array([int(r[3]) for r in data], np.uint32)
+        np.testing.assert_array_equal(c.points["rgba"], want)

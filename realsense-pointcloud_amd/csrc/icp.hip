@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "icp_kernels.hpp"
 #include "icp_tile_kernel.hpp"
@@ -115,17 +117,36 @@ double cell_cap_from_env()
     return 0.0115;  // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
+// Host-side record loops (32-byte AoS records <-> packed xyz in pinned staging) are memory-bound
+// copies of tens of MB: split them over a few threads.  f(lo, hi) handles records [lo, hi).
+template <typename F> void host_parallel_for(size_t n, F f)
+{
+    static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::min<size_t>(hw, n / 65536 + 1);
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+    f((size_t)0, n / nt);
+    for (auto &t : th) t.join();
+}
+
 int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
 {
     hipError_t e = ctx->h_stage.reserve(n * 12 + 16);
     if (e != hipSuccess) return fail(ctx, RSREG_ERR_ALLOC, "pinned staging", e);
     float *dst = ctx->h_stage.as<float>();
     const char *src = static_cast<const char *>(points);
-    if (stride == 12) {
-        std::memcpy(dst, src, n * 12);
-    } else {
-        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
-    }
+    host_parallel_for(n, [=](size_t lo, size_t hi) {
+        if (stride == 12) {
+            std::memcpy(dst + 3 * lo, src + 12 * lo, (hi - lo) * 12);
+        } else {
+            for (size_t i = lo; i < hi; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+        }
+    });
     return RSREG_OK;
 }
 
@@ -1065,11 +1086,13 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     if (aligned_out && n) {
         const float *src = ctx->h_stage.as<float>();
         char *dst = static_cast<char *>(aligned_out);
-        const float one = 1.0f;
-        for (size_t i = 0; i < n; ++i) {
-            std::memcpy(dst + i * out_stride, src + 3 * i, 12);
-            if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
-        }
+        host_parallel_for(n, [=](size_t lo, size_t hi) {
+            const float one = 1.0f;
+            for (size_t i = lo; i < hi; ++i) {
+                std::memcpy(dst + i * out_stride, src + 3 * i, 12);
+                if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
+            }
+        });
     }
     if (result) {
         std::memset(result, 0, sizeof(*result));
@@ -1177,10 +1200,12 @@ int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, s
     const char *src = static_cast<const char *>(in);
     char *dst = static_cast<char *>(out);
     const float *xyz = ctx->h_stage.as<float>();
-    for (size_t i = 0; i < n; ++i) {
-        if (dst != src) std::memmove(dst + i * stride, src + i * stride, stride);
-        std::memcpy(dst + i * stride, xyz + 3 * i, 12);
-    }
+    host_parallel_for(n, [=](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            if (dst != src) std::memmove(dst + i * stride, src + i * stride, stride);
+            std::memcpy(dst + i * stride, xyz + 3 * i, 12);
+        }
+    });
     return RSREG_OK;
 }
 

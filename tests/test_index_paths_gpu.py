@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 def test_parity_suite_on_alternative_index_paths(env):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_icp_gpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_icp_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_nn_fuzz_gpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -1,0 +1,94 @@
+"""GPU: randomized exactness test of the correspondence search.  Many small random scenes --
+clustered, planar, lattice (many exact distance ties), duplicated points, queries far outside
+the target's box, gates from a fraction of a cell to unbounded -- each checked against a float32
+brute force that follows FLANN's L2_Simple order ((dx^2 + dy^2) + dz^2) with the canonical
+tie-break (lowest target index), and PCL's gate (reject iff d^2 > max_dist^2 in double).
+Two search rounds per scene: the second starts from the seeds the first one left."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(rs):
+    from rsreg_amd import api as a, lib
+    lib.build()
+    if a.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return a
+
+
+def brute(src, tgt, gate):
+    s = src.astype(np.float32)
+    t = tgt.astype(np.float32)
+    idx = np.full(len(s), -1, np.int64)
+    d2o = np.zeros(len(s), np.float32)
+    ok_t = np.isfinite(t).all(1)
+    ti = np.nonzero(ok_t)[0]
+    tt = t[ok_t]
+    gate2 = float(gate) * float(gate)
+    for i in range(len(s)):
+        if not np.isfinite(s[i]).all() or len(tt) == 0:
+            continue
+        d = s[i] - tt
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # float32, FLANN's order
+        j = int(np.argmin(d2))                                             # first minimum = lowest index
+        if not (float(d2[j]) > gate2):
+            idx[i] = ti[j]
+            d2o[i] = d2[j]
+    return idx, d2o
+
+
+def scene(rng, kind, n):
+    if kind == "uniform":
+        return rng.uniform(-0.3, 0.3, (n, 3))
+    if kind == "plane":
+        p = rng.uniform(-0.4, 0.4, (n, 3))
+        p[:, 2] = 1.0 + 0.002 * rng.standard_normal(n)
+        return p
+    if kind == "clusters":
+        c = rng.uniform(-0.5, 0.5, (6, 3))
+        return c[rng.integers(0, 6, n)] + 0.01 * rng.standard_normal((n, 3)) * rng.uniform(0.1, 3.0)
+    if kind == "lattice":       # exact ties everywhere
+        g = rng.integers(0, 12, (n, 3)).astype(np.float64)
+        return g * 0.0078125
+    if kind == "line":
+        t = rng.uniform(0, 1, n)
+        return np.stack([t, 0.5 * t, np.full(n, 0.25)], 1)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_search_matches_brute_force_on_random_scenes(api, rs, seed):
+    rng = np.random.default_rng(1234 + seed)
+    kinds = ["uniform", "plane", "clusters", "lattice", "line"]
+    gates = [0.004, 0.013, 0.05, 0.2, 1e30]
+    n_checked = 0
+    for rep in range(16):
+        kind = kinds[(seed + rep) % len(kinds)]
+        nt, ns = int(rng.integers(1, 3000)), int(rng.integers(1, 1500))
+        tgt = scene(rng, kind, nt).astype(np.float32)
+        src = (scene(rng, kind, ns) + rng.uniform(-0.02, 0.02, 3)).astype(np.float32)
+        if rep % 3 == 0:       # duplicates (the RealSense (0,0,0) convention) and invalid records
+            tgt[rng.integers(0, nt, max(1, nt // 10))] = 0.0
+            src[rng.integers(0, ns, max(1, ns // 10))] = 0.0
+            tgt[rng.integers(0, nt, max(1, nt // 50))] = np.nan
+            src[rng.integers(0, ns, max(1, ns // 50))] = np.inf
+        if rep % 4 == 1:       # some queries far outside the target's box
+            src[rng.integers(0, ns, max(1, ns // 8))] += rng.uniform(-3, 3, 3).astype(np.float32)
+        gate = gates[int(rng.integers(0, len(gates)))]
+        tc, sc = rs.PointCloud.from_xyz(tgt), rs.PointCloud.from_xyz(src)
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(max_iterations=3, criteria_mode=1, pipeline_mode=0, max_correspondence_distance=gate)
+        icp.setInputSource(sc)
+        icp.setInputTarget(tc)
+        icp.begin()
+        want_idx, want_d2 = brute(src, tgt, gate)
+        for _ in range(2):     # second round: seeded
+            idx, d2 = icp.search()
+            assert np.array_equal(idx.astype(np.int64), want_idx), (kind, nt, ns, gate, rep)
+            assert np.array_equal(d2[want_idx >= 0], want_d2[want_idx >= 0]), (kind, nt, ns, gate, rep)
+        icp.end()
+        n_checked += ns
+    assert n_checked > 0

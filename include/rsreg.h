@@ -216,11 +216,17 @@ int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, s
 
 /* ---- pcl::ApproximateVoxelGrid<PointXYZRGB>::filter --------------------------------- */
 /* incremental_icp.hpp:54-55, icp_edge...hpp:47,59-60,75-76, ndt_edge...hpp:45,57-58,68-69.
- * Order-dependent streaming hash-history centroiding: kept sequential on the host so the
- * output equals PCL's record for record.  Records must be PointXYZRGB (stride >= 20, rgb
+ * Order-dependent streaming hash-history centroiding; this entry point runs it sequentially
+ * on the host (no context needed), record for record like PCL.  Records must be PointXYZRGB (stride >= 20, rgb
  * at byte 16).  out must hold n records; *n_out receives the count.  in == out allowed. */
 int rsreg_approx_voxel_grid(const void *in, size_t n, size_t stride, const float leaf[3],
                             void *out, size_t *n_out);
+/* The same filter on the GPU, same output record for record: the points of one hash slot are
+ * an independent stream, each run of equal voxels in it gives one centroid (float sums in input
+ * order), and a run is emitted where the next run of its slot begins -- all of which sorts and
+ * scans reconstruct (csrc/voxel.hip).  stride must be a multiple of 4. */
+int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_t n, size_t stride,
+                                const float leaf[3], void *out, size_t *n_out);
 
 /* ---- NDT: pcl::NormalDistributionsTransform<PointXYZRGB,PointXYZRGB> ---------------- */
 /* ndt.setInputTarget (ndt_edge...hpp:72): voxel binning + per-voxel mean / covariance /

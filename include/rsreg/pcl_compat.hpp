@@ -270,8 +270,12 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
 };
 
 // ---- pcl::ApproximateVoxelGrid (host, sequential: order-dependent by definition)
+// Default-constructed: the sequential host filter.  With a Context: the same filter on the GPU
+// (csrc/voxel.hip), same records in the same order.
 template <typename PointT> class ApproximateVoxelGrid {
   public:
+    ApproximateVoxelGrid() = default;
+    explicit ApproximateVoxelGrid(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) {}
     void setLeafSize(float lx, float ly, float lz) { leaf_[0] = lx; leaf_[1] = ly; leaf_[2] = lz; }
     void setInputCloud(const typename PointCloud<PointT>::Ptr &cloud) { input_ = cloud; }
     void filter(PointCloud<PointT> &output)  // output may be *input (the reference filters in place)
@@ -279,7 +283,11 @@ template <typename PointT> class ApproximateVoxelGrid {
         if (!input_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputCloud not called");
         std::vector<PointT> out(input_->size());
         size_t n_out = 0;
-        check(rsreg_approx_voxel_grid(input_->points.data(), input_->size(), sizeof(PointT), leaf_, out.data(), &n_out));
+        if (ctx_)
+            check(rsreg_approx_voxel_grid_gpu(ctx_->get(), input_->points.data(), input_->size(), sizeof(PointT), leaf_, out.data(),
+                                              &n_out), ctx_->get());
+        else
+            check(rsreg_approx_voxel_grid(input_->points.data(), input_->size(), sizeof(PointT), leaf_, out.data(), &n_out));
         out.resize(n_out);
         output.points = std::move(out);
         output.width = (uint32_t)n_out;
@@ -289,6 +297,7 @@ template <typename PointT> class ApproximateVoxelGrid {
   private:
     float leaf_[3] = {1.f, 1.f, 1.f};  // PCL default: IncrementalICP never sets it (incremental_icp.hpp:36)
     typename PointCloud<PointT>::Ptr input_;
+    std::shared_ptr<Context> ctx_;
 };
 
 // ---- pcl::transformPointCloud(in, out, Matrix4f); in and out may be the same object

@@ -78,7 +78,7 @@ class IncrementalICP : public RegistrationScheme {
   public:
     rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
     {
-        ApproximateVoxelGrid<rgb_point> voxel;  // leaf never set: PCL's 1 m default applies
+        ApproximateVoxelGrid<rgb_point> voxel(Context::Default());  // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
         rgb_point_cloud_pointer model = clouds[0];  // aliases (and grows) the caller's frame 0
@@ -114,7 +114,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         if (use_imu) assert(clouds.size() == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
-        ApproximateVoxelGrid<rgb_point> voxel;
+        ApproximateVoxelGrid<rgb_point> voxel(Context::Default());
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
 

@@ -344,11 +344,13 @@ class NormalDistributionsTransform:
 
 
 class ApproximateVoxelGrid:
-    """pcl::ApproximateVoxelGrid<PointXYZRGB> (host, sequential: see csrc/voxel_host.cpp)."""
+    """pcl::ApproximateVoxelGrid<PointXYZRGB>.  Without a context: the sequential host filter
+    (csrc/voxel_host.cpp); with one: the GPU filter (csrc/voxel.hip), same records in the same order."""
 
-    def __init__(self):
+    def __init__(self, ctx=None):
         self.leaf = np.ones(3, np.float32)  # PCL default leaf: 1 m (IncrementalICP never sets it)
         self._in = None
+        self.ctx = ctx
 
     def setLeafSize(self, lx, ly, lz):
         self.leaf = np.array([lx, ly, lz], np.float32)
@@ -360,8 +362,12 @@ class ApproximateVoxelGrid:
         pts = np.ascontiguousarray(self._in.points)
         out = np.zeros_like(pts)
         n_out = C.c_size_t(0)
-        _l.check(_l.lib().rsreg_approx_voxel_grid(pts.ctypes.data, len(pts), pts.dtype.itemsize,
-                                                  self.leaf.ctypes.data, out.ctypes.data, C.byref(n_out)))
+        if self.ctx is not None:
+            _l.check(_l.lib().rsreg_approx_voxel_grid_gpu(self.ctx.h, pts.ctypes.data, len(pts), pts.dtype.itemsize,
+                                                          self.leaf.ctypes.data, out.ctypes.data, C.byref(n_out)), self.ctx.h)
+        else:
+            _l.check(_l.lib().rsreg_approx_voxel_grid(pts.ctypes.data, len(pts), pts.dtype.itemsize,
+                                                      self.leaf.ctypes.data, out.ctypes.data, C.byref(n_out)))
         out = out[: n_out.value].copy()
         return PointCloud(out, width=len(out), height=1, is_dense=False)
 

@@ -117,23 +117,6 @@ double cell_cap_from_env()
     return 0.0115;  // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
-// Host-side record loops (32-byte AoS records <-> packed xyz in pinned staging) are memory-bound
-// copies of tens of MB: split them over a few threads.  f(lo, hi) handles records [lo, hi).
-template <typename F> void host_parallel_for(size_t n, F f)
-{
-    static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    const unsigned nt = (unsigned)std::min<size_t>(hw, n / 65536 + 1);
-    if (nt <= 1) {
-        f((size_t)0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    th.reserve(nt - 1);
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
-    f((size_t)0, n / nt);
-    for (auto &t : th) t.join();
-}
-
 int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
 {
     hipError_t e = ctx->h_stage.reserve(n * 12 + 16);
@@ -869,7 +852,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
-                      &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
+                      &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();

@@ -6,7 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rsreg.h"
@@ -140,6 +142,9 @@ struct rsreg_ctx {
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     rsreg::IcpState icp;
 
+    // ---- ApproximateVoxelGrid on the device (voxel.hip)
+    rsreg::DevBuf d_vox_in, d_vox_out, d_vox_cent;
+
     // ---- NDT
     bool have_ndt_target = false;
     double ndt_resolution = 0;
@@ -174,6 +179,23 @@ inline int fail(rsreg_ctx *ctx, int code, const char *what, hipError_t e = hipSu
         }
     }
     return code;
+}
+
+// Host-side record loops (32-byte AoS records <-> packed xyz in pinned staging) are memory-bound
+// copies of tens of MB: split them over a few threads.  f(lo, hi) handles records [lo, hi).
+template <typename F> inline void host_parallel_for(size_t n, F f)
+{
+    static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::min<size_t>(hw, n / 65536 + 1);
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+    f((size_t)0, n / nt);
+    for (auto &t : th) t.join();
 }
 
 #define RSREG_HIP(ctx, expr)                                              \

@@ -1,0 +1,292 @@
+// voxel.hip — pcl::ApproximateVoxelGrid<PointXYZRGB>::filter on the GPU, record for record.
+//
+// Reference call sites: src/incremental_icp.hpp:54-55, src/icp_edge_based_registration.hpp:47,
+// 59-60,75-76, src/ndt_edge_based_registration.hpp:45,57-58,68-69.  PCL's filter (SURVEY.md
+// App. A.5; sequential restatement: voxel_host.cpp) streams the points through a 512-slot hash
+// history: a point whose slot holds a different voxel flushes that voxel's centroid to the
+// output and takes the slot; at the end the occupied slots are flushed in slot order.  The
+// output therefore depends on the input order -- but not on anything a parallel machine cannot
+// reconstruct:
+//   * the points that hash to one slot form an independent stream; inside it, every maximal run
+//     of consecutive points with the same voxel yields exactly one centroid;
+//   * a run that is followed by another run in its slot is emitted when that next run's first
+//     point arrives, i.e. at that point's position in the input; the last run of every slot is
+//     emitted at the end, in slot order;
+//   * a centroid is a float sum in input order divided by the count.
+// So: stable-sort the point indices by slot, cut the runs, let one thread add up each run in
+// order (same float additions as PCL), and sort the runs by their emission position.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#include "rsreg_ctx.hpp"
+
+namespace rsreg {
+namespace {
+
+constexpr int kVBlock = 256;
+constexpr uint32_t kHist = 512;   // PCL's histsize_
+
+struct VoxelOf {
+    int ix, iy, iz;
+    bool ok;
+};
+
+__device__ __forceinline__ VoxelOf voxel_of(const char *rec, float ivx, float ivy, float ivz)
+{
+    const float *p = reinterpret_cast<const float *>(rec);
+    const float x = p[0], y = p[1], z = p[2];
+    VoxelOf v;
+    v.ok = isfinite(x) && isfinite(y) && isfinite(z);
+    v.ix = (int)floorf(__fmul_rn(x, ivx));
+    v.iy = (int)floorf(__fmul_rn(y, ivy));
+    v.iz = (int)floorf(__fmul_rn(z, ivz));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t slot_of(const VoxelOf &v)
+{
+    return (uint32_t)(v.ix * 7171 + v.iy * 3079 + v.iz * 4231) & (kHist - 1);
+}
+
+// key = slot (non-finite points: kHist, sorted behind everything), value = input position
+__global__ __launch_bounds__(kVBlock) void k_vox_keys(const char *recs, size_t stride, uint32_t n, float ivx, float ivy, float ivz,
+                                                      uint32_t *keys, uint32_t *vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const VoxelOf v = voxel_of(recs + (size_t)i * stride, ivx, ivy, ivz);
+    keys[i] = v.ok ? slot_of(v) : kHist;
+    vals[i] = i;
+}
+
+// p = position in the slot-sorted order; flag[p] = 1 when a run starts there
+__global__ __launch_bounds__(kVBlock) void k_vox_flags(const char *recs, size_t stride, uint32_t n, float ivx, float ivy, float ivz,
+                                                       const uint32_t *skeys, const uint32_t *svals, uint32_t *flag)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t f = 0;
+    if (skeys[p] < kHist) {
+        f = 1;
+        if (p > 0 && skeys[p - 1] == skeys[p]) {
+            const VoxelOf a = voxel_of(recs + (size_t)svals[p] * stride, ivx, ivy, ivz);
+            const VoxelOf b = voxel_of(recs + (size_t)svals[p - 1] * stride, ivx, ivy, ivz);
+            if (a.ix == b.ix && a.iy == b.iy && a.iz == b.iz) f = 0;
+        }
+    }
+    flag[p] = f;
+}
+
+// run r starts at sorted position start[r]; stats[0] = number of runs, stats[1] = number of finite points
+__global__ __launch_bounds__(kVBlock) void k_vox_starts(const uint32_t *skeys, const uint32_t *flag, const uint32_t *rid, uint32_t n,
+                                                        uint32_t *start, uint32_t *stats)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (flag[p]) start[rid[p]] = p;
+    if (p == n - 1) stats[0] = rid[p] + flag[p];
+    if (skeys[p] < kHist && (p == n - 1 || skeys[p + 1] >= kHist)) stats[1] = p + 1;
+}
+
+constexpr uint32_t kLongRun = 48;   // runs from this length on are summed by a whole wave (k_vox_long_runs)
+
+__device__ __forceinline__ void vox_store_run(const float acc[7], uint32_t a, uint32_t b, uint32_t n, uint32_t nfin, uint32_t r,
+                                              const uint32_t *skeys, const uint32_t *svals, float *cent, uint32_t *ekey, uint32_t *erun)
+{
+    const float cnt = (float)(b - a);
+    float *o = cent + (size_t)r * 8;
+    for (int k = 0; k < 7; ++k) o[k] = __fdiv_rn(acc[k], cnt);
+    const uint32_t slot = skeys[a];
+    const bool last_of_slot = (b >= nfin) || skeys[b] != slot;
+    ekey[r] = last_of_slot ? n + slot : svals[b];
+    erun[r] = r;
+}
+
+// the seven values PCL accumulates for a point: x y z, the rgb field read as a float, r g b
+__device__ __forceinline__ void vox_terms(const char *rec, float t[7])
+{
+    const float *f = reinterpret_cast<const float *>(rec);
+    const unsigned char *c = reinterpret_cast<const unsigned char *>(rec + 16);
+    t[0] = f[0]; t[1] = f[1]; t[2] = f[2]; t[3] = f[4];
+    t[4] = (float)c[2]; t[5] = (float)c[1]; t[6] = (float)c[0];
+}
+
+// One thread per run: the centroid record (sums in input order, like PCL) and the run's
+// emission key: the input position of the first point of the next run in the same slot, or
+// n + slot for the last run of a slot.  Long runs are only listed here (stats[2] counts them).
+__global__ __launch_bounds__(kVBlock) void k_vox_runs(const char *recs, size_t stride, uint32_t n, const uint32_t *skeys,
+                                                      const uint32_t *svals, const uint32_t *start, uint32_t *stats,
+                                                      float *cent /* 8 floats per run */, uint32_t *ekey, uint32_t *erun,
+                                                      uint32_t *long_runs)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nr = stats[0], nfin = stats[1];
+    if (r >= nr) return;
+    const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
+    if (b - a >= kLongRun) {
+        long_runs[atomicAdd(&stats[2], 1u)] = r;
+        return;
+    }
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t p = a; p < b; ++p) {
+        float t[7];
+        vox_terms(recs + (size_t)svals[p] * stride, t);
+        for (int k = 0; k < 7; ++k) acc[k] = __fadd_rn(acc[k], t[k]);
+    }
+    vox_store_run(acc, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);
+}
+
+// One wave per long run (a 1 m leaf puts 10^4..10^5 points in a run): 64 lanes fetch 64 points
+// at a time into LDS (component-major), lanes 0..6 each add one of the seven components in input
+// order, four LDS values per read; the next 64 points are in flight meanwhile.  A short last
+// chunk is padded with +0.0f, which leaves a float sum unchanged.
+__global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, size_t stride, uint32_t n, const uint32_t *skeys,
+                                                           const uint32_t *svals, const uint32_t *start, const uint32_t *stats,
+                                                           float *cent, uint32_t *ekey, uint32_t *erun, const uint32_t *long_runs)
+{
+    __shared__ __attribute__((aligned(16))) float sh[kVBlock / 64][8][64];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nr = stats[0], nfin = stats[1], n_long = stats[2];
+    for (uint32_t k = wave; k < n_long; k += n_waves) {
+        const uint32_t r = long_runs[k];
+        const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
+        float acc = 0.0f;
+        float t[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (a + lane < b) vox_terms(recs + (size_t)svals[a + lane] * stride, t);
+        for (uint32_t p0 = a; p0 < b; p0 += 64) {
+            for (int c = 0; c < 7; ++c) sh[w][c][lane] = t[c];
+            for (int c = 0; c < 7; ++c) t[c] = 0.0f;
+            if (p0 + 64 + lane < b) vox_terms(recs + (size_t)svals[p0 + 64 + lane] * stride, t);   // next chunk, in flight
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 7) {
+                const float4 *v = reinterpret_cast<const float4 *>(&sh[w][lane][0]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 q = v[i];
+                    acc = __fadd_rn(acc, q.x);
+                    acc = __fadd_rn(acc, q.y);
+                    acc = __fadd_rn(acc, q.z);
+                    acc = __fadd_rn(acc, q.w);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float all[7];
+        for (int c = 0; c < 7; ++c) all[c] = __shfl(acc, c);
+        if (lane == 0) vox_store_run(all, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);
+    }
+}
+
+// output record j = centroid of run order[j]: a default PointXYZRGB with xyz and packed rgb set
+__global__ __launch_bounds__(kVBlock) void k_vox_emit(const float *cent, const uint32_t *order, const uint32_t *stats, size_t stride,
+                                                      char *out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= stats[0]) return;
+    const float *c = cent + (size_t)order[j] * 8;
+    char *rec = out + (size_t)j * stride;
+    for (size_t k = 0; k < stride; k += 4) *reinterpret_cast<uint32_t *>(rec + k) = 0u;
+    float *f = reinterpret_cast<float *>(rec);
+    f[0] = c[0];
+    f[1] = c[1];
+    f[2] = c[2];
+    f[3] = 1.0f;
+    const int rgb = ((int)c[4] << 16) | ((int)c[5] << 8) | (int)c[6];
+    *reinterpret_cast<int *>(rec + 16) = rgb;
+}
+
+inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+}  // namespace rsreg
+
+using namespace rsreg;
+
+extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_t n, size_t stride, const float leaf[3], void *out,
+                                           size_t *n_out)
+{
+    if (!ctx || !leaf || !n_out || (n && (!in || !out)) || stride < 20 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0)) return RSREG_ERR_INVALID_ARG;
+    if (n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
+    *n_out = 0;
+    if (n == 0) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t)n;
+    const float ivx = 1.0f / leaf[0], ivy = 1.0f / leaf[1], ivz = 1.0f / leaf[2];
+    // buffers (all reused from the context; nothing here overlaps an ICP call in flight)
+    RSREG_HIP(ctx, ctx->d_vox_in.reserve(n * stride));
+    RSREG_HIP(ctx, ctx->d_vox_out.reserve(n * stride));
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
+    RSREG_HIP(ctx, ctx->d_vox_cent.reserve(n * 32));
+    RSREG_HIP(ctx, ctx->d_misc.reserve(256));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(1024));
+    char *d_in = ctx->d_vox_in.as<char>(), *d_out = ctx->d_vox_out.as<char>();
+    uint32_t *keys = ctx->d_keys.as<uint32_t>(), *skeys = ctx->d_keys_alt.as<uint32_t>();
+    uint32_t *vals = ctx->d_vals.as<uint32_t>(), *svals = ctx->d_vals_alt.as<uint32_t>();
+    uint32_t *flag = ctx->d_flags.as<uint32_t>(), *rid = ctx->d_scan.as<uint32_t>();
+    uint32_t *start = keys;                 // keys are dead once sorted
+    uint32_t *ekey = vals, *erun = flag;    // vals dead once sorted, flag dead after the starts
+    uint32_t *ekey2 = keys + N, *order = vals + N;
+    uint32_t *long_runs = rid;              // the run ids are dead once the starts are written
+    float *cent = ctx->d_vox_cent.as<float>();
+    uint32_t *stats = ctx->d_misc.as<uint32_t>() + 32;
+    // through pinned staging, copied by a few threads: a pageable hipMemcpy of 10-30 MB is several times slower
+    RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
+    {
+        char *stage = ctx->h_stage.as<char>();
+        const char *src = static_cast<const char *>(in);
+        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+    }
+    RSREG_HIP(ctx, hipMemcpyAsync(d_in, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
+    RSREG_HIP(ctx, hipMemsetAsync(stats, 0, 16, st));
+    const uint32_t nb = div_up_u(N, kVBlock);
+    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
+    k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    k_vox_starts<<<nb, kVBlock, 0, st>>>(skeys, flag, rid, N, start, stats);
+    RSREG_HIP(ctx, hipGetLastError());
+    uint32_t *h = ctx->h_sums.as<uint32_t>();
+    RSREG_HIP(ctx, hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t nr = h[0];
+    if (nr == 0) return RSREG_OK;
+    k_vox_runs<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun, long_runs);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_vox_long_runs<<<std::min(div_up_u(nr, 4u), 2048u), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun,
+                                                                           long_runs);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
+    k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, order, stats, stride, d_out);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, d_out, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    {
+        const char *stage = ctx->h_stage.as<char>();
+        char *dst = static_cast<char *>(out);
+        host_parallel_for(nr, [=](size_t lo, size_t hi) { std::memcpy(dst + lo * stride, stage + lo * stride, (hi - lo) * stride); });
+    }
+    *n_out = nr;
+    return RSREG_OK;
+}

@@ -21,14 +21,14 @@ struct Slot {
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};  // x y z rgb-as-float r g b
 };
 
-void emit(std::vector<unsigned char> &out, size_t stride, const Slot &s)
+void emit(unsigned char *out, size_t &n_out, size_t stride, const Slot &s)
 {
     const float n = static_cast<float>(s.count);
     float c[7];
     for (int k = 0; k < 7; ++k) c[k] = s.acc[k] / n;
-    const size_t at = out.size();
-    out.resize(at + stride, 0);  // a default PointXYZRGB: zeros, data[3] = 1
-    unsigned char *rec = out.data() + at;
+    unsigned char *rec = out + n_out * stride;  // a default PointXYZRGB: zeros, data[3] = 1
+    ++n_out;
+    std::memset(rec, 0, stride);
     const float one = 1.0f;
     std::memcpy(rec, c, 12);
     std::memcpy(rec + 12, &one, 4);
@@ -46,8 +46,16 @@ extern "C" int rsreg_approx_voxel_grid(const void *in, size_t n, size_t stride, 
     constexpr int kHist = 512;
     std::vector<Slot> hist(kHist);
     const float inv[3] = {1.0f / leaf[0], 1.0f / leaf[1], 1.0f / leaf[2]};
-    std::vector<unsigned char> result;  // built aside: in == out is allowed
-    result.reserve(n * stride / 4 + stride);
+    // in == out is allowed, and the output can only fall behind the input (a record is emitted
+    // after at least one more input record has been read) except in the final flush -- but the
+    // slot an emission frees may still be read as input later, so an aliased call works aside
+    std::vector<unsigned char> aside;
+    unsigned char *result = static_cast<unsigned char *>(out);
+    if (in == out) {
+        aside.resize(n * stride);
+        result = aside.data();
+    }
+    size_t count = 0;
     const unsigned char *src = static_cast<const unsigned char *>(in);
     for (size_t i = 0; i < n; ++i) {
         const unsigned char *rec = src + i * stride;
@@ -63,7 +71,7 @@ extern "C" int rsreg_approx_voxel_grid(const void *in, size_t n, size_t stride, 
         const unsigned h = static_cast<unsigned>((ix * 7171 + iy * 3079 + iz * 4231) & (kHist - 1));
         Slot &s = hist[h];
         if (s.count && (s.ix != ix || s.iy != iy || s.iz != iz)) {
-            emit(result, stride, s);
+            emit(result, count, stride, s);
             s = Slot();
         }
         s.ix = ix; s.iy = iy; s.iz = iz;
@@ -72,8 +80,8 @@ extern "C" int rsreg_approx_voxel_grid(const void *in, size_t n, size_t stride, 
         for (int k = 0; k < 7; ++k) s.acc[k] += add[k];
     }
     for (const Slot &s : hist)
-        if (s.count) emit(result, stride, s);
-    if (!result.empty()) std::memcpy(out, result.data(), result.size());
-    *n_out = result.size() / stride;
+        if (s.count) emit(result, count, stride, s);
+    if (in == out && count) std::memcpy(out, result, count * stride);
+    *n_out = count;
     return RSREG_OK;
 }

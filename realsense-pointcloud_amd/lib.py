@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["icp.hip", "ndt.hip", "comm.cpp", "voxel_host.cpp"]
+SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
 UNIQUE_ID_BYTES = 128
@@ -24,7 +24,7 @@ EXPORTS = [
     "rsreg_ndt_params_reference", "rsreg_icp_set_target", "rsreg_icp_set_target_device",
     "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_begin",
     "rsreg_icp_search", "rsreg_icp_sums", "rsreg_icp_update", "rsreg_icp_end",
-    "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid",
+    "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
     "rsreg_icp_grid_info",
@@ -151,6 +151,7 @@ def lib():
     L.rsreg_umeyama_from_sums.argtypes = [vp, vp]
     L.rsreg_transform_cloud.argtypes = [vp, vp, vp, sz, sz, i32, vp]
     L.rsreg_approx_voxel_grid.argtypes = [vp, sz, sz, vp, vp, C.POINTER(sz)]
+    L.rsreg_approx_voxel_grid_gpu.argtypes = [vp, vp, sz, sz, vp, vp, C.POINTER(sz)]
     L.rsreg_ndt_set_target.argtypes = [vp, vp, sz, sz, i32, dbl]
     L.rsreg_ndt_align.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp, sz]
     L.rsreg_ndt_derivatives.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(dbl), vp, vp]

@@ -64,7 +64,7 @@ class HipBackend:
         return ndt
 
     def voxel(self, leaf=None):
-        f = self.api.ApproximateVoxelGrid()
+        f = self.api.ApproximateVoxelGrid(self.ctx or self.api.default_context())   # the GPU filter (same records as the host one)
         if leaf is not None:
             f.setLeafSize(*leaf)
         return f

@@ -37,3 +37,16 @@ print("align (+aligned)   %.3f ms" % t(lambda: lib.check(L.rsreg_icp_align(ctx.h
 T = np.ascontiguousarray(np.eye(4, dtype=np.float32))
 print("transform_cloud    %.3f ms" % t(lambda: lib.check(L.rsreg_transform_cloud(ctx.h, src.points.ctypes.data, out.ctypes.data, n, stride, 0, T.ctypes.data), ctx.h)))
 print("numpy copy 32MB    %.3f ms" % t(lambda: src.points.copy()))
+
+# ApproximateVoxelGrid: sequential host filter vs the GPU filter (same output), C calls on preallocated buffers
+for size_v, leaf in (("N300", 0.01), ("N300", 1.0), ("N1M", 0.01)):
+    c = synth.render_frame(2, size_v, "bench")
+    pts = np.ascontiguousarray(c.points)
+    outb = np.zeros_like(pts)
+    outb[:] = pts          # touch every page once
+    lf = np.array([leaf] * 3, np.float32)
+    n_out = C.c_size_t(0)
+    ms_h = t(lambda: lib.check(L.rsreg_approx_voxel_grid(pts.ctypes.data, len(pts), stride, lf.ctypes.data, outb.ctypes.data, C.byref(n_out))), reps=3)
+    nh = n_out.value
+    ms_g = t(lambda: lib.check(L.rsreg_approx_voxel_grid_gpu(ctx.h, pts.ctypes.data, len(pts), stride, lf.ctypes.data, outb.ctypes.data, C.byref(n_out)), ctx.h), reps=3)
+    print("approx_voxel_grid %s leaf %.2f: host %.3f ms, gpu %.3f ms -> %d / %d points" % (size_v, leaf, ms_h, ms_g, nh, n_out.value))

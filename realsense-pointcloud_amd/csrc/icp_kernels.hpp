@@ -719,6 +719,24 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// one step of the recursive-halving reduction (tile_reduce_store): the lane holds the sums
+// [base, base + cnt) in v[0..N); it keeps the lower or the upper half according to its bit
+// `mask` and adds its partner's copy of that half
+template <int N>
+__device__ __forceinline__ void halve_sums(const double (&v)[N], double (&out)[(N + 1) / 2], int lane, int mask, int &base, int &cnt)
+{
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & mask) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const double lo = v[j], hi = (H + j < N) ? v[H + j] : 0.0;
+        const double mine = up ? hi : lo, send = up ? lo : hi;
+        out[j] = mine + __shfl_xor(send, mask);
+    }
+    base = up ? base + H : base;
+    cnt = up ? max(cnt - H, 0) : min(cnt, H);
+}
+
 // accumulate one accepted pair (p = source, q = target) into the 17 sums; w = how many
 // identical source points this one stands for (exact duplicates are searched once)
 __device__ __forceinline__ void accum_pair(double *a, float px, float py, float pz, float qx, float qy, float qz, float d2,
@@ -743,10 +761,23 @@ __device__ __forceinline__ void tile_reduce_store(double *a, double *partials, u
 {
     __shared__ double shr[kTileWaves][RSREG_NUM_SUMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < RSREG_NUM_SUMS; ++k) {
-        const double v = wave_sum(a[k]);
-        if (lane == 0) shr[wave][k] = v;
+    // 17 sums over the 64 lanes by recursive halving: at each of the six steps a lane keeps half
+    // of the sums it still holds and hands the other half to its partner (lane ^ 32, 16, ... 1),
+    // so the steps move 9 + 5 + 3 + 2 + 1 + 1 = 21 doubles instead of 17 x 6 = 102 for seventeen
+    // separate butterflies.  The tree (who adds what, in which order) is fixed.
+    int base = 0, cnt = RSREG_NUM_SUMS;
+    double v9[9], v5[5], v3[3], v2[2], v1[1], v0[1];
+    {
+        double v17[RSREG_NUM_SUMS];
+        for (int k = 0; k < RSREG_NUM_SUMS; ++k) v17[k] = a[k];
+        halve_sums<RSREG_NUM_SUMS>(v17, v9, lane, 32, base, cnt);
     }
+    halve_sums<9>(v9, v5, lane, 16, base, cnt);
+    halve_sums<5>(v5, v3, lane, 8, base, cnt);
+    halve_sums<3>(v3, v2, lane, 4, base, cnt);
+    halve_sums<2>(v2, v1, lane, 2, base, cnt);
+    halve_sums<1>(v1, v0, lane, 1, base, cnt);
+    if (cnt >= 1) shr[wave][base] = v0[0];   // exactly one lane ends up owning each of the 17 sums
     __syncthreads();
     if (threadIdx.x < RSREG_NUM_SUMS) {
         double v = shr[0][threadIdx.x];

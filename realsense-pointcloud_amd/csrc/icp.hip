@@ -325,7 +325,9 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     // ---- cell size: a whole fraction of the gate, no larger than the cap; an unbounded
     // gate searches outward until the grid is exhausted.  `refine` (second pass only) shrinks
     // the cells of a dense cloud towards ~8 points per occupied cell.
-    const double cap = cell_cap_from_env();
+    // the cap is tuned on 10^6-point D435i-like frames; sparser clouds (lower resolution of the same
+    // scene: sample spacing ~ n^-1/2) do best with somewhat larger cells (swept at 50 k and 300 k points)
+    const double cap = cell_cap_from_env() * std::min(3.0, std::max(1.0, std::pow(1.0e6 / std::max<double>(nfin, 1.0e4), 0.28)));
     double extent = 0;
     for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
     double cell;

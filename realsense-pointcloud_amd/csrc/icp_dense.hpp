@@ -245,17 +245,20 @@ __device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int 
 
 // rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
 template <bool kDiag = false>
-__device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
-                                               DDiag *dg = nullptr)
+__device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b,
+                                               float &limit2, DDiag *dg = nullptr)
 {
     const f32x2 qxy = {q.qx, q.qy};
     const float qz = q.qz;
     const float cell2 = g.cell * g.cell;
     const int base = (int)dense_cell_id(g, q.cx, q.cy, q.cz);
+    // the three first loads (neighbourhood word, own cell's range, the seed point) go out together:
+    // a search is a chain of dependent loads, and every round trip saved shortens the slowest waves
     const uint32_t occ = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
+    const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
+    dense_seed(rs, q, seed_pos, b, limit2);
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
     {
-        const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
         if (kDiag) dg->own = (se.y - se.x + 3) / 4;
         dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qxy, qz);
         limit2 = fminf(limit2, b.d);
@@ -281,20 +284,32 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
         mask |= (lb <= lim_c) ? (1u << j) : 0u;
     }
     mask &= occ;         // empty cells are never opened
+    // flat loop: a trip moves on to the next plausible cell and/or scores 4 candidates.  The range
+    // of the cell after the current one is already in flight (nse) while the current one is scored.
     uint32_t po = 0, pe = 0;
-    for (;;) {   // flat: each iteration takes the next plausible cell and/or scores 4 candidates
+    u32x2 nse = {0u, 0u};
+    float nlb2 = 0.0f;
+    bool nvalid = false;
+    for (;;) {
         if (po >= pe) {
-            if (!mask) break;
-            if (kDiag) ++dg->r1_cells;
-            const int j = __ffs((int)mask) - 1;
-            mask &= mask - 1;
-            const int dz = j / 9, dy = (j - dz * 9) / 3, dx = j - dz * 9 - dy * 3;
-            const float lb2 = (sel3(gx0, gx1, gx2, dx) + sel3(gy0, gy1, gy2, dy) + sel3(gz0, gz1, gz2, dz)) * cell2;
-            if (lb2 <= limit2) {   // the limit may have tightened since the mask was built
-                const int idx = base + (dz - 1) * g.sxy + (dy - 1) * g.sx + (dx - 1);
-                const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)idx * 4u, 0, 0);
-                po = se.x * 16u;
-                pe = se.y * 16u;
+            if (!nvalid && !mask) break;
+            if (nvalid && nlb2 <= limit2) {   // (the limit may have tightened since that range was asked for)
+                po = nse.x * 16u;
+                pe = nse.y * 16u;
+            }
+            nvalid = false;
+            if (mask) {
+                if (kDiag) ++dg->r1_cells;
+                const int j = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                const int dz = j / 9, dy = (j - dz * 9) / 3, dx = j - dz * 9 - dy * 3;
+                const float lb2 = (sel3(gx0, gx1, gx2, dx) + sel3(gy0, gy1, gy2, dy) + sel3(gz0, gz1, gz2, dz)) * cell2;
+                if (lb2 <= limit2) {
+                    const int idx = base + (dz - 1) * g.sxy + (dy - 1) * g.sx + (dx - 1);
+                    nse = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)idx * 4u, 0, 0);
+                    nlb2 = lb2;
+                    nvalid = true;
+                }
             }
         }
         if (po < pe) {
@@ -397,8 +412,7 @@ __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, floa
     const DQuery q = dense_query(g, qx, qy, qz);
     float limit2 = g.prune2;
     DBest b{__uint_as_float(0x7f800000u), 0xffffffffu, 0xffffffffu};
-    dense_seed(rs, q, seed_pos, b, limit2);
-    dense_near<kDiag>(g, rs, q, b, limit2, dg);
+    dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, dg);
     if (kDiag) dg->t_near = wall_clock64();
     const bool far = dense_needs_far(g, limit2);
     if (far) dense_far<kDiag>(g, rs, q, b, limit2, dg);

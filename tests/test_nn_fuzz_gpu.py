@@ -92,3 +92,60 @@ def test_search_matches_brute_force_on_random_scenes(api, rs, seed):
         icp.end()
         n_checked += ns
     assert n_checked > 0
+
+
+def test_wide_extent_cloud_takes_the_brick_hash_and_stays_exact(api, rs):
+    """Two clusters 400 m apart: the dense table would need ~10^13 cells at this gate, so the
+    index falls back to the brick hash by itself (no environment override)."""
+    rng = np.random.default_rng(77)
+    a = rng.uniform(-0.5, 0.5, (3000, 3))
+    b = rng.uniform(-0.5, 0.5, (3000, 3)) + np.array([400.0, -250.0, 100.0])
+    tgt = np.concatenate([a, b]).astype(np.float32)
+    src = (tgt[rng.permutation(len(tgt))[:2500]] + rng.normal(0, 0.004, (2500, 3))).astype(np.float32)
+    gate = 0.02
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=2, criteria_mode=1, pipeline_mode=0, max_correspondence_distance=gate)
+    icp.setInputSource(rs.PointCloud.from_xyz(src))
+    icp.setInputTarget(rs.PointCloud.from_xyz(tgt))
+    icp.begin()
+    idx, d2 = icp.search()
+    assert icp.grid_info().index_kind == 0          # brick hash
+    want_idx, want_d2 = brute(src, tgt, gate)
+    assert np.array_equal(idx.astype(np.int64), want_idx)
+    assert np.array_equal(d2[want_idx >= 0], want_d2[want_idx >= 0])
+    icp.end()
+    # and a whole alignment in each pipeline on that index
+    out = []
+    for pipeline in (0, 1, 2):
+        icp.params = api.icp_params(max_iterations=4, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=gate)
+        icp.align()
+        out.append((bytes(icp.result.transform), icp.result.n_correspondences))
+    assert out[0] == out[1] == out[2]
+
+
+def test_tiny_and_identical_clouds(api, rs):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    # identical clouds: every distance is exactly zero, the transform stays the identity
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=3, criteria_mode=1, max_correspondence_distance=0.05)
+    icp.setInputSource(rs.PointCloud.from_xyz(pts))
+    icp.setInputTarget(rs.PointCloud.from_xyz(pts))
+    icp.begin()
+    idx, d2 = icp.search()
+    assert np.array_equal(idx, np.arange(500)) and not d2.any()
+    icp.end()
+    icp.align()
+    assert np.abs(icp.getFinalTransformation() - np.eye(4)).max() < 1e-6
+    # one, two and three points
+    for n in (1, 2, 3):
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(max_iterations=2, criteria_mode=1, max_correspondence_distance=1.0)
+        icp.setInputSource(rs.PointCloud.from_xyz(pts[:n] + 0.001))
+        icp.setInputTarget(rs.PointCloud.from_xyz(pts[:n]))
+        icp.begin()
+        idx, _ = icp.search()
+        assert np.array_equal(idx.astype(np.int64), brute(pts[:n] + np.float32(0.001), pts[:n], 1.0)[0])
+        icp.end()
+        icp.align()
+        assert icp.hasConverged() == (n >= 3)        # PCL: fewer than 3 correspondences is a failure

@@ -41,6 +41,9 @@ def parse():
                     help="0 staged kernels, 1 fused kernel + host 3x3 solve per iteration, 2 fused kernel + device-resident loop")
     ap.add_argument("--shard-block", type=int, default=256, help="N > 1: source points per block, blocks dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dev: take the multi-rank code path (process group, native RCCL transport, all-reduce per iteration) "
+                         "even with one rank, e.g. under `torch.distributed.run --nproc-per-node 1`")
     ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
     return ap.parse_args()
@@ -66,8 +69,14 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -86,7 +95,7 @@ def main():
 
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=not a.no_events)
     transport = "none"
-    if world > 1:
+    if multi:
         # native transport: RCCL all-reduce of the 17 sums on the ctx stream inside rsreg_icp_align.
         # If the communicator cannot be set up, all ranks agree to fall back to the step-wise
         # driver whose all-reduce is torch.distributed (also RCCL on ROCm).

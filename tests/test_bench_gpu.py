@@ -1,0 +1,46 @@
+"""GPU: bench.py prints ONE JSON line with the fields the driver reads, and its multi-rank code
+path (process group, native RCCL transport inside rsreg_icp_align, barrier + max-over-ranks
+timing) runs -- here with a single rank, which is all a one-GPU box allows."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    j = run(["bench.py", "--size", "50k", "--steps", "2", "--warmup", "1", "--cpu-iterations", "2"])
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["vs_baseline"] is None
+    assert j["value"] > 0 and j["higher_is_better"] is True and j["data"] == "synthetic" and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert j["transform_error_vs_cpu_frobenius"] < 1e-4          # north-star bar
+
+
+def test_bench_multi_rank_path_with_one_rank():
+    j = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+             str(29600 + os.getpid() % 300), "bench.py", "--gpus", "1", "--size", "50k", "--steps", "2", "--warmup", "1",
+             "--no-cpu-baseline", "--force-dist"])
+    assert j["n_gpus"] == 1 and j["value"] > 0

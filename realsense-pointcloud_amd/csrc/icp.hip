@@ -114,7 +114,7 @@ double cell_cap_from_env()
         double v = std::atof(e);
         if (v > 0) return v;
     }
-    return 0.0115;  // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
+    return 0.014;   // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
 int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)

@@ -40,7 +40,8 @@ __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int 
     return (uint32_t)(((z + 1) * (g.ny + 2) + (y + 1)) * (g.nx + 2) + (x + 1));
 }
 
-// sort key: [padded cell id | hash16(xyz)]; non-finite points sort to the very end
+// sort key: [padded cell id | x position inside the cell, 16 bits]: a cell's points are sorted
+// by x, which lets a search stop inside a cell (dense_walk); non-finite points sort to the very end
 __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t stride, uint32_t n, DenseDev g,
                                                        unsigned long long *keys, uint32_t *vals)
 {
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t s
     if (finite3(x, y, z)) {
         const int cx = min(max(cell_coord(x, g.ox, g.inv_cell), 0), g.nx - 1), cy = min(max(cell_coord(y, g.oy, g.inv_cell), 0), g.ny - 1),
                   cz = min(max(cell_coord(z, g.oz, g.inv_cell), 0), g.nz - 1);
-        key = ((unsigned long long)dense_cell_id(g, cx, cy, cz) << 16) | hash_xyz16(x, y, z);
+        const float fx = (cell_pos(x, g.ox, g.inv_cell) - (float)cx) * 65536.0f;
+        key = ((unsigned long long)dense_cell_id(g, cx, cy, cz) << 16) | (unsigned long long)min(max((int)fx, 0), 65535);
     }
     keys[i] = key;
     vals[i] = i;
@@ -197,6 +199,50 @@ __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts
     for (; po < pe; po += 64) dscan4(b, pts, po, qxy, qz);
 }
 
+// A cell's points are sorted by x (to 2^-16 of a cell).  A walk reads a cell 4 points at a time
+// from the end that is nearer to the query in x and stops as soon as the x distance alone
+// exceeds the best so far: everything behind that point is farther still.
+struct DWalk {
+    uint32_t cur, lo;   // forward: next chunk starts at cur; backward: the chunk before cur; lo = the cell's first byte
+    int left;           // chunks still to read (0: nothing)
+    bool back;
+};
+
+__device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back)
+{
+    w.lo = se.x * 16u;
+    w.left = (int)((se.y - se.x + 3u) >> 2);
+    w.back = back;
+    w.cur = back ? se.y * 16u : w.lo;
+}
+
+// one chunk; x_slack = how far the x order inside a cell can be off (quantisation of the sort key)
+__device__ __forceinline__ void dwalk_step(DWalk &w, DBest &b, __amdgpu_buffer_rsrc_t pts, f32x2 qxy, float qz, float x_slack,
+                                           float &limit2)
+{
+    uint32_t po;
+    if (w.back) {
+        po = (w.cur - w.lo >= 64u) ? w.cur - 64u : w.lo;   // the last chunk of a backward walk starts at the cell's first point
+        w.cur = po;
+    } else {
+        po = w.cur;
+        w.cur += 64u;
+    }
+    --w.left;
+    const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(pts, po, 0, 0);
+    const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 16, 0, 0);
+    const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 32, 0, 0);
+    const u32x4 t3 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 48, 0, 0);
+    dconsider(b, qxy, qz, t0, po);
+    dconsider(b, qxy, qz, t1, po + 16);
+    dconsider(b, qxy, qz, t2, po + 32);
+    dconsider(b, qxy, qz, t3, po + 48);
+    limit2 = fminf(limit2, b.d);
+    // beyond this chunk (in walking direction) every point of the cell is at least `gap` away in x
+    const float gap = (w.back ? qxy.x - __uint_as_float(t0.x) : __uint_as_float(t3.x) - qxy.x) - x_slack;
+    if (gap > 0.0f && gap * gap > limit2) w.left = 0;
+}
+
 struct DDiag {       // diagnostic launches only: per-lane step counts and two clock stamps
     uint32_t own = 0, r1_cells = 0, r1_scans = 0, far_rows = 0, far_scans = 0;
     unsigned long long t_near = 0, t_far = 0;
@@ -258,10 +304,13 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
     dense_seed(rs, q, seed_pos, b, limit2);
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
-    {
-        if (kDiag) dg->own = (se.y - se.x + 3) / 4;
-        dscan_range(b, rs.pts, se.x * 16u, se.y * 16u, qxy, qz);
-        limit2 = fminf(limit2, b.d);
+    const float x_slack = g.cell * 3.0e-5f;
+    const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
+    DWalk w;
+    dwalk_open(w, se, right_half);
+    while (w.left > 0) {
+        if (kDiag) ++dg->own;
+        dwalk_step(w, b, rs.pts, qxy, qz, x_slack, limit2);
     }
     // ---- ring 1: only the cells whose box can still hold something closer.  A neighbour at
     // offset (dx,dy,dz) needs every non-zero axis offset's face to be within the limit, so when
@@ -286,17 +335,14 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     mask &= occ;         // empty cells are never opened
     // flat loop: a trip moves on to the next plausible cell and/or scores 4 candidates.  The range
     // of the cell after the current one is already in flight (nse) while the current one is scored.
-    uint32_t po = 0, pe = 0;
+    w.left = 0;
     u32x2 nse = {0u, 0u};
     float nlb2 = 0.0f;
-    bool nvalid = false;
+    bool nvalid = false, nback = false;
     for (;;) {
-        if (po >= pe) {
+        if (w.left <= 0) {
             if (!nvalid && !mask) break;
-            if (nvalid && nlb2 <= limit2) {   // (the limit may have tightened since that range was asked for)
-                po = nse.x * 16u;
-                pe = nse.y * 16u;
-            }
+            if (nvalid && nlb2 <= limit2) dwalk_open(w, nse, nback);   // (the limit may have tightened since that range was asked for)
             nvalid = false;
             if (mask) {
                 if (kDiag) ++dg->r1_cells;
@@ -309,14 +355,13 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
                     nse = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)idx * 4u, 0, 0);
                     nlb2 = lb2;
                     nvalid = true;
+                    nback = dx == 0 ? true : (dx == 1 ? right_half : false);   // a cell to the left is read from its right end
                 }
             }
         }
-        if (po < pe) {
+        if (w.left > 0) {
             if (kDiag) ++dg->r1_scans;
-            dscan4(b, rs.pts, po, qxy, qz);
-            po += 64;
-            limit2 = fminf(limit2, b.d);
+            dwalk_step(w, b, rs.pts, qxy, qz, x_slack, limit2);
         }
     }
     return occ;
@@ -444,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
 // gate, accumulate (same contract and summation order as k_icp_fused).  kDiag: the diagnostic
 // instantiation (RSREG_WAVE_TIMES) also writes 8 clock stamps per wave.
 template <bool kDiag>
-__global__ __launch_bounds__(kTile) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
+__global__ __launch_bounds__(kTile, 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev)
 {

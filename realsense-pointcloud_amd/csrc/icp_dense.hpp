@@ -206,10 +206,12 @@ struct DWalk {
     uint32_t cur, lo;   // forward: next chunk starts at cur; backward: the chunk before cur; lo = the cell's first byte
     int left;           // chunks still to read (0: nothing)
     bool back;
+    float yz2;          // what every point of this cell is away from the query in y and z at least, squared
 };
 
-__device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back)
+__device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back, float yz2)
 {
+    w.yz2 = yz2;
     w.lo = se.x * 16u;
     w.left = (int)((se.y - se.x + 3u) >> 2);
     w.back = back;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void dwalk_step(DWalk &w, DBest &b, __amdgpu_buffer_r
     limit2 = fminf(limit2, b.d);
     // beyond this chunk (in walking direction) every point of the cell is at least `gap` away in x
     const float gap = (w.back ? qxy.x - __uint_as_float(t0.x) : __uint_as_float(t3.x) - qxy.x) - x_slack;
-    if (gap > 0.0f && gap * gap > limit2) w.left = 0;
+    if (gap > 0.0f && gap * gap + w.yz2 > limit2) w.left = 0;
 }
 
 struct DDiag {       // diagnostic launches only: per-lane step counts and two clock stamps
@@ -307,7 +309,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     const float x_slack = g.cell * 3.0e-5f;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
     DWalk w;
-    dwalk_open(w, se, right_half);
+    dwalk_open(w, se, right_half, 0.0f);
     while (w.left > 0) {
         if (kDiag) ++dg->own;
         dwalk_step(w, b, rs.pts, qxy, qz, x_slack, limit2);
@@ -337,12 +339,12 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     // of the cell after the current one is already in flight (nse) while the current one is scored.
     w.left = 0;
     u32x2 nse = {0u, 0u};
-    float nlb2 = 0.0f;
+    float nlb2 = 0.0f, nyz2 = 0.0f;
     bool nvalid = false, nback = false;
     for (;;) {
         if (w.left <= 0) {
             if (!nvalid && !mask) break;
-            if (nvalid && nlb2 <= limit2) dwalk_open(w, nse, nback);   // (the limit may have tightened since that range was asked for)
+            if (nvalid && nlb2 <= limit2) dwalk_open(w, nse, nback, nyz2);   // (the limit may have tightened since that range was asked for)
             nvalid = false;
             if (mask) {
                 if (kDiag) ++dg->r1_cells;
@@ -354,6 +356,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
                     const int idx = base + (dz - 1) * g.sxy + (dy - 1) * g.sx + (dx - 1);
                     nse = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)idx * 4u, 0, 0);
                     nlb2 = lb2;
+                    nyz2 = (sel3(gy0, gy1, gy2, dy) + sel3(gz0, gz1, gz2, dz)) * cell2;
                     nvalid = true;
                     nback = dx == 0 ? true : (dx == 1 ? right_half : false);   // a cell to the left is read from its right end
                 }

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
 // gate, accumulate (same contract and summation order as k_icp_fused).  kDiag: the diagnostic
 // instantiation (RSREG_WAVE_TIMES) also writes 8 clock stamps per wave.
 template <bool kDiag>
-__global__ __launch_bounds__(kTile, 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
+__global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev)
 {

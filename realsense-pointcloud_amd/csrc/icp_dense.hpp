@@ -3,8 +3,10 @@
 // When the grid over the target's bounding box has a bounded number of cells (a room-scale
 // depth-camera cloud at ~1 cm cells: ~10^7 cells, tens of MB out of 288 GB of HBM), the
 // engine keeps `start[cell]` for EVERY cell instead of hashing the occupied ones:
-//   * points are sorted by linear cell id (x fastest), so the cells x-1, x, x+1 of one (y, z)
-//     row are one contiguous run of points;
+//   * points are sorted by linear cell id (x fastest) and by x inside a cell, so the cells
+//     x-1, x, x+1 of one (y, z) row are one contiguous, x-sorted run of points -- a search walks
+//     a cell from the end nearer to the query and stops once the x distance alone is too large;
+//   * a word per cell says which of its 27 neighbours hold points: empty cells are never opened;
 //   * a cell lookup is one 8-byte load, an empty cell costs no hash probe;
 //   * the table has a one-cell border of empties, so neighbour offsets need no bounds checks.
 // Clouds whose box is too large for the table keep the brick-hash index (icp_kernels.hpp).

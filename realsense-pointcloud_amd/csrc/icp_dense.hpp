@@ -400,6 +400,10 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
     const float sr = sqrtf(rem) + kCellMargin + 1e-4f, fx = q.ux - (float)q.cx;
     const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), (float)g.max_ring), kr = (int)fminf(fmaxf(sr + fx, 0.0f), (float)g.max_ring);
     const int xa = max(q.cx - kl, 0), xb = min(q.cx + kr, g.nx - 1);
+    // a row is one x-sorted run of points: it is walked like a cell, from the end nearer to the
+    // query, and left once the x distance alone no longer fits the budget
+    const float yz2 = (ay * ay + az * az) * (g.cell * g.cell), x_slack = g.cell * 3.0e-5f;
+    DWalk w;
     if (!central) {
         const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
         const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
@@ -413,8 +417,10 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
         const uint32_t s1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + min(r0, xb + 1)) * 4u, 0, 0);
         const uint32_t e1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
         if (kDiag) dg->far_scans += (e0 - s0 + 3) / 4 + (e1 - s1 + 3) / 4;
-        dscan_range(b, rs.pts, s0 * 16u, e0 * 16u, qxy, q.qz);
-        dscan_range(b, rs.pts, s1 * 16u, e1 * 16u, qxy, q.qz);
+        dwalk_open(w, u32x2{s0, e0}, true, yz2);    // the part to the left, from its right end
+        while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
+        dwalk_open(w, u32x2{s1, e1}, false, yz2);   // the part to the right, from its left end
+        while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
     }
     limit2 = fminf(limit2, b.d);
 }

@@ -147,15 +147,27 @@ template <int N> RSREG_HD inline void jacobi_svd(const double *A, SvdResult<N> &
 // Same operations in the same order as the generic template above.
 RSREG_HD inline double pick3(double a0, double a1, double a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
 
-RSREG_HD inline void jacobi_svd3(const double *A, SvdResult<3> &out)
+// `v0` (optional): an orthogonal matrix to start from, e.g. the V of a nearby matrix (the
+// cross-covariances of consecutive ICP iterations differ little: two or three sweeps then do
+// what takes six from the identity).  Starting from the identity, W = A exactly as before.
+RSREG_HD inline void jacobi_svd3(const double *A, SvdResult<3> &out, const double *v0 = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int N = 3;
     double W[9], V[9];
+    if (v0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) W[i] = A[i];
+        for (int i = 0; i < 9; ++i) V[i] = v0[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) W[i * 3 + j] = (A[i * 3] * V[j] + A[i * 3 + 1] * V[3 + j]) + A[i * 3 + 2] * V[6 + j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) W[i] = A[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
     for (int sweep = 0; sweep < 64; ++sweep) {
         bool rotated = false;
 #pragma unroll
@@ -280,7 +292,8 @@ template <int N> inline void svd_solve(const double *A, const double *b, double 
 
 // Eigen::umeyama(src, dst, with_scaling = false) from the 17 sums of an ICP iteration
 // (layout: include/rsreg.h RSREG_NUM_SUMS).  Returns false when n < 1.
-RSREG_HD inline bool umeyama_from_sums(const double *sums, Mat4f &T)
+// `v_warm` (optional, 9 doubles, in/out): the V of the previous solve of the same alignment
+RSREG_HD inline bool umeyama_from_sums(const double *sums, Mat4f &T, double *v_warm = nullptr)
 {
 #pragma clang fp contract(off)
     const double n = sums[0];
@@ -290,7 +303,11 @@ RSREG_HD inline bool umeyama_from_sums(const double *sums, Mat4f &T)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = sums[7 + i * 3 + j] / n - mu_q[i] * mu_p[j];
     SvdResult<3> r;
-    jacobi_svd3(sigma, r);
+    jacobi_svd3(sigma, r, v_warm);
+    if (v_warm) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v_warm[i] = r.V[i];
+    }
     double S[3] = {1, 1, 1};
     if (det3(r.U) * det3(r.V) < 0) S[2] = -1;
     double R[9];

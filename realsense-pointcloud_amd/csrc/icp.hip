@@ -721,6 +721,7 @@ int run_device_loop(rsreg_ctx *ctx)
     std::memset(h, 0, sizeof(IcpDevState) + 16);
     h->t_inc = to_mat34(Mat4f::identity());
     h->final_t = s.final_t;
+    for (int k = 0; k < 9; ++k) h->svd_v[k] = (k % 4 == 0) ? 1.0 : 0.0;
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState) + 16, hipMemcpyHostToDevice, ctx->stream));
     const int iters = std::max(1, s.prm.max_iterations);
     for (int it = 0; it < iters; ++it) {
@@ -773,7 +774,7 @@ int update_from_sums(rsreg_ctx *ctx, const double *sums, int *done)
         *done = 1;
         return RSREG_OK;
     }
-    umeyama_from_sums(sums, s.t_inc);
+    umeyama_from_sums(sums, s.t_inc, s.svd_v);
     s.pending_transform = true;
     s.final_t = mul(s.t_inc, s.final_t);
     s.iterations++;

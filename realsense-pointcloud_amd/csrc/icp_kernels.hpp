@@ -62,6 +62,7 @@ struct IcpDevState {
     double sums_last[RSREG_NUM_SUMS];
     double cur_mse;
     unsigned long long ncorr;
+    double svd_v[9];             // V of the previous solve: where the next Jacobi SVD starts
 };
 
 RSREG_HD inline Mat34 to_mat34(const Mat4f &T)
@@ -878,7 +879,7 @@ __device__ __forceinline__ void icp_solve_step(const double *sums, IcpDevState *
         return;
     }
     Mat4f t;
-    umeyama_from_sums(s, t);
+    umeyama_from_sums(s, t, st->svd_v);
     st->t_inc = to_mat34(t);
     st->apply = 1;
     st->final_t = mul(t, st->final_t);

@@ -91,6 +91,7 @@ struct IcpState {
     double prev_mse = 0, cur_mse = 0;
     uint64_t ncorr = 0;
     double sums_last[RSREG_NUM_SUMS] = {0};
+    double svd_v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // V of the previous Umeyama solve (warm start of the next)
     bool have_search = false;     // corr buffers hold the current iteration's search
     bool pending_transform = false;  // fused mode: t_inc not yet applied to d_cur
     double ms_nn = 0, ms_reduce = 0, ms_transform = 0;

@@ -44,3 +44,10 @@ def test_bench_multi_rank_path_with_one_rank():
              str(29600 + os.getpid() % 300), "bench.py", "--gpus", "1", "--size", "50k", "--steps", "2", "--warmup", "1",
              "--no-cpu-baseline", "--force-dist"])
     assert j["n_gpus"] == 1 and j["value"] > 0
+
+
+def test_device_resident_inputs_match_host_inputs():
+    """rsreg_icp_set_{source,target}_device with record strides 12, 16 and 32 (tests/device_inputs_check.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "device_inputs_check.py")], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "device inputs ok" in r.stdout, r.stderr[-3000:]

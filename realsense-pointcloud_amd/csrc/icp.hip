@@ -188,6 +188,8 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.n_pts = p.n_points;
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
     g.nbr = ctx->d_nbr.as<uint32_t>();
+    // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
+    g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
     return g;
 }
 

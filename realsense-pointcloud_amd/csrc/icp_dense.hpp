@@ -34,6 +34,8 @@ struct DenseDev {
     const float4 *pts;       // sorted target points followed by 4 far-away sentinels
     uint32_t n_pts;          // sorted target points (without the sentinels)
     uint32_t table_bytes;
+    float margin;            // slack (in cells) on every geometric lower bound: covers the float rounding of
+                             // cell assignment, which grows with the grid (6e-7 x its largest dimension, >= 0.004)
     const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
 };
 
@@ -320,9 +322,9 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     // offset (dx,dy,dz) needs every non-zero axis offset's face to be within the limit, so when
     // no face passes (the common case) the whole ring is skipped with six compares.
     const float lim_c = limit2 / cell2;   // limit in squared cell units (the gaps carry the safety margin)
-    float gx0 = axis_gap(q.ux, q.cx - 1, q.cx - 1), gx2 = axis_gap(q.ux, q.cx + 1, q.cx + 1);
-    float gy0 = axis_gap(q.uy, q.cy - 1, q.cy - 1), gy2 = axis_gap(q.uy, q.cy + 1, q.cy + 1);
-    float gz0 = axis_gap(q.uz, q.cz - 1, q.cz - 1), gz2 = axis_gap(q.uz, q.cz + 1, q.cz + 1);
+    float gx0 = axis_gap(q.ux, q.cx - 1, q.cx - 1, g.margin), gx2 = axis_gap(q.ux, q.cx + 1, q.cx + 1, g.margin);
+    float gy0 = axis_gap(q.uy, q.cy - 1, q.cy - 1, g.margin), gy2 = axis_gap(q.uy, q.cy + 1, q.cy + 1, g.margin);
+    float gz0 = axis_gap(q.uz, q.cz - 1, q.cz - 1, g.margin), gz2 = axis_gap(q.uz, q.cz + 1, q.cz + 1, g.margin);
     gx0 *= gx0; gx2 *= gx2; gy0 *= gy0; gy2 *= gy2; gz0 *= gz0; gz2 *= gz2;
     const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis: 0 is always a valid lower bound
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
@@ -375,7 +377,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
 // does this query still need rings >= 2 after rings 0-1 ?
 __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
 {
-    const float reach = (1.0f - kCellMargin) * g.cell;   // ring 1 proves everything up to here
+    const float reach = (1.0f - g.margin) * g.cell;   // ring 1 proves everything up to here
     return g.max_ring >= 2 && limit2 > reach * reach;
 }
 
@@ -391,13 +393,13 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
 {
     const int y = q.cy + dy, z = q.cz + dz;
     if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
-    const float ay = axis_gap(q.uy, y, y), az = axis_gap(q.uz, z, z);
+    const float ay = axis_gap(q.uy, y, y, g.margin), az = axis_gap(q.uz, z, z, g.margin);
     const float rem = limit2 * inv_cell2 - (ay * ay + az * az);   // budget left for the x gap, squared cells
     if (rem < 0.0f) return;
     if (kDiag) ++dg->far_rows;
     const int row = (int)dense_cell_id(g, 0, y, z);
     // cells cx-kl .. cx+kr are the ones whose x gap fits the budget (gap = fx + k - 1 to the left, k - fx to the right)
-    const float sr = sqrtf(rem) + kCellMargin + 1e-4f, fx = q.ux - (float)q.cx;
+    const float sr = sqrtf(rem) + g.margin + 1e-4f, fx = q.ux - (float)q.cx;
     const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), (float)g.max_ring), kr = (int)fminf(fmaxf(sr + fx, 0.0f), (float)g.max_ring);
     const int xa = max(q.cx - kl, 0), xb = min(q.cx + kr, g.nx - 1);
     // a row is one x-sorted run of points: it is walked like a cell, from the end nearer to the
@@ -433,7 +435,7 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
     const float inv_cell2 = 1.0f / (g.cell * g.cell);
     for (int rho = 0; rho <= g.max_ring; ++rho) {
         if (rho >= 2) {   // a row at distance rho is at least rho - 1 cells away on one axis
-            const float reach = ((float)(rho - 1) - kCellMargin) * g.cell;
+            const float reach = ((float)(rho - 1) - g.margin) * g.cell;
             if (limit2 <= reach * reach) break;
         }
         const bool central = rho <= 1;

@@ -516,10 +516,10 @@ __device__ __forceinline__ bool brick_lookup(const GridDev &g, int bx, int by, i
 
 // lower bound (in cells) on the distance along one axis from a query at in-grid position u
 // (cell units) to cells lo..hi; kCellMargin absorbs the float rounding of cell assignment
-__device__ __forceinline__ float axis_gap(float u, int lo, int hi)
+__device__ __forceinline__ float axis_gap(float u, int lo, int hi, float margin = kCellMargin)
 {
     const float a = (float)lo - u, b = u - (float)(hi + 1);
-    return fmaxf(fmaxf(a, b) - kCellMargin, 0.0f);
+    return fmaxf(fmaxf(a, b) - margin, 0.0f);
 }
 
 // bits of a 4x4x4 brick whose local coordinates lie in [x0,x1] x [y0,y1] x [z0,z1] (all in 0..3)

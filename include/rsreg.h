@@ -239,7 +239,7 @@ int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
                     const float *guess, const rsreg_ndt_params *params, rsreg_ndt_result *result,
                     void *aligned_out, size_t out_stride);
 /* One score/gradient/Hessian pass at pose p = [tx ty tz rx ry rz] (tests; the unit an
- * N-GPU run all-reduces: 1 + 6 + 36 doubles). */
+ * N-GPU run all-reduces; on the wire 1 + 6 + 21 doubles, the Hessian being symmetric). */
 int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
                           int is_dense, const double pose[6], double *score, double gradient[6],
                           double hessian[36]);
@@ -251,7 +251,8 @@ int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_ico
 /* One process per GPU.  Rank 0 calls rsreg_comm_unique_id, the caller ships the 128 bytes
  * to every rank (any side channel, e.g. torch.distributed broadcast over gloo), every rank
  * calls rsreg_comm_init.  After that rsreg_icp_align / rsreg_ndt_align all-reduce their
- * sums (17 / 43 doubles per pass) over RCCL on the ctx stream; every rank then runs the
+ * sums (17 / 28 doubles per pass: NDT ships the score, the gradient and the upper triangle
+ * of the Hessian) over RCCL on the ctx stream; every rank then runs the
  * same host solve on identical numbers, so no broadcast of the transform is needed. */
 #define RSREG_UNIQUE_ID_BYTES 128
 int rsreg_comm_unique_id(uint8_t id[RSREG_UNIQUE_ID_BYTES]);
@@ -259,6 +260,15 @@ int rsreg_comm_init(rsreg_ctx *ctx, const uint8_t id[RSREG_UNIQUE_ID_BYTES], int
 int rsreg_comm_destroy(rsreg_ctx *ctx);
 /* All-reduce (sum) `count` doubles in place across the ranks of ctx's communicator. */
 int rsreg_comm_allreduce_f64(rsreg_ctx *ctx, double *host_buf, int count);
+
+/* ---- PCD files: the LZF coder of "DATA binary_compressed" bodies (host only, no ctx) ------ */
+/* pcl::io::loadPCDFile / savePCDFileBinaryCompressed as reached from main.cpp:53,81,87: the body
+ * is u32 compressed size, u32 uncompressed size, then one LZF stream over the fields laid out one
+ * after the other.  encode/decode return the number of bytes written, 0 on failure (capacity
+ * too small, malformed stream). */
+size_t rsreg_lzf_max_encoded_size(size_t n);
+size_t rsreg_lzf_encode(const void *in, size_t n, void *out, size_t capacity);
+size_t rsreg_lzf_decode(const void *in, size_t n, void *out, size_t capacity);
 
 /* ---- introspection (tests, bench) --------------------------------------------------- */
 typedef struct rsreg_grid_info {

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../rsreg.h"
+#include "lzf.hpp"
 
 namespace rsreg {
 
@@ -316,7 +317,8 @@ void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, 
     out.is_dense = dense;
 }
 
-// ---- pcl::io: PCD files with FIELDS x y z rgb (ascii or binary), as the reference reads/writes
+// ---- pcl::io: PCD files with FIELDS x y z rgb (ascii, binary, binary_compressed), as the reference reads/writes
+// (src/main.cpp:53,81,87)
 namespace io {
 
 inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
@@ -385,8 +387,28 @@ inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
             if (ic >= 0) std::memcpy(&p.rgba, r + off[ic], 4);
             if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) dense = false;
         }
+    } else if (data_mode == "binary_compressed") {
+        // u32 compressed size, u32 uncompressed size, LZF stream of the fields one after the other
+        uint32_t csize = 0, usize = 0;
+        f.read(reinterpret_cast<char *>(&csize), 4);
+        f.read(reinterpret_cast<char *>(&usize), 4);
+        size_t rec = 0;
+        std::vector<size_t> foff(fields.size());
+        for (size_t k = 0; k < fields.size(); ++k) { foff[k] = rec * n; rec += (size_t)sizes[k]; }
+        if (!f || (size_t)usize != rec * n) return -4;
+        std::vector<uint8_t> comp(csize), soa(usize);
+        f.read(reinterpret_cast<char *>(comp.data()), (std::streamsize)csize);
+        if (!f || (usize && lzf::decode(comp.data(), csize, soa.data(), usize) != usize)) return -4;
+        for (size_t i = 0; i < n; ++i) {
+            PointXYZRGB &p = cloud.points[i];
+            std::memcpy(&p.x, soa.data() + foff[ix] + 4 * i, 4);
+            std::memcpy(&p.y, soa.data() + foff[iy] + 4 * i, 4);
+            std::memcpy(&p.z, soa.data() + foff[iz] + 4 * i, 4);
+            if (ic >= 0) std::memcpy(&p.rgba, soa.data() + foff[ic] + 4 * i, 4);
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) dense = false;
+        }
     } else {
-        return -3;  // binary_compressed is not supported yet
+        return -3;
     }
     cloud.is_dense = dense;
     return 0;
@@ -403,6 +425,33 @@ inline int savePCDFileBinary(const std::string &path, const PointCloud<PointXYZR
         f.write(reinterpret_cast<const char *>(&p.x), 12);
         f.write(reinterpret_cast<const char *>(&p.rgba), 4);
     }
+    return f ? 0 : -1;
+}
+
+// pcl::io::savePCDFileBinaryCompressed: same header, DATA binary_compressed, LZF over the SoA body
+inline int savePCDFileBinaryCompressed(const std::string &path, const PointCloud<PointXYZRGB> &cloud)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return -1;
+    const size_t n = cloud.size();
+    std::vector<uint8_t> soa(16 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const PointXYZRGB &p = cloud.points[i];
+        std::memcpy(soa.data() + 4 * i, &p.x, 4);
+        std::memcpy(soa.data() + 4 * (n + i), &p.y, 4);
+        std::memcpy(soa.data() + 4 * (2 * n + i), &p.z, 4);
+        std::memcpy(soa.data() + 4 * (3 * n + i), &p.rgba, 4);
+    }
+    std::vector<uint8_t> comp(lzf::max_encoded_size(soa.size()));
+    const uint32_t usize = (uint32_t)soa.size();
+    const uint32_t csize = (uint32_t)lzf::encode(soa.data(), soa.size(), comp.data(), comp.size());
+    if (usize && !csize) return -1;
+    f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+      << "WIDTH " << cloud.width << "\nHEIGHT " << cloud.height << "\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n
+      << "\nDATA binary_compressed\n";
+    f.write(reinterpret_cast<const char *>(&csize), 4);
+    f.write(reinterpret_cast<const char *>(&usize), 4);
+    f.write(reinterpret_cast<const char *>(comp.data()), csize);
     return f ? 0 : -1;
 }
 

@@ -69,8 +69,20 @@ _PCD_TYPES = {("F", 4): "<f4", ("F", 8): "<f8", ("U", 1): "u1", ("U", 2): "<u2",
               ("I", 1): "i1", ("I", 2): "<i2", ("I", 4): "<i4"}
 
 
+def _lzf(fn, data, capacity):
+    """LZF coder of the C ABI (include/rsreg/lzf.hpp through librsreg.so; host code, no GPU)."""
+    import ctypes as C
+
+    from . import lib as _l
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty(max(capacity, 1), np.uint8)
+    n = getattr(_l.lib(), fn)(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, capacity)
+    return out[:n].tobytes()
+
+
 def load_pcd(path):
-    """Read an ASCII or binary (uncompressed) .pcd with x y z [rgb|rgba] fields."""
+    """Read an ASCII, binary or binary_compressed .pcd with x y z [rgb|rgba] fields
+    (pcl::io::loadPCDFile, src/main.cpp:81)."""
     with open(path, "rb") as f:
         raw = f.read()
     hdr = {}
@@ -105,6 +117,17 @@ def load_pcd(path):
         dt = np.dtype([(name, _PCD_TYPES[(types[k], sizes[k])]) for k, name in enumerate(fields)])
         arr = np.frombuffer(raw, dtype=dt, count=n, offset=pos)
         col = {name: arr[name] for name in fields}
+    elif mode == "binary_compressed":
+        # u32 compressed size, u32 uncompressed size, one LZF stream over the fields laid out
+        # one after the other (all x, all y, ...)
+        csize, usize = np.frombuffer(raw, "<u4", count=2, offset=pos)
+        body = _lzf("rsreg_lzf_decode", raw[pos + 8:pos + 8 + int(csize)], int(usize))
+        if len(body) != int(usize) or int(usize) != n * sum(sizes):
+            raise ValueError("corrupt binary_compressed PCD body")
+        col, off = {}, 0
+        for k, name in enumerate(fields):
+            col[name] = np.frombuffer(body, _PCD_TYPES[(types[k], sizes[k])], count=n, offset=off)
+            off += n * sizes[k]
     else:
         raise ValueError("unsupported PCD DATA mode: " + mode)
     pts = np.zeros(n, POINT_DTYPE)
@@ -120,18 +143,29 @@ def load_pcd(path):
     return PointCloud(pts, width=width, height=height, is_dense=dense)
 
 
-def save_pcd(path, cloud, binary=True):
-    """pcl::io::savePCDFileBinary layout: FIELDS x y z rgb, SIZE 4 4 4 4, TYPE F F F F."""
+def save_pcd(path, cloud, binary=True, compressed=False):
+    """pcl::io::savePCDFileBinary / savePCDFileBinaryCompressed / savePCDFileASCII layout:
+    FIELDS x y z rgb, SIZE 4 4 4 4, TYPE F F F F (src/main.cpp:53,87)."""
     n = len(cloud)
+    if compressed:
+        binary = True
     hdr = (
         "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\n"
         "TYPE F F F F\nCOUNT 1 1 1 1\nWIDTH %d\nHEIGHT %d\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n"
-        % (cloud.width, cloud.height, n, "binary" if binary else "ascii")
+        % (cloud.width, cloud.height, n, "binary_compressed" if compressed else ("binary" if binary else "ascii"))
     )
     p = cloud.points
     with open(path, "wb") as f:
         f.write(hdr.encode("ascii"))
-        if binary:
+        if compressed:
+            soa = b"".join(np.ascontiguousarray(p[k]).tobytes() for k in ("x", "y", "z", "rgba"))
+            from . import lib as _l
+            body = _lzf("rsreg_lzf_encode", soa, int(_l.lib().rsreg_lzf_max_encoded_size(len(soa))))
+            if soa and not body:
+                raise ValueError("LZF encoding failed")
+            f.write(np.array([len(body), len(soa)], "<u4").tobytes())
+            f.write(body)
+        elif binary:
             rec = np.zeros(n, np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgb", "<u4")]))
             rec["x"], rec["y"], rec["z"], rec["rgb"] = p["x"], p["y"], p["z"], p["rgba"]
             f.write(rec.tobytes())

@@ -117,22 +117,6 @@ double cell_cap_from_env()
     return 0.014;   // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
-int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
-{
-    hipError_t e = ctx->h_stage.reserve(n * 12 + 16);
-    if (e != hipSuccess) return fail(ctx, RSREG_ERR_ALLOC, "pinned staging", e);
-    float *dst = ctx->h_stage.as<float>();
-    const char *src = static_cast<const char *>(points);
-    host_parallel_for(n, [=](size_t lo, size_t hi) {
-        if (stride == 12) {
-            std::memcpy(dst + 3 * lo, src + 12 * lo, (hi - lo) * 12);
-        } else {
-            for (size_t i = lo; i < hi; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
-        }
-    });
-    return RSREG_OK;
-}
-
 // bounding box + count of the finite points of a device-resident cloud (one host sync)
 int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, float mn[3], float mx[3], uint32_t *nfin)
 {
@@ -190,6 +174,9 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.nbr = ctx->d_nbr.as<uint32_t>();
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
+    // how far the x order of a sorted run can be off: one 2^-16 bucket of the sort key, plus the float
+    // rounding of (x - ox) * inv_cell, which grows with the grid (ulp of the largest in-grid position)
+    g.x_slack = p.cell * (1.52587890625e-5f + 9.5367431640625e-7f * (float)std::max(p.dims[0], 1));
     return g;
 }
 
@@ -360,7 +347,8 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     gp.max_ring = max_ring;
     {
         const long long padded = (long long)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
-        if (padded <= dense_cell_budget()) return build_dense(ctx, d_pts, n, stride, max_dist, nfin, ev0, ev1);
+        // (the dense search addresses points by 32-bit byte offsets: 16 B x 2^28)
+        if (padded <= dense_cell_budget() && (unsigned long long)nfin + 4ull < (1ull << 28)) return build_dense(ctx, d_pts, n, stride, max_dist, nfin, ev0, ev1);
     }
 
     // ---- sort by (brick, cell in brick, xyz hash)
@@ -858,12 +846,14 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
-                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_comm};
+                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
     ctx->h_stage.release();
     ctx->h_ndt.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_ndt)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RSREG_OK;
@@ -1094,6 +1084,15 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         result->n_nn_launches = s.n_nn_launches;
         if (ctx->profiling) {
             result->ms_nn = sum_events(ctx, ctx->ev_nn);
+            if (std::getenv("RSREG_DUMP_NN_MS")) {   // dev: duration of every search launch of this call
+                std::fprintf(stderr, "[rsreg] search launches (us):");
+                for (auto &p : ctx->ev_nn) {
+                    float t = 0;
+                    (void)hipEventElapsedTime(&t, ctx->ev_pool[p.first], ctx->ev_pool[p.second]);
+                    std::fprintf(stderr, " %.1f", t * 1e3);
+                }
+                std::fprintf(stderr, "\n");
+            }
             result->ms_reduce = sum_events(ctx, ctx->ev_reduce);
             if (ctx->ev_reduce.empty())   // fused pipelines: everything between two consecutive search kernels
                 for (size_t k = 0; k + 1 < ctx->ev_nn.size(); ++k) {

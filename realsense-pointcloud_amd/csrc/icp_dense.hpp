@@ -36,6 +36,7 @@ struct DenseDev {
     uint32_t table_bytes;
     float margin;            // slack (in cells) on every geometric lower bound: covers the float rounding of
                              // cell assignment, which grows with the grid (6e-7 x its largest dimension, >= 0.004)
+    float x_slack;           // metres: slack on the x order of a sorted run (sort-key bucket + float rounding of the position)
     const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
 };
 
@@ -310,7 +311,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
     dense_seed(rs, q, seed_pos, b, limit2);
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
-    const float x_slack = g.cell * 3.0e-5f;
+    const float x_slack = g.x_slack;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
     DWalk w;
     dwalk_open(w, se, right_half, 0.0f);
@@ -404,7 +405,7 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
     const int xa = max(q.cx - kl, 0), xb = min(q.cx + kr, g.nx - 1);
     // a row is one x-sorted run of points: it is walked like a cell, from the end nearer to the
     // query, and left once the x distance alone no longer fits the budget
-    const float yz2 = (ay * ay + az * az) * (g.cell * g.cell), x_slack = g.cell * 3.0e-5f;
+    const float yz2 = (ay * ay + az * az) * (g.cell * g.cell), x_slack = g.x_slack;
     DWalk w;
     if (!central) {
         const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);

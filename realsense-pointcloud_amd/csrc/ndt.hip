@@ -174,13 +174,10 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
     pp.mode = mode;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
-        if (ctx->ev_pool.size() < 2) {
-            ctx->ev_pool.resize(2);
-            (void)hipEventCreate(&ctx->ev_pool[0]);
-            (void)hipEventCreate(&ctx->ev_pool[1]);
-        }
-        e0 = ctx->ev_pool[0];
-        e1 = ctx->ev_pool[1];
+        for (hipEvent_t &e : ctx->ev_ndt)
+            if (!e) (void)hipEventCreate(&e);
+        e0 = ctx->ev_ndt[0];
+        e1 = ctx->ev_ndt[1];
         (void)hipEventRecord(e0, ctx->stream);
     }
     k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
@@ -190,7 +187,7 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
     k_ndt_final_reduce<<<1, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks, ctx->d_ndt_out.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
-    if (ctx->nranks > 1) {
+    if (ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
         int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_ndt_out.as<double>(), kNdtAcc);
         if (rc) return rc;
     }
@@ -333,10 +330,8 @@ int step_length(NdtRun &r, const double *x, double *dir, double step_init, doubl
 
 int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
 {
-    RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
-    float *dst = ctx->h_stage.as<float>();
-    const char *src = static_cast<const char *>(source);
-    for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+    int rc_pack = pack_to_stage(ctx, source, n, stride);
+    if (rc_pack) return rc_pack;
     RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
@@ -344,7 +339,7 @@ int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
     if (n) {
-        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.ptr, dst, n * 12, hipMemcpyHostToDevice, ctx->stream));
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
         k_ndt_load_source<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(ctx->d_tmp.as<char>(), 12, (uint32_t)n,
                                                                                         ctx->d_ndt_src.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
@@ -393,11 +388,9 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     ctx->ndt_centroid.clear();
 
     // ---- upload xyz, bounding box of the finite points (pcl::getMinMax3D)
-    RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
     {
-        float *dst = ctx->h_stage.as<float>();
-        const char *src = static_cast<const char *>(points);
-        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+        int rc_pack = pack_to_stage(ctx, points, n, stride);
+        if (rc_pack) return rc_pack;
     }
     RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_misc.reserve(64 * 4));
@@ -443,12 +436,12 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
-    RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_ndt_seg.reserve(((size_t)nfin + 2) * 4));
     auto *keys = ctx->d_keys.as<unsigned long long>();
     auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
-    uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_cellpos.as<uint32_t>();
+    uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_ndt_seg.as<uint32_t>();
     k_ndt_keys<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, 12, (uint32_t)n, bp, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0;

@@ -152,6 +152,8 @@ struct rsreg_ctx {
     int ndt_n_voxels = 0;
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;
+    rsreg::DevBuf d_ndt_seg;      // first sorted point of every occupied leaf (NDT's own: d_cellpos belongs to the live ICP hash index)
+    hipEvent_t ev_ndt[2] = {nullptr, nullptr};   // NDT's own event pair (the pool's indices belong to an ICP begin..end)
     std::vector<double> ndt_mean_cov_icov;   // 21 per voxel (host copy)
     std::vector<int> ndt_counts;
     std::vector<float> ndt_centroid;         // 3 per voxel
@@ -197,6 +199,23 @@ template <typename F> inline void host_parallel_for(size_t n, F f)
     for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
     f((size_t)0, n / nt);
     for (auto &t : th) t.join();
+}
+
+// 32-byte (or any stride) AoS records -> packed xyz in the pinned staging buffer
+inline int pack_to_stage(rsreg_ctx *ctx, const void *points, size_t n, size_t stride)
+{
+    hipError_t e = ctx->h_stage.reserve(n * 12 + 16);
+    if (e != hipSuccess) return fail(ctx, RSREG_ERR_ALLOC, "pinned staging", e);
+    float *dst = ctx->h_stage.as<float>();
+    const char *src = static_cast<const char *>(points);
+    host_parallel_for(n, [=](size_t lo, size_t hi) {
+        if (stride == 12) {
+            std::memcpy(dst + 3 * lo, src + 12 * lo, (hi - lo) * 12);
+        } else {
+            for (size_t i = lo; i < hi; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+        }
+    });
+    return RSREG_OK;
 }
 
 #define RSREG_HIP(ctx, expr)                                              \

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp"]
+SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
 UNIQUE_ID_BYTES = 128
@@ -27,7 +27,7 @@ EXPORTS = [
     "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
-    "rsreg_icp_grid_info",
+    "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
 ]
 
 
@@ -91,7 +91,8 @@ def needs_build():
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "rsreg.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "rsreg.h"),
+                                                                os.path.join(ROOT, "include", "rsreg", "lzf.hpp")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -161,6 +162,11 @@ def lib():
     L.rsreg_comm_destroy.argtypes = [vp]
     L.rsreg_comm_allreduce_f64.argtypes = [vp, vp, i32]
     L.rsreg_icp_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    L.rsreg_lzf_max_encoded_size.argtypes = [sz]
+    L.rsreg_lzf_max_encoded_size.restype = sz
+    for f in ("rsreg_lzf_encode", "rsreg_lzf_decode"):
+        getattr(L, f).argtypes = [vp, sz, vp, sz]
+        getattr(L, f).restype = sz
     _lib = L
     return L
 

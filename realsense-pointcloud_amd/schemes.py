@@ -102,6 +102,7 @@ class IncrementalICP(RegistrationScheme):
         icp = b.icp()
         model = clouds[0]                 # aliases and grows the caller's frame 0
         self.transforms = []
+        self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
         for k in range(1, len(clouds)):
             voxel.setInputCloud(clouds[k])
             reduced = voxel.filter()
@@ -114,6 +115,7 @@ class IncrementalICP(RegistrationScheme):
             merged = model + moved
             model.points, model.width, model.height, model.is_dense = merged.points, merged.width, merged.height, merged.is_dense
             self.transforms.append(icp.getFinalTransformation())
+            self.merged_frames.append(k)
         return model
 
 

@@ -193,6 +193,7 @@ def main():
     # this process, so the number comes from the committed rocprofv3 passes of this same
     # command (profiles/*_traffic.json, collected per MI355X_MICROARCH.md's HBM section)
     traffic = None
+    traffic_source = None
     try:
         tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
         if tj:
@@ -201,6 +202,7 @@ def main():
             if (w.get("size") == a.size and w.get("iterations") == a.iterations and w.get("max_dist") == a.max_dist
                     and w.get("pipeline") == ("fused" if a.pipeline >= 1 else "staged") and world == 1 and kern in t["kernels"]):
                 traffic = t["kernels"][kern]["traffic_bytes_corrected"]
+                traffic_source = "profiles/%s (static: rocprofv3 --pmc passes of this command, not measured in this run)" % tj[-1]
     except Exception:  # noqa: BLE001
         traffic = None
     out = {
@@ -228,7 +230,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": kern,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
             "launches": n_launch,
         },
         "breakdown_ms_per_step": {

@@ -135,6 +135,10 @@ class Context {
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rsreg_ctx *get() const { return ctx_; }
+    // A context holds ONE ICP target index, ONE ICP source and ONE NDT voxel grid.  The object that
+    // uploaded each of them last is remembered here, so that a second registration object sharing
+    // the context (e.g. the default one) re-uploads its own clouds instead of silently using another's.
+    const void *icp_target_owner = nullptr, *icp_source_owner = nullptr, *ndt_target_owner = nullptr;
     static std::shared_ptr<Context> Default()
     {
         static std::shared_ptr<Context> ctx = std::make_shared<Context>(0);
@@ -185,14 +189,16 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     {
         if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
         rsreg_ctx *c = ctx_->get();
-        if (target_dirty_) {
+        if (target_dirty_ || ctx_->icp_target_owner != this) {
             check(rsreg_icp_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
                                        prm_.max_correspondence_distance), c);
             target_dirty_ = false;
+            ctx_->icp_target_owner = this;
         }
-        if (source_dirty_) {
+        if (source_dirty_ || ctx_->icp_source_owner != this) {
             check(rsreg_icp_set_source(c, source_->points.data(), source_->size(), sizeof(PointSource), source_->is_dense), c);
             source_dirty_ = false;
+            ctx_->icp_source_owner = this;
         }
         PointCloud<PointSource> tmp;
         detail::copy_aligned(*source_, tmp);
@@ -242,10 +248,11 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
     {
         if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
         rsreg_ctx *c = ctx_->get();
-        if (target_dirty_) {
+        if (target_dirty_ || ctx_->ndt_target_owner != this) {
             check(rsreg_ndt_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
                                        prm_.resolution), c);
             target_dirty_ = false;
+            ctx_->ndt_target_owner = this;
         }
         PointCloud<PointSource> tmp;
         detail::copy_aligned(*source_, tmp);

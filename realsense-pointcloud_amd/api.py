@@ -54,6 +54,8 @@ class Context:
         _l.check(_l.lib().rsreg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.device = device
+        # a context holds ONE ICP target index, ONE ICP source and ONE NDT voxel grid: who uploaded each last
+        self.icp_target_owner = self.icp_source_owner = self.ndt_target_owner = None
         if profiling:
             self.set_profiling(True)
 
@@ -175,7 +177,7 @@ class IterativeClosestPoint:
         L, h = _l.lib(), self.ctx.h
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
-        if self._tgt_dirty:
+        if self._tgt_dirty or self.ctx.icp_target_owner is not self:
             if isinstance(self._tgt, tuple):
                 _, p, n, s = self._tgt
                 _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
@@ -184,7 +186,8 @@ class IterativeClosestPoint:
                 dense = int(getattr(self._tgt, "is_dense", False))
                 _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
             self._tgt_dirty = False
-        if self._src_dirty:
+            self.ctx.icp_target_owner = self
+        if self._src_dirty or self.ctx.icp_source_owner is not self:
             if isinstance(self._src, tuple):
                 _, p, n, s = self._src
                 _l.check(L.rsreg_icp_set_source_device(h, p, n, s, 0), h)
@@ -194,6 +197,7 @@ class IterativeClosestPoint:
                 _l.check(L.rsreg_icp_set_source(h, p, n, s, dense), h)
             self._n_src = n
             self._src_dirty = False
+            self.ctx.icp_source_owner = self
 
     def align(self, guess=None):
         """icp.align(out[, guess]): returns the aligned cloud (source colours, xyz <- final * xyz)."""
@@ -293,11 +297,12 @@ class NormalDistributionsTransform:
     def _sync_target(self):
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
-        if self._tgt_dirty:
+        if self._tgt_dirty or self.ctx.ndt_target_owner is not self:
             keep, p, n, s = _records(self._tgt)
             _l.check(_l.lib().rsreg_ndt_set_target(self.ctx.h, p, n, s, int(getattr(self._tgt, "is_dense", False)),
                                                    self.params.resolution), self.ctx.h)
             self._tgt_dirty = False
+            self.ctx.ndt_target_owner = self
 
     def align(self, guess=None):
         self._sync_target()

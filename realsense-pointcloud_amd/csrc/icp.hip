@@ -565,7 +565,7 @@ unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
 {
     static const bool on = std::getenv("RSREG_WAVE_TIMES") != nullptr;
     if (!on) return nullptr;
-    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 128) != hipSuccess) return nullptr;
+    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 128 + (size_t)n * 4 + 64) != hipSuccess) return nullptr;
     return ctx->d_brick.as<unsigned long long>();
 }
 
@@ -1046,7 +1046,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
         if (ctx->grid.dense && ctx->n_work) {
             const size_t nw = (ctx->n_work + 63) / 64;
-            std::vector<unsigned long long> h(16 * nw);
+            std::vector<unsigned long long> h(16 * nw + (ctx->n_work + 1) / 2);   // wave records, then a uint32 of step counts per lane
             (void)hipMemcpy(h.data(), ctx->d_brick.ptr, h.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = std::fopen(wt_path, "wb")) {
                 std::fwrite(h.data(), 8, h.size(), f);

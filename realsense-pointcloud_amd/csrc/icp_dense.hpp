@@ -526,8 +526,9 @@ __global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4
                 q = make_float4(t.x, t.y, t.z, q.w);
                 cur[i] = q;
             }
-            const Best b = nn_query_dense<kDiag>(g, q.x, q.y, q.z, seed ? seed[i] : -1, &dg);
-            if (seed) seed[i] = b.pos;
+            const int seed_in = seed ? seed[i] : -1;
+            const Best b = nn_query_dense<kDiag>(g, q.x, q.y, q.z, seed_in, &dg);
+            if (seed && b.pos != seed_in) seed[i] = b.pos;   // (most matches do not change once the clouds have settled)
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
                 d2 = b.d2;
@@ -563,6 +564,10 @@ __global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4
             for (int k = 0; k < 5; ++k) w[5 + k] = (unsigned long long)mx[k] | ((unsigned long long)sm[k] << 32);
             for (int k = 10; k < 16; ++k) w[k] = 0;
         }
+        // per-lane step counts behind the wave records: own | ring-1 scans << 8 | far rows << 16 | far scans << 24
+        if (i < n)
+            reinterpret_cast<uint32_t *>(wave_times + 16ull * ((n + 63) / 64))[i] =
+                min(dg.own, 255u) | min(dg.r1_scans, 255u) << 8 | min(dg.far_rows, 255u) << 16 | min(dg.far_scans, 255u) << 24;
     }
 }
 

@@ -26,7 +26,47 @@ icp.params = api.icp_params(max_iterations=iters, criteria_mode=1, max_correspon
 icp.setInputSource(src)
 icp.setInputTarget(tgt)
 icp.align(guess)
-w = np.fromfile(path, dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+raw = np.fromfile(path, dtype=np.uint64)
+gi = icp.grid_info()
+nq = int(gi.n_source_distinct)
+nw = (nq + 63) // 64
+w = raw[:16 * nw].reshape(-1, 16).astype(np.int64)
+lane = raw[16 * nw:].view(np.uint32)[:nq]
+own, r1, frow, fscan = (lane & 255).astype(np.int64), (lane >> 8 & 255).astype(np.int64), (lane >> 16 & 255).astype(np.int64), (lane >> 24).astype(np.int64)
+near = own + r1
+far = 2 * frow + fscan            # a far row costs about two dependent loads besides its scans
+
+
+def wave_steps(v, order=None):
+    """Sum over waves of the slowest lane's steps (what a wave executes), for lanes taken in `order`."""
+    if order is not None:
+        v = v[order]
+    pad = (-len(v)) % 64
+    v = np.concatenate([v, np.zeros(pad, v.dtype)]).reshape(-1, 64)
+    return v.max(axis=1)
+
+
+cost = near + far
+print("lanes %d: steps per lane mean near %.2f far %.2f; lanes needing far rows %.2f %%" % (nq, near.mean(), far.mean(), 100.0 * (frow > 0).mean()))
+print("per-lane cost percentiles p50/p90/p99/p99.9/max: %s" % [int(np.percentile(cost, p)) for p in (50, 90, 99, 99.9, 100)])
+base = wave_steps(near).sum() + wave_steps(far).sum()
+print("wave-steps as launched: near %d + far %d (sum of lanes / 64 would be %d)" % (wave_steps(near).sum(), wave_steps(far).sum(), cost.sum() // 64))
+for win in (128, 512, 1024, 4096, 1 << 30):
+    key = (np.arange(nq) // win) * 100000 - np.minimum(cost, 99999)
+    o = np.argsort(key, kind="stable")
+    ws = wave_steps(cost, o)
+    print("lanes regrouped by cost inside windows of %d queries: wave-steps %d (%.2f x), slowest wave %d steps"
+          % (win, ws.sum(), base / max(ws.sum(), 1), ws.max()))
+for cap in (8, 12, 16, 24, 32):
+    k = np.maximum(1, np.ceil(cost / cap)).astype(np.int64)
+    k = np.minimum(1 << np.ceil(np.log2(k)).astype(np.int64), 64)
+    per = np.ceil(cost / k)
+    lanes = int(k.sum())
+    key = (np.arange(nq) // 1024) * 100000 - np.minimum(cost, 99999)
+    o = np.argsort(key, kind="stable")
+    v = np.repeat(per[o], k[o])
+    print("  + queries above %d steps split over 2..64 lanes: %d lanes (%.3f x), wave-steps %d (%.2f x), slowest wave %d steps"
+          % (cap, lanes, lanes / nq, wave_steps(v).sum(), base / wave_steps(v).sum(), wave_steps(v).max()))
 t0 = w[:, 0].min()
 span = (w[:, 4].max() - t0) / 100.0
 print("waves %d, kernel span %.1f us (launch avg by events %.1f us)" % (len(w), span, icp.result.ms_nn / icp.result.n_nn_launches * 1e3))

@@ -261,6 +261,47 @@ int rsreg_comm_destroy(rsreg_ctx *ctx);
 /* All-reduce (sum) `count` doubles in place across the ranks of ctx's communicator. */
 int rsreg_comm_allreduce_f64(rsreg_ctx *ctx, double *host_buf, int count);
 
+/* ---- device-resident clouds: the frame loop without leaving HBM ------------------------- */
+/* The reference's schemes run, per frame, ApproximateVoxelGrid::filter -> align (-> align) ->
+ * transformPointCloud x2 -> operator+ on host clouds (incremental_icp.hpp:54-64,
+ * icp_edge_based_registration.hpp:75-76,95-120, ndt_edge_based_registration.hpp:68-108).  A
+ * rsreg_cloud holds the records of one cloud in HBM (whole records, `stride` bytes each, plus
+ * width / height / is_dense); every step below takes and leaves its clouds there, so a frame is
+ * uploaded once and the merged cloud downloaded once.  A cloud belongs to the ctx it was created
+ * on; handles given to rsreg_icp_set_*_cloud must stay alive and unchanged until the align that
+ * uses them has returned. */
+typedef struct rsreg_cloud rsreg_cloud;
+int rsreg_cloud_create(rsreg_ctx *ctx, rsreg_cloud **out);
+int rsreg_cloud_destroy(rsreg_cloud *cloud);
+int rsreg_cloud_upload(rsreg_cloud *cloud, const void *points, size_t n, size_t stride, uint32_t width,
+                       uint32_t height, int is_dense);
+int rsreg_cloud_download(const rsreg_cloud *cloud, void *out, size_t capacity_records);
+int rsreg_cloud_info(const rsreg_cloud *cloud, size_t *n, size_t *stride, uint32_t *width, uint32_t *height,
+                     int *is_dense);
+const void *rsreg_cloud_device_ptr(const rsreg_cloud *cloud);
+int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
+/* ApproximateVoxelGrid::filter, same records in the same order as the host filter; in == out allowed */
+int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);
+/* pcl::transformPointCloud; in == out allowed */
+int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float transform[16], rsreg_cloud *out);
+/* PointCloud::operator+ : out = a followed by b (width = size, height = 1, is_dense = both); out may be a or b */
+int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b, rsreg_cloud *out);
+/* icp.setInputTarget / setInputSource / align on handles; aligned_out (nullable, may be the source
+ * cloud): the source records with xyz <- final * xyz and data[3] = 1 */
+int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud, double max_correspondence_distance);
+int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud);
+int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params,
+                          rsreg_icp_result *result, rsreg_cloud *aligned_out);
+/* ndt.setInputTarget / align on handles, and on raw device pointers */
+int rsreg_ndt_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud, double resolution);
+int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float *guess,
+                          const rsreg_ndt_params *params, rsreg_ndt_result *result, rsreg_cloud *aligned_out);
+int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense,
+                                double resolution);
+int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_t stride, int is_dense,
+                           const float *guess, const rsreg_ndt_params *params, rsreg_ndt_result *result,
+                           void *d_aligned_out);
+
 /* ---- PCD files: the LZF coder of "DATA binary_compressed" bodies (host only, no ctx) ------ */
 /* pcl::io::loadPCDFile / savePCDFileBinaryCompressed as reached from main.cpp:53,81,87: the body
  * is u32 compressed size, u32 uncompressed size, then one LZF stream over the fields laid out one

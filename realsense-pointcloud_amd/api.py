@@ -103,6 +103,73 @@ def default_context():
     return _default_ctx
 
 
+class DeviceCloud:
+    """A cloud resident in HBM (rsreg_cloud): whole records plus width / height / is_dense.  What the
+    reference's frame loop hands from step to step (filter -> align -> transformPointCloud -> operator+,
+    icp_edge_based_registration.hpp:75-120) without the records leaving the GPU."""
+
+    def __init__(self, cloud=None, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        _l.check(_l.lib().rsreg_cloud_create(self.ctx.h, C.byref(h)), self.ctx.h)
+        self.h = h
+        if cloud is not None:
+            self.upload(cloud)
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            _l.lib().rsreg_cloud_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, cloud):
+        pts = np.ascontiguousarray(cloud.points)
+        _l.check(_l.lib().rsreg_cloud_upload(self.h, pts.ctypes.data, len(pts), pts.dtype.itemsize, cloud.width, cloud.height,
+                                             int(cloud.is_dense)), self.ctx.h)
+        return self
+
+    def info(self):
+        n, s = C.c_size_t(0), C.c_size_t(0)
+        w, h, d = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+        _l.check(_l.lib().rsreg_cloud_info(self.h, C.byref(n), C.byref(s), C.byref(w), C.byref(h), C.byref(d)), self.ctx.h)
+        return n.value, s.value, w.value, h.value, bool(d.value)
+
+    def __len__(self):
+        return self.info()[0]
+
+    @property
+    def device_ptr(self):
+        return _l.lib().rsreg_cloud_device_ptr(self.h)
+
+    def download(self):
+        n, stride, w, h, dense = self.info()
+        assert stride == POINT_DTYPE.itemsize or n == 0
+        pts = np.zeros(n, POINT_DTYPE)
+        _l.check(_l.lib().rsreg_cloud_download(self.h, pts.ctypes.data, n), self.ctx.h)
+        return PointCloud(pts, width=w, height=h, is_dense=dense)
+
+    def copy(self):
+        out = DeviceCloud(ctx=self.ctx)
+        _l.check(_l.lib().rsreg_cloud_copy(self.ctx.h, self.h, out.h), self.ctx.h)
+        return out
+
+    def __add__(self, other):
+        """PointCloud::operator+ in HBM: self's records followed by other's."""
+        out = DeviceCloud(ctx=self.ctx)
+        _l.check(_l.lib().rsreg_cloud_concat(self.ctx.h, self.h, other.h, out.h), self.ctx.h)
+        return out
+
+    def append(self, other):
+        """PointCloud::operator+= in HBM (grows in place; the copy is of `other` only once there is room)."""
+        _l.check(_l.lib().rsreg_cloud_concat(self.ctx.h, self.h, other.h, self.h), self.ctx.h)
+        return self
+
+
 def icp_params(reference=False, **kw):
     p = _l.IcpParams()
     (_l.lib().rsreg_icp_params_reference if reference else _l.lib().rsreg_icp_params_default)(C.byref(p))
@@ -178,7 +245,9 @@ class IterativeClosestPoint:
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
         if self._tgt_dirty or self.ctx.icp_target_owner is not self:
-            if isinstance(self._tgt, tuple):
+            if isinstance(self._tgt, DeviceCloud):
+                _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
+            elif isinstance(self._tgt, tuple):
                 _, p, n, s = self._tgt
                 _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
             else:
@@ -188,7 +257,10 @@ class IterativeClosestPoint:
             self._tgt_dirty = False
             self.ctx.icp_target_owner = self
         if self._src_dirty or self.ctx.icp_source_owner is not self:
-            if isinstance(self._src, tuple):
+            if isinstance(self._src, DeviceCloud):
+                _l.check(L.rsreg_icp_set_source_cloud(h, self._src.h), h)
+                n = len(self._src)
+            elif isinstance(self._src, tuple):
                 _, p, n, s = self._src
                 _l.check(L.rsreg_icp_set_source_device(h, p, n, s, 0), h)
             else:
@@ -204,6 +276,12 @@ class IterativeClosestPoint:
         self._sync_inputs()
         g = _colmajor(guess)
         res = _l.IcpResult()
+        if isinstance(self._src, DeviceCloud):   # the aligned cloud stays in HBM too
+            out = DeviceCloud(ctx=self.ctx)
+            _l.check(_l.lib().rsreg_icp_align_cloud(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
+                                                    C.byref(res), out.h), self.ctx.h)
+            self.result = res
+            return out
         out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(self._n_src, POINT_DTYPE)
         _l.check(_l.lib().rsreg_icp_align(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
                                           C.byref(res), out.ctypes.data, out.dtype.itemsize), self.ctx.h)
@@ -298,17 +376,26 @@ class NormalDistributionsTransform:
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
         if self._tgt_dirty or self.ctx.ndt_target_owner is not self:
-            keep, p, n, s = _records(self._tgt)
-            _l.check(_l.lib().rsreg_ndt_set_target(self.ctx.h, p, n, s, int(getattr(self._tgt, "is_dense", False)),
-                                                   self.params.resolution), self.ctx.h)
+            if isinstance(self._tgt, DeviceCloud):
+                _l.check(_l.lib().rsreg_ndt_set_target_cloud(self.ctx.h, self._tgt.h, self.params.resolution), self.ctx.h)
+            else:
+                keep, p, n, s = _records(self._tgt)
+                _l.check(_l.lib().rsreg_ndt_set_target(self.ctx.h, p, n, s, int(getattr(self._tgt, "is_dense", False)),
+                                                       self.params.resolution), self.ctx.h)
             self._tgt_dirty = False
             self.ctx.ndt_target_owner = self
 
     def align(self, guess=None):
         self._sync_target()
-        keep, p, n, s = _records(self._src)
         g = _colmajor(guess)
         res = _l.NdtResult()
+        if isinstance(self._src, DeviceCloud):
+            out = DeviceCloud(ctx=self.ctx)
+            _l.check(_l.lib().rsreg_ndt_align_cloud(self.ctx.h, self._src.h, g.ctypes.data if g is not None else None,
+                                                    C.byref(self.params), C.byref(res), out.h), self.ctx.h)
+            self.result = res
+            return out
+        keep, p, n, s = _records(self._src)
         out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(n, POINT_DTYPE)
         _l.check(_l.lib().rsreg_ndt_align(self.ctx.h, p, n, s, int(getattr(self._src, "is_dense", False)),
                                           g.ctypes.data if g is not None else None, C.byref(self.params),
@@ -364,6 +451,10 @@ class ApproximateVoxelGrid:
         self._in = cloud
 
     def filter(self):
+        if isinstance(self._in, DeviceCloud):
+            out = DeviceCloud(ctx=self._in.ctx)
+            _l.check(_l.lib().rsreg_cloud_filter(self._in.ctx.h, self._in.h, self.leaf.ctypes.data, out.h), self._in.ctx.h)
+            return out
         pts = np.ascontiguousarray(self._in.points)
         out = np.zeros_like(pts)
         n_out = C.c_size_t(0)
@@ -379,6 +470,11 @@ class ApproximateVoxelGrid:
 
 def transformPointCloud(cloud, T, ctx=None):
     """pcl::transformPointCloud(in, out, Matrix4f): returns the transformed copy."""
+    if isinstance(cloud, DeviceCloud):
+        out = DeviceCloud(ctx=cloud.ctx)
+        t = _colmajor(T)
+        _l.check(_l.lib().rsreg_cloud_transform(cloud.ctx.h, cloud.h, t.ctypes.data, out.h), cloud.ctx.h)
+        return out
     ctx = ctx or default_context()
     pts = np.ascontiguousarray(cloud.points)
     out = np.empty_like(pts)

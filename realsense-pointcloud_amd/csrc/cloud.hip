@@ -1,0 +1,269 @@
+// cloud.hip — clouds that stay in HBM across the reference's frame loop (C ABI: include/rsreg.h,
+// "device-resident clouds").
+//
+// The reference's schemes run, per frame, ApproximateVoxelGrid::filter -> align (-> align) ->
+// transformPointCloud x2 -> operator+ (src/icp_edge_based_registration.hpp:75-76,95-120,
+// src/ndt_edge_based_registration.hpp:68-108, src/incremental_icp.hpp:54-64) on host clouds.
+// With cloud handles each of those steps takes and leaves its clouds in HBM: a frame is uploaded
+// once, the merged cloud is downloaded once, nothing else crosses PCIe (and no 32 -> 12 byte packing
+// on the host: the kernels read the 32-byte records as they are, through their stride).
+#include <cstring>
+
+#include "records.hpp"
+
+using namespace rsreg;
+
+struct rsreg_cloud {
+    rsreg_ctx *ctx = nullptr;
+    DevBuf buf;
+    size_t n = 0, stride = 32;
+    uint32_t width = 0, height = 1;
+    int is_dense = 0;
+};
+
+namespace rsreg {
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out);   // voxel.hip
+}
+
+namespace {
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// pcl::transformPointCloud / the aligned cloud of icp.align(): whole records copied, xyz <- T * xyz for
+// finite points; set_w: data[3] = 1 like Registration::align does.  in == out allowed.
+__global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, char *out, uint32_t n, size_t stride, Mat34 T, int set_w)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(in + (size_t)i * stride);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)i * stride);
+    const float x = __uint_as_float(src[0]), y = __uint_as_float(src[1]), z = __uint_as_float(src[2]);
+    if (out != in)
+        for (uint32_t k = 3; k < stride / 4; ++k) dst[k] = src[k];
+    float3 t = make_float3(x, y, z);
+    if (finite3(x, y, z)) t = xform(T, x, y, z);
+    dst[0] = __float_as_uint(t.x);
+    dst[1] = __float_as_uint(t.y);
+    dst[2] = __float_as_uint(t.z);
+    if (set_w && stride >= 16) dst[3] = __float_as_uint(1.0f);
+}
+
+int check_pair(const rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b)
+{
+    if (!ctx || !a || !b || a->ctx != ctx || b->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    return RSREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsreg_cloud_create(rsreg_ctx *ctx, rsreg_cloud **out)
+{
+    if (!ctx || !out) return RSREG_ERR_INVALID_ARG;
+    rsreg_cloud *c = new (std::nothrow) rsreg_cloud();
+    if (!c) return RSREG_ERR_ALLOC;
+    c->ctx = ctx;
+    *out = c;
+    return RSREG_OK;
+}
+
+int rsreg_cloud_destroy(rsreg_cloud *c)
+{
+    if (!c) return RSREG_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    c->buf.release();
+    delete c;
+    return RSREG_OK;
+}
+
+int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
+{
+    if (!c || (n && !points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, c->buf.reserve(n * stride + 16));
+    if (n) {
+        // through pinned staging, copied by a few threads (a pageable hipMemcpy of tens of MB is several times slower)
+        RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
+        char *stage = ctx->h_stage.as<char>();
+        const char *src = static_cast<const char *>(points);
+        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+        RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, stage, n * stride, hipMemcpyHostToDevice, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
+    }
+    c->n = n;
+    c->stride = stride;
+    c->width = width;
+    c->height = height;
+    c->is_dense = is_dense;
+    return RSREG_OK;
+}
+
+int rsreg_cloud_download(const rsreg_cloud *c, void *out, size_t capacity)
+{
+    if (!c || (c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
+    rsreg_ctx *ctx = c->ctx;
+    if (!c->n) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = c->n * c->stride;
+    RSREG_HIP(ctx, ctx->h_stage.reserve(bytes));
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, c->buf.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const char *stage = ctx->h_stage.as<char>();
+    char *dst = static_cast<char *>(out);
+    const size_t stride = c->stride;
+    host_parallel_for(c->n, [=](size_t lo, size_t hi) { std::memcpy(dst + lo * stride, stage + lo * stride, (hi - lo) * stride); });
+    return RSREG_OK;
+}
+
+int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *width, uint32_t *height, int *is_dense)
+{
+    if (!c) return RSREG_ERR_INVALID_ARG;
+    if (n) *n = c->n;
+    if (stride) *stride = c->stride;
+    if (width) *width = c->width;
+    if (height) *height = c->height;
+    if (is_dense) *is_dense = c->is_dense;
+    return RSREG_OK;
+}
+
+const void *rsreg_cloud_device_ptr(const rsreg_cloud *c) { return c ? c->buf.ptr : nullptr; }
+
+int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc) return rc;
+    if (in == out) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, out->buf.reserve(in->n * in->stride + 16));
+    if (in->n) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, in->buf.ptr, in->n * in->stride, hipMemcpyDeviceToDevice, ctx->stream));
+    out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
+    return RSREG_OK;
+}
+
+// pcl::ApproximateVoxelGrid::filter (incremental_icp.hpp:54-55, icp_edge...hpp:59-60,75-76): in == out allowed
+int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc || !leaf) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
+    if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t nr = 0;
+    const size_t stride = in->stride;
+    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr);
+    if (rc) return rc;
+    RSREG_HIP(ctx, out->buf.reserve((size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
+    if (nr) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
+    return RSREG_OK;
+}
+
+// pcl::transformPointCloud (incremental_icp.hpp:63, icp_edge...hpp:116-117): in == out allowed
+int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float transform[16], rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc || !transform) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    if (in != out) RSREG_HIP(ctx, out->buf.reserve(in->n * in->stride + 16));
+    Mat4f T;
+    std::memcpy(T.m, transform, 64);
+    if (in->n) {
+        k_records_transform<<<div_up((uint32_t)in->n, kBlock), kBlock, 0, ctx->stream>>>(in->buf.as<char>(), out->buf.as<char>(), (uint32_t)in->n,
+                                                                                        in->stride, to_mat34(T), 0);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
+    return RSREG_OK;
+}
+
+// pcl::PointCloud::operator+ / += (incremental_icp.hpp:64, icp_edge...hpp:119-120): out = a followed by b;
+// out may be a (the append of `target += transformed` then costs only the copy of b) or b
+int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b, rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, a, b);
+    if (rc || !out || out->ctx != ctx) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    if (a->n && b->n && a->stride != b->stride) return fail(ctx, RSREG_ERR_INVALID_ARG, "record strides differ");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t stride = a->n ? a->stride : b->stride, na = a->n, nb = b->n, total = na + nb;
+    const int dense = a->is_dense && b->is_dense;
+    if (out == a && out->buf.cap >= total * stride + 16) {
+        if (nb) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.as<char>() + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        DevBuf fresh;
+        RSREG_HIP(ctx, fresh.reserve(total * stride + (out == a ? total * stride / 2 : 0) + 16));   // a growing model: room for the next frames
+        if (na) RSREG_HIP(ctx, hipMemcpyAsync(fresh.ptr, a->buf.ptr, na * stride, hipMemcpyDeviceToDevice, ctx->stream));
+        if (nb) RSREG_HIP(ctx, hipMemcpyAsync(static_cast<char *>(fresh.ptr) + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a or b may be `out`, whose old buffer goes away now
+        out->buf.release();
+        out->buf = fresh;
+    }
+    out->n = total; out->stride = stride; out->width = (uint32_t)total; out->height = 1; out->is_dense = dense;
+    return RSREG_OK;
+}
+
+// ---- ICP on cloud handles (the handles must stay alive and unchanged until the align has returned)
+int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_correspondence_distance)
+{
+    if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    return rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
+}
+
+int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
+{
+    if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    int rc = rsreg_icp_set_source_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense);
+    if (rc) return rc;
+    ctx->src_cloud = c;
+    return RSREG_OK;
+}
+
+// icp.align(out[, guess]) with the aligned cloud left in HBM (nullable; may be the source cloud itself)
+int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result,
+                          rsreg_cloud *aligned_out)
+{
+    if (!ctx || !params || !result) return RSREG_ERR_INVALID_ARG;
+    if (aligned_out && (aligned_out->ctx != ctx || !ctx->src_cloud)) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_set_source_cloud not called");
+    int rc = rsreg_icp_align(ctx, guess, params, result, nullptr, 0);
+    if (rc || !aligned_out) return rc;
+    const rsreg_cloud *src = ctx->src_cloud;
+    if (aligned_out != src) RSREG_HIP(ctx, aligned_out->buf.reserve(src->n * src->stride + 16));
+    Mat4f T;
+    std::memcpy(T.m, result->transform, 64);
+    if (src->n) {
+        k_records_transform<<<div_up((uint32_t)src->n, kBlock), kBlock, 0, ctx->stream>>>(src->buf.as<char>(), aligned_out->buf.as<char>(),
+                                                                                         (uint32_t)src->n, src->stride, to_mat34(T), 1);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    aligned_out->n = src->n; aligned_out->stride = src->stride; aligned_out->width = src->width; aligned_out->height = src->height;
+    aligned_out->is_dense = src->is_dense;
+    return RSREG_OK;
+}
+
+// ---- NDT on cloud handles
+int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense, double resolution);
+int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_t stride, int is_dense, const float *guess,
+                           const rsreg_ndt_params *params, rsreg_ndt_result *result, void *d_aligned_out);
+
+int rsreg_ndt_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double resolution)
+{
+    if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    return rsreg_ndt_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, resolution);
+}
+
+int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float *guess, const rsreg_ndt_params *params,
+                          rsreg_ndt_result *result, rsreg_cloud *aligned_out)
+{
+    if (!ctx || !source || source->ctx != ctx || !params || (aligned_out && aligned_out->ctx != ctx)) return RSREG_ERR_INVALID_ARG;
+    if (aligned_out && aligned_out != source) RSREG_HIP(ctx, aligned_out->buf.reserve(source->n * source->stride + 16));
+    int rc = rsreg_ndt_align_device(ctx, source->n ? source->buf.ptr : nullptr, source->n, source->stride, source->is_dense, guess, params,
+                                    result, aligned_out ? aligned_out->buf.ptr : nullptr);
+    if (rc || !aligned_out) return rc;
+    aligned_out->n = source->n; aligned_out->stride = source->stride; aligned_out->width = source->width;
+    aligned_out->height = source->height; aligned_out->is_dense = source->is_dense;
+    return RSREG_OK;
+}
+
+}  // extern "C"

@@ -466,6 +466,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     ctx->n_source = n;
     ctx->n_work = 0;
+    ctx->src_cloud = nullptr;
     ctx->have_source = false;
     ctx->icp.active = 0;
     if (n) {

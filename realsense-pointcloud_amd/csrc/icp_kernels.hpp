@@ -26,10 +26,10 @@
 #include <cstdint>
 
 #include "rsreg_ctx.hpp"
+#include "records.hpp"
 
 namespace rsreg {
 
-constexpr int kBlock = 256;            // 4 waves of 64
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr float kCellMargin = 0.03f;   // slack (in cells) on every geometric lower bound: covers
                                        // the float rounding of the point -> cell assignment
@@ -44,10 +44,6 @@ struct GridDev {
     const BrickEntry *bricks;
     const uint32_t *cellpos;
     const float4 *pts;
-};
-
-struct Mat34 {  // rows of the 3x4 part of a column-major Mat4f, passed by value to kernels
-    float r0[4], r1[4], r2[4];
 };
 
 // State of the device-resident loop (RSREG_PIPELINE_DEVICE_LOOP): what update_from_sums keeps
@@ -65,30 +61,10 @@ struct IcpDevState {
     double svd_v[9];             // V of the previous solve: where the next Jacobi SVD starts
 };
 
-RSREG_HD inline Mat34 to_mat34(const Mat4f &T)
-{
-    Mat34 m;
-    for (int c = 0; c < 4; ++c) { m.r0[c] = T(0, c); m.r1[c] = T(1, c); m.r2[c] = T(2, c); }
-    return m;
-}
-
-__device__ __forceinline__ float3 xform(const Mat34 &m, float x, float y, float z)
-{
-    float ox = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m.r0[0], x), __fmul_rn(m.r0[1], y)), __fmul_rn(m.r0[2], z)), m.r0[3]);
-    float oy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m.r1[0], x), __fmul_rn(m.r1[1], y)), __fmul_rn(m.r1[2], z)), m.r1[3]);
-    float oz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m.r2[0], x), __fmul_rn(m.r2[1], y)), __fmul_rn(m.r2[2], z)), m.r2[3]);
-    return make_float3(ox, oy, oz);
-}
-
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float tx, float ty, float tz)
 {
     const float dx = __fsub_rn(qx, tx), dy = __fsub_rn(qy, ty), dz = __fsub_rn(qz, tz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-}
-
-__device__ __forceinline__ bool finite3(float x, float y, float z)
-{
-    return isfinite(x) && isfinite(y) && isfinite(z);
 }
 
 // position in cell units relative to the grid origin; the SAME expression feeds the build
@@ -149,11 +125,6 @@ inline float ordered_float(uint32_t u)
     float f;
     memcpy(&f, &v, 4);
     return f;
-}
-
-__device__ __forceinline__ const float *rec_xyz(const char *base, size_t stride, size_t i)
-{
-    return reinterpret_cast<const float *>(base + i * stride);
 }
 
 // ------------------------------------------------------------------------------ grid build

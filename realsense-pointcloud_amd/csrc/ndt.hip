@@ -328,6 +328,21 @@ int step_length(NdtRun &r, const double *x, double *dir, double step_init, doubl
     return RSREG_OK;
 }
 
+int load_ndt_source_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_t stride)
+{
+    RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
+    RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
+    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    if (n) {
+        k_ndt_load_source<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(static_cast<const char *>(d_source), stride,
+                                                                                        (uint32_t)n, ctx->d_ndt_src.as<float4>());
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    return RSREG_OK;
+}
+
 int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
 {
     int rc_pack = pack_to_stage(ctx, source, n, stride);
@@ -373,10 +388,11 @@ void rsreg_ndt_params_reference(rsreg_ndt_params *p)
     p->max_iterations = 50;            // :43
 }
 
-int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense, double resolution)
+// VoxelGridCovariance over records already in HBM (d_points / stride); keeps no pointer to them
+int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense, double resolution)
 {
     (void)is_dense;
-    if (!ctx || (n && !points) || stride < 12 || !(resolution > 0)) return RSREG_ERR_INVALID_ARG;
+    if (!ctx || (n && !d_points) || stride < 12 || (stride & 3) || !(resolution > 0)) return RSREG_ERR_INVALID_ARG;
     if (n > 0xfffffff0ull) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -387,25 +403,20 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     ctx->ndt_counts.clear();
     ctx->ndt_centroid.clear();
 
-    // ---- upload xyz, bounding box of the finite points (pcl::getMinMax3D)
-    {
-        int rc_pack = pack_to_stage(ctx, points, n, stride);
-        if (rc_pack) return rc_pack;
-    }
-    RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
+    // ---- bounding box of the finite points (pcl::getMinMax3D)
     RSREG_HIP(ctx, ctx->d_misc.reserve(64 * 4));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
-    const char *d_pts = ctx->d_tgt_raw.as<char>();
+    const char *d_pts = static_cast<const char *>(d_points);
+    const size_t pstride = stride;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_ndt.as<uint32_t>();
     for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
     for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
     RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, 64, hipMemcpyHostToDevice, st));
-    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
     h_misc[6] = 0;
     if (n) {
-        k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 1024), 256, 0, st>>>(d_pts, 12, (uint32_t)n, d_misc);
+        k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 1024), 256, 0, st>>>(d_pts, pstride, (uint32_t)n, d_misc);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
         RSREG_HIP(ctx, hipStreamSynchronize(st));
@@ -442,7 +453,7 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
     uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_ndt_seg.as<uint32_t>();
-    k_ndt_keys<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, 12, (uint32_t)n, bp, keys, vals);
+    k_ndt_keys<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0;
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
@@ -460,7 +471,7 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
 
     // ---- per-voxel moments on the device, one block per occupied leaf
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * 10 * 8, 64 * 8)));
-    k_ndt_voxel_stats<<<nseg, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, 12, ctx->d_ndt_out.as<double>());
+    k_ndt_voxel_stats<<<nseg, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_ndt_out.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
     std::vector<double> stats((size_t)nseg * 10);
     RSREG_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->d_ndt_out.ptr, stats.size() * 8, hipMemcpyDeviceToHost, st));
@@ -525,6 +536,18 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     return RSREG_OK;
 }
 
+int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense, double resolution)
+{
+    if (!ctx || (n && !points) || stride < 12 || !(resolution > 0)) return RSREG_ERR_INVALID_ARG;
+    if (n > 0xfffffff0ull) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = pack_to_stage(ctx, points, n, stride);
+    if (rc) return rc;
+    RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
+    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    return rsreg_ndt_set_target_device(ctx, n ? ctx->d_tgt_raw.ptr : nullptr, n, 12, is_dense, resolution);
+}
+
 int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_icov, int32_t *counts, int32_t capacity)
 {
     if (!ctx || !n_voxels) return RSREG_ERR_INVALID_ARG;
@@ -554,19 +577,15 @@ int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *source, size_t n, size_t s
     return derivative_pass(r, pose, pose_matrix(pose), 0, false, score, gradient, hessian);
 }
 
-int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride, int is_dense, const float *guess,
-                    const rsreg_ndt_params *params, rsreg_ndt_result *result, void *aligned_out, size_t out_stride)
-{
-    (void)is_dense;
-    if (!ctx || !params || (n && !source) || stride < 12) return RSREG_ERR_INVALID_ARG;
-    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
-    if (aligned_out && out_stride < 12) return RSREG_ERR_INVALID_ARG;
-    if (std::fabs(params->resolution - ctx->ndt_resolution) > 0)
-        return fail(ctx, RSREG_ERR_INVALID_ARG, "resolution differs from the one the NDT target was built with");
-    RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = load_ndt_source(ctx, source, n, stride);
-    if (rc) return rc;
+}  // extern "C"
 
+namespace {
+
+// Newton + More-Thuente on the source already loaded into d_ndt_src (n points); leaves the cloud at
+// the last evaluated pose in d_ndt_trans (packed xyz)
+int ndt_align_loaded(rsreg_ctx *ctx, size_t n, const float *guess, const rsreg_ndt_params *params, rsreg_ndt_result *result)
+{
+    int rc = RSREG_OK;
     NdtRun r;
     r.ctx = ctx;
     r.prm = *params;
@@ -611,22 +630,6 @@ int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
             converged = 1;
         ++nr_iterations;
     }
-    if (aligned_out && n) {  // output cloud = the cloud at the last evaluated pose
-        RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
-        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_ndt_trans.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
-        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const float *xyz = ctx->h_stage.as<float>();
-        const char *in = static_cast<const char *>(source);
-        char *dst = static_cast<char *>(aligned_out);
-        const float one = 1.0f;
-        for (size_t i = 0; i < n; ++i) {
-            float q[3];
-            std::memcpy(q, in + i * stride, 12);
-            const bool ok = std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]);
-            std::memcpy(dst + i * out_stride, ok ? xyz + 3 * i : q, 12);
-            if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
-        }
-    }
     if (result) {
         std::memset(result, 0, sizeof(*result));
         std::memcpy(result->transform, r.final_t.m, 64);
@@ -638,6 +641,74 @@ int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
         result->n_derivative_passes = r.passes;
         result->ms_derivatives = r.ms_derivatives;
         result->ms_total = r.ms_derivatives;
+    }
+    return RSREG_OK;
+}
+
+int ndt_check(rsreg_ctx *ctx, const rsreg_ndt_params *params)
+{
+    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
+    if (std::fabs(params->resolution - ctx->ndt_resolution) > 0)
+        return fail(ctx, RSREG_ERR_INVALID_ARG, "resolution differs from the one the NDT target was built with");
+    return RSREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride, int is_dense, const float *guess,
+                    const rsreg_ndt_params *params, rsreg_ndt_result *result, void *aligned_out, size_t out_stride)
+{
+    (void)is_dense;
+    if (!ctx || !params || (n && !source) || stride < 12) return RSREG_ERR_INVALID_ARG;
+    if (aligned_out && out_stride < 12) return RSREG_ERR_INVALID_ARG;
+    int rc = ndt_check(ctx, params);
+    if (rc) return rc;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    rc = load_ndt_source(ctx, source, n, stride);
+    if (rc) return rc;
+    rc = ndt_align_loaded(ctx, n, guess, params, result);
+    if (rc) return rc;
+    if (aligned_out && n) {  // output cloud = the cloud at the last evaluated pose
+        RSREG_HIP(ctx, ctx->h_stage.reserve(n * 12 + 16));
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_ndt_trans.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const float *xyz = ctx->h_stage.as<float>();
+        const char *in = static_cast<const char *>(source);
+        char *dst = static_cast<char *>(aligned_out);
+        host_parallel_for(n, [=](size_t lo, size_t hi) {
+            const float one = 1.0f;
+            for (size_t i = lo; i < hi; ++i) {
+                float q[3];
+                std::memcpy(q, in + i * stride, 12);
+                const bool ok = std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]);
+                std::memcpy(dst + i * out_stride, ok ? xyz + 3 * i : q, 12);
+                if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
+            }
+        });
+    }
+    return RSREG_OK;
+}
+
+// source records already in HBM; d_aligned_out (nullable, may be d_source): the records with xyz at the final pose
+int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_t stride, int is_dense, const float *guess,
+                           const rsreg_ndt_params *params, rsreg_ndt_result *result, void *d_aligned_out)
+{
+    (void)is_dense;
+    if (!ctx || !params || (n && !d_source) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    int rc = ndt_check(ctx, params);
+    if (rc) return rc;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    rc = load_ndt_source_device(ctx, d_source, n, stride);
+    if (rc) return rc;
+    rc = ndt_align_loaded(ctx, n, guess, params, result);
+    if (rc) return rc;
+    if (d_aligned_out && n) {
+        k_ndt_write_aligned<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(static_cast<const char *>(d_source), stride, (uint32_t)n,
+                                                                                          ctx->d_ndt_trans.as<float>(),
+                                                                                          static_cast<char *>(d_aligned_out));
+        RSREG_HIP(ctx, hipGetLastError());
     }
     return RSREG_OK;
 }

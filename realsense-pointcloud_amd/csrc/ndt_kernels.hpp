@@ -255,4 +255,22 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_load_source(const char *raw, 
     src[i] = make_float4(x, y, z, ndt_finite3(x, y, z) ? 1.0f : 0.0f);
 }
 
+// the aligned cloud of ndt.align() as records in HBM: the source record, xyz at the last evaluated pose
+// (a non-finite point keeps its coordinates), data[3] = 1; in and out may be the same array
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_write_aligned(const char *in, size_t stride, uint32_t n, const float *xyz, char *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(in + (size_t)i * stride);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)i * stride);
+    const float x = __uint_as_float(src[0]), y = __uint_as_float(src[1]), z = __uint_as_float(src[2]);
+    const bool ok = ndt_finite3(x, y, z);
+    if (out != in)
+        for (uint32_t k = 3; k < stride / 4; ++k) dst[k] = src[k];
+    dst[0] = ok ? __float_as_uint(xyz[3 * i]) : src[0];
+    dst[1] = ok ? __float_as_uint(xyz[3 * i + 1]) : src[1];
+    dst[2] = ok ? __float_as_uint(xyz[3 * i + 2]) : src[2];
+    if (stride >= 16) dst[3] = __float_as_uint(1.0f);
+}
+
 }  // namespace rsreg

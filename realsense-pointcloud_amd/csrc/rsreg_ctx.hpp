@@ -124,6 +124,7 @@ struct rsreg_ctx {
 
     // ---- ICP source
     bool have_source = false;
+    const struct rsreg_cloud *src_cloud = nullptr;   // set by rsreg_icp_set_source_cloud: where the aligned cloud's records come from
     size_t n_source = 0;          // source points handed in
     size_t n_work = 0;            // distinct source points the iteration works on (exact copies merged)
     rsreg::DevBuf d_src_all;      // float4 {x,y,z,valid} of every source point, spatially sorted

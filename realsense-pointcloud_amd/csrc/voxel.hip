@@ -210,20 +210,18 @@ inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 using namespace rsreg;
 
-extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_t n, size_t stride, const float leaf[3], void *out,
-                                           size_t *n_out)
+namespace rsreg {
+
+// The filter on records already in HBM (d_in, N records of `stride` bytes); the filtered records
+// land in ctx->d_vox_out, *n_out of them.  One host synchronisation (the number of runs).
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out)
 {
-    if (!ctx || !leaf || !n_out || (n && (!in || !out)) || stride < 20 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
-    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0)) return RSREG_ERR_INVALID_ARG;
-    if (n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
     *n_out = 0;
-    if (n == 0) return RSREG_OK;
-    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    if (N == 0) return RSREG_OK;
     hipStream_t st = ctx->stream;
-    const uint32_t N = (uint32_t)n;
+    const size_t n = N;
     const float ivx = 1.0f / leaf[0], ivy = 1.0f / leaf[1], ivz = 1.0f / leaf[2];
     // buffers (all reused from the context; nothing here overlaps an ICP call in flight)
-    RSREG_HIP(ctx, ctx->d_vox_in.reserve(n * stride));
     RSREG_HIP(ctx, ctx->d_vox_out.reserve(n * stride));
     RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
@@ -233,8 +231,8 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_vox_cent.reserve(n * 32));
     RSREG_HIP(ctx, ctx->d_misc.reserve(256));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(1024));
-    char *d_in = ctx->d_vox_in.as<char>(), *d_out = ctx->d_vox_out.as<char>();
+    RSREG_HIP(ctx, ctx->h_sums.reserve(2048));
+    char *d_out = ctx->d_vox_out.as<char>();
     uint32_t *keys = ctx->d_keys.as<uint32_t>(), *skeys = ctx->d_keys_alt.as<uint32_t>();
     uint32_t *vals = ctx->d_vals.as<uint32_t>(), *svals = ctx->d_vals_alt.as<uint32_t>();
     uint32_t *flag = ctx->d_flags.as<uint32_t>(), *rid = ctx->d_scan.as<uint32_t>();
@@ -244,14 +242,6 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     uint32_t *long_runs = rid;              // the run ids are dead once the starts are written
     float *cent = ctx->d_vox_cent.as<float>();
     uint32_t *stats = ctx->d_misc.as<uint32_t>() + 32;
-    // through pinned staging, copied by a few threads: a pageable hipMemcpy of 10-30 MB is several times slower
-    RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
-    {
-        char *stage = ctx->h_stage.as<char>();
-        const char *src = static_cast<const char *>(in);
-        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
-    }
-    RSREG_HIP(ctx, hipMemcpyAsync(d_in, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
     RSREG_HIP(ctx, hipMemsetAsync(stats, 0, 16, st));
     const uint32_t nb = div_up_u(N, kVBlock);
     k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals);
@@ -280,7 +270,35 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
     k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, order, stats, stride, d_out);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, d_out, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
+    *n_out = nr;
+    return RSREG_OK;
+}
+
+}  // namespace rsreg
+
+extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_t n, size_t stride, const float leaf[3], void *out,
+                                           size_t *n_out)
+{
+    if (!ctx || !leaf || !n_out || (n && (!in || !out)) || stride < 20 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0)) return RSREG_ERR_INVALID_ARG;
+    if (n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
+    *n_out = 0;
+    if (n == 0) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    RSREG_HIP(ctx, ctx->d_vox_in.reserve(n * stride));
+    // through pinned staging, copied by a few threads: a pageable hipMemcpy of 10-30 MB is several times slower
+    RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
+    {
+        char *stage = ctx->h_stage.as<char>();
+        const char *src = static_cast<const char *>(in);
+        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+    }
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
+    uint32_t nr = 0;
+    int rc = voxel_filter_device(ctx, ctx->d_vox_in.as<char>(), (uint32_t)n, stride, leaf, &nr);
+    if (rc || nr == 0) return rc;
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
     {
         const char *stage = ctx->h_stage.as<char>();

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp"]
+SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
 UNIQUE_ID_BYTES = 128
@@ -27,6 +27,10 @@ EXPORTS = [
     "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
+    "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_download", "rsreg_cloud_info",
+    "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_transform", "rsreg_cloud_concat",
+    "rsreg_icp_set_target_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
+    "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
     "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
 ]
 
@@ -162,6 +166,25 @@ def lib():
     L.rsreg_comm_destroy.argtypes = [vp]
     L.rsreg_comm_allreduce_f64.argtypes = [vp, vp, i32]
     L.rsreg_icp_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    u32 = C.c_uint32
+    L.rsreg_cloud_create.argtypes = [vp, C.POINTER(vp)]
+    L.rsreg_cloud_destroy.argtypes = [vp]
+    L.rsreg_cloud_upload.argtypes = [vp, vp, sz, sz, u32, u32, i32]
+    L.rsreg_cloud_download.argtypes = [vp, vp, sz]
+    L.rsreg_cloud_info.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)]
+    L.rsreg_cloud_device_ptr.argtypes = [vp]
+    L.rsreg_cloud_device_ptr.restype = vp
+    L.rsreg_cloud_copy.argtypes = [vp, vp, vp]
+    L.rsreg_cloud_filter.argtypes = [vp, vp, vp, vp]
+    L.rsreg_cloud_transform.argtypes = [vp, vp, vp, vp]
+    L.rsreg_cloud_concat.argtypes = [vp, vp, vp, vp]
+    L.rsreg_icp_set_target_cloud.argtypes = [vp, vp, dbl]
+    L.rsreg_icp_set_source_cloud.argtypes = [vp, vp]
+    L.rsreg_icp_align_cloud.argtypes = [vp, vp, C.POINTER(IcpParams), C.POINTER(IcpResult), vp]
+    L.rsreg_ndt_set_target_cloud.argtypes = [vp, vp, dbl]
+    L.rsreg_ndt_align_cloud.argtypes = [vp, vp, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp]
+    L.rsreg_ndt_set_target_device.argtypes = [vp, vp, sz, sz, i32, dbl]
+    L.rsreg_ndt_align_device.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp]
     L.rsreg_lzf_max_encoded_size.argtypes = [sz]
     L.rsreg_lzf_max_encoded_size.restype = sz
     for f in ("rsreg_lzf_encode", "rsreg_lzf_decode"):

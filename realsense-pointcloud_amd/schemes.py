@@ -72,10 +72,38 @@ class HipBackend:
     def transform(self, cloud, T):
         return self.api.transformPointCloud(cloud, T, self.ctx)
 
+    # what a scheme does with whole clouds between the steps (host clouds here: nothing to move)
+    def upload(self, cloud):
+        return cloud
+
+    def download(self, cloud):
+        return cloud
+
+    def concat(self, a, b):
+        return a + b
+
+
+class HipDeviceBackend(HipBackend):
+    """The product path with the frame loop resident in HBM: a frame is uploaded once, every step
+    (filter, align, transform, concatenate) takes and leaves its clouds on the GPU, and only what the
+    caller gets back is downloaded.  Same records, same order as HipBackend."""
+
+    def upload(self, cloud):
+        return self.api.DeviceCloud(cloud, self.ctx or self.api.default_context())
+
+    def download(self, cloud):
+        return cloud.download()
+
+
+def _assign(dst, src):
+    """`*dst = *src` for host clouds: the caller's object takes the new contents."""
+    dst.points, dst.width, dst.height, dst.is_dense = src.points, src.width, src.height, src.is_dense
+    return dst
+
 
 class RegistrationScheme:
     def __init__(self, backend=None):
-        self.backend = backend or HipBackend()
+        self.backend = backend or HipDeviceBackend()
 
     def registration(self, clouds):
         raise NotImplementedError
@@ -100,23 +128,23 @@ class IncrementalICP(RegistrationScheme):
         b = self.backend
         voxel = b.voxel()                 # leaf never set -> PCL's 1 m default
         icp = b.icp()
-        model = clouds[0]                 # aliases and grows the caller's frame 0
+        frames = [b.upload(c) for c in clouds]
+        model = frames[0]                 # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
         for k in range(1, len(clouds)):
-            voxel.setInputCloud(clouds[k])
+            voxel.setInputCloud(frames[k])
             reduced = voxel.filter()
             icp.setInputSource(reduced)
             icp.setInputTarget(model)
             icp.align()
             if not icp.hasConverged():
                 continue
-            moved = b.transform(clouds[k], icp.getFinalTransformation())
-            merged = model + moved
-            model.points, model.width, model.height, model.is_dense = merged.points, merged.width, merged.height, merged.is_dense
+            moved = b.transform(frames[k], icp.getFinalTransformation())
+            model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
             self.transforms.append(icp.getFinalTransformation())
             self.merged_frames.append(k)
-        return model
+        return _assign(clouds[0], b.download(model))   # the caller's frame 0 has become the merged cloud
 
 
 class _EdgeBased(TwoPhaseRegistrationScheme):
@@ -139,15 +167,13 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         icp = b.icp()
         voxel = b.voxel((0.01, 0.01, 0.01))
         coarse = self._coarse()
-        target = pairs[0][0]                       # frame-0 features: filtered in place, then grown
-        merged = PointCloud() + pairs[0][1]
-        voxel.setInputCloud(target)
-        f0 = voxel.filter()
-        target.points, target.width, target.height, target.is_dense = f0.points, f0.width, f0.height, f0.is_dense
+        merged = b.upload(pairs[0][1])
+        voxel.setInputCloud(b.upload(pairs[0][0]))
+        target = voxel.filter()                    # frame-0 features: filtered in place, then grown
         acc = np.float32(0.0)
         self.frame_transforms = []
         for k in range(1, len(pairs)):
-            voxel.setInputCloud(pairs[k][0])
+            voxel.setInputCloud(b.upload(pairs[k][0]))
             reduced = voxel.filter()
             if self.use_imu:
                 t0 = self.thetas[0]
@@ -165,13 +191,14 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             refined = icp.align()
             if not icp.hasConverged():
                 continue
-            moved = b.transform(pairs[k][1], t_coarse)
+            moved = b.transform(b.upload(pairs[k][1]), t_coarse)
             moved = b.transform(moved, icp.getFinalTransformation())
-            grown = refined + target               # new points first
-            target.points, target.width, target.height, target.is_dense = grown.points, grown.width, grown.height, grown.is_dense
-            merged = merged + moved
+            target = b.concat(refined, target)     # new points first
+            merged = b.concat(merged, moved)
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
-        return merged
+        _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
+        out = b.download(merged)
+        return PointCloud(out.points, width=len(out), height=1, is_dense=out.is_dense)
 
 
 class ICPEdgeBasedRegistration(_EdgeBased):

@@ -19,7 +19,7 @@ def L(rs):
 
 def test_header_and_exports_agree(L):
     hdr = open(os.path.join(ROOT, "include", "rsreg.h")).read()
-    declared = set(re.findall(r"^(?:int|void|size_t|const char \*)\s*(rsreg_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t|const char \*|const void \*)\s*(rsreg_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     handle = L.lib()
     for name in L.EXPORTS:

@@ -1,0 +1,116 @@
+"""GPU: clouds that stay in HBM across the frame loop (rsreg_cloud_*, include/rsreg.h).  Every
+device-resident step must hand back exactly the records its host-cloud counterpart does, and the
+three schemes must produce the same merged clouds and transforms whether their frame loop runs
+on host clouds (one upload + download per step) or on cloud handles (one upload per frame)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(rs):
+    from rsreg_amd import api as a, lib
+    lib.build()
+    if a.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return a
+
+
+def _same_records(a, b):
+    assert (len(a), a.width, a.height, a.is_dense) == (len(b), b.width, b.height, b.is_dense)
+    for f in ("x", "y", "z", "w", "rgba"):
+        np.testing.assert_array_equal(a.points[f].view(np.uint32), b.points[f].view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def frames(rs):
+    out = [rs.synth.render_frame(k, "50k", "parity") for k in range(3)]
+    out[1].points["x"][11] = np.nan          # a non-finite record travels through every step unchanged
+    return out
+
+
+def test_upload_download_copy_concat(api, rs, frames):
+    a, b = frames[0], frames[1]
+    da, db = api.DeviceCloud(a), api.DeviceCloud(b)
+    assert len(da) == len(a) and da.info()[1:] == (32, a.width, a.height, a.is_dense) and da.device_ptr
+    _same_records(da.download(), a)
+    _same_records(da.copy().download(), a)
+    _same_records((da + db).download(), a + b)
+    grown = da.copy()
+    for _ in range(3):                      # repeated += : the buffer grows once, later appends copy only the new part
+        grown.append(db)
+    _same_records(grown.download(), a + b + b + b)
+    empty = api.DeviceCloud(rs.PointCloud())
+    assert len(empty) == 0 and len((empty + empty).download()) == 0
+    _same_records((empty + da).download(), rs.PointCloud() + a)
+
+
+@pytest.mark.parametrize("leaf", [(0.01, 0.01, 0.01), (1.0, 1.0, 1.0)])
+def test_filter_and_transform_match_host_path(api, rs, frames, leaf):
+    c = frames[1]
+    ctx = api.default_context()
+    vd, vh = api.ApproximateVoxelGrid(ctx), api.ApproximateVoxelGrid(ctx)
+    vd.setLeafSize(*leaf)
+    vh.setLeafSize(*leaf)
+    vd.setInputCloud(api.DeviceCloud(c))
+    vh.setInputCloud(c)
+    _same_records(vd.filter().download(), vh.filter())
+    T = rs.synth.small_transform(3.0, (0.01, -0.02, 0.03)).astype(np.float32)
+    _same_records(api.transformPointCloud(api.DeviceCloud(c), T).download(), api.transformPointCloud(c, T))
+
+
+def test_icp_and_ndt_on_handles_match_host_clouds(api, rs, frames):
+    tgt, src = frames[0], frames[1]
+    guess = rs.synth.small_transform(0.05, (0.001, 0.0, -0.0005)).astype(np.float32)
+    for prm in (api.icp_params(reference=True), api.icp_params(max_iterations=6, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=0.02)):
+        out = []
+        for dev in (False, True):
+            icp = api.IterativeClosestPoint()
+            icp.params = prm
+            icp.setInputSource(api.DeviceCloud(src) if dev else src)
+            icp.setInputTarget(api.DeviceCloud(tgt) if dev else tgt)
+            aligned = icp.align(guess)
+            out.append((aligned.download() if dev else aligned, bytes(icp.result.transform), icp.result.iterations, icp.result.n_correspondences))
+        assert out[0][1:] == out[1][1:]
+        _same_records(out[0][0], out[1][0])
+    out = []
+    for dev in (False, True):
+        ndt = api.NormalDistributionsTransform()
+        ndt.params = api.ndt_params(reference=True)
+        ndt.setInputSource(api.DeviceCloud(src) if dev else src)
+        ndt.setInputTarget(api.DeviceCloud(tgt) if dev else tgt)
+        aligned = ndt.align(guess)
+        out.append((aligned.download() if dev else aligned, bytes(ndt.result.transform), ndt.result.iterations, ndt.result.n_derivative_passes))
+    assert out[0][1:] == out[1][1:]
+    _same_records(out[0][0], out[1][0])
+
+
+def _subsample(rs, cloud):
+    c = cloud.crop(0, 0, cloud.width, cloud.height, step=2)
+    pts = np.ascontiguousarray(c.points[c.points["z"] != 0])
+    return rs.PointCloud(pts, width=len(pts), height=1, is_dense=False)
+
+
+@pytest.mark.parametrize("kind", ["incremental", "icp_edge", "ndt_edge"])
+def test_schemes_device_loop_equals_host_loop(api, rs, kind):
+    from rsreg_amd import schemes
+    frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
+    res = []
+    for backend in (schemes.HipBackend(), schemes.HipDeviceBackend()):
+        if kind == "incremental":
+            s = schemes.IncrementalICP(backend=backend)
+        else:
+            cls = schemes.ICPEdgeBasedRegistration if kind == "icp_edge" else schemes.NDTEdgeBasedRegistration
+            s = cls(rads=-0.0261799, backend=backend)
+            s.feature_fn = lambda c: _subsample(rs, c)
+        clouds = [f.copy() for f in frames]
+        merged = s.registration(clouds)
+        tr = s.transforms if kind == "incremental" else [t for pair in s.frame_transforms for t in pair]
+        res.append((merged, clouds[0], [np.asarray(t).tobytes() for t in tr]))
+    (ma, c0a, ta), (mb, c0b, tb) = res
+    assert ta == tb and len(ta) >= 1
+    _same_records(ma, mb)
+    _same_records(c0a, c0b)                 # what the scheme did to the caller's frame 0 is the same too
+    if kind == "incremental":
+        assert ma is c0a and mb is c0b      # the reference returns (and grows) the caller's frame 0

@@ -295,6 +295,38 @@ def main():
         hs = (time.perf_counter() - th) / reps
         out["host_buffers"] = {"ms_per_pair": hs * 1e3, "point_pairs_per_s": float(n_src_total) * a.iterations / hs,
                                "note": "host AoS clouds packed + copied over PCIe inside the call; not used as value"}
+    if world == 1 and not a.no_cpu_baseline:
+        # the reference's own parameters (one iteration, 1 cm gate: SURVEY.md App. A.4) on a 1M pair inside
+        # that gate, per pair: index build + source load + align + aligned cloud.  Host clouds in and out
+        # (what the PCL call surface does) against clouds resident in HBM (rsreg_cloud_*: the frame loop of
+        # the schemes, nothing crosses PCIe).  Secondary line, never `value`.
+        tp, sp = synth.render_frame(0, a.size, "parity"), synth.render_frame(1, a.size, "parity")
+        ref = api.IterativeClosestPoint(ctx)
+        ref.params = api.icp_params(reference=True)
+
+        def pair(t, s_):
+            ref.setInputSource(s_)
+            ref.setInputTarget(t)
+            return ref.align()
+
+        modes = {}
+        for name, (t, s_) in (("host_clouds", (tp, sp)), ("device_clouds", (api.DeviceCloud(tp, ctx), api.DeviceCloud(sp, ctx)))):
+            pair(t, s_)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                out_cloud = pair(t, s_)
+            ctx.synchronize()
+            modes[name] = (time.perf_counter() - t0) / reps * 1e3
+            modes[name + "_T"] = ref.getFinalTransformation()
+        out["reference_mode"] = {
+            "workload": "icp_pair_%sx%s reference parameters (100 max iterations, 1 cm gate, eps 1 / 1000 -> 1 iteration)" % (a.size, a.size),
+            "iterations": int(ref.result.iterations), "n_correspondences": int(ref.result.n_correspondences),
+            "ms_per_pair_host_clouds": modes["host_clouds"], "ms_per_pair_device_clouds": modes["device_clouds"],
+            "point_pairs_per_s_device_clouds": float(len(sp)) * ref.result.iterations / (modes["device_clouds"] * 1e-3),
+            "same_transform": bool((modes["host_clouds_T"] == modes["device_clouds_T"]).all()),
+        }
     gt = synth.ground_truth(1, 0, "bench")
     out["transform_error_vs_ground_truth_frobenius"] = float(np.linalg.norm(T_gpu - gt))
     print(json.dumps(out))

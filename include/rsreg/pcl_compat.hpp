@@ -148,6 +148,65 @@ class Context {
     rsreg_ctx *ctx_ = nullptr;
 };
 
+// ---- a cloud resident in HBM (rsreg_cloud): what the frame loop hands from step to step without
+// leaving the GPU (filter -> align -> transformPointCloud -> operator+, icp_edge_based_registration.hpp:75-120)
+template <typename PointT> class DeviceCloud {
+  public:
+    using Ptr = std::shared_ptr<DeviceCloud<PointT>>;
+    explicit DeviceCloud(std::shared_ptr<Context> ctx = Context::Default()) : ctx_(std::move(ctx))
+    {
+        check(rsreg_cloud_create(ctx_->get(), &h_), ctx_->get());
+    }
+    explicit DeviceCloud(const PointCloud<PointT> &host, std::shared_ptr<Context> ctx = Context::Default()) : DeviceCloud(std::move(ctx))
+    {
+        upload(host);
+    }
+    ~DeviceCloud() { if (h_) rsreg_cloud_destroy(h_); }
+    DeviceCloud(const DeviceCloud &) = delete;
+    DeviceCloud &operator=(const DeviceCloud &) = delete;
+    void upload(const PointCloud<PointT> &host)
+    {
+        check(rsreg_cloud_upload(h_, host.points.data(), host.size(), sizeof(PointT), host.width, host.height, host.is_dense), ctx_->get());
+    }
+    void download(PointCloud<PointT> &host) const
+    {
+        size_t n = 0, stride = 0;
+        uint32_t w = 0, h = 0;
+        int dense = 0;
+        check(rsreg_cloud_info(h_, &n, &stride, &w, &h, &dense), ctx_->get());
+        if (n && stride != sizeof(PointT)) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: record size of the device cloud differs");
+        std::vector<PointT> pts(n);
+        check(rsreg_cloud_download(h_, pts.data(), n), ctx_->get());
+        host.points = std::move(pts);
+        host.width = w;
+        host.height = h;
+        host.is_dense = dense != 0;
+    }
+    size_t size() const
+    {
+        size_t n = 0;
+        check(rsreg_cloud_info(h_, &n, nullptr, nullptr, nullptr, nullptr), ctx_->get());
+        return n;
+    }
+    // *this += other (PointCloud::operator+=): grows in place
+    DeviceCloud &operator+=(const DeviceCloud &other)
+    {
+        check(rsreg_cloud_concat(ctx_->get(), h_, other.h_, h_), ctx_->get());
+        return *this;
+    }
+    // out = a + b (a's records first); out may be a or b
+    static void concatenate(const DeviceCloud &a, const DeviceCloud &b, DeviceCloud &out)
+    {
+        check(rsreg_cloud_concat(a.ctx_->get(), a.h_, b.h_, out.h_), a.ctx_->get());
+    }
+    rsreg_cloud *handle() const { return h_; }
+    const std::shared_ptr<Context> &context() const { return ctx_; }
+
+  private:
+    std::shared_ptr<Context> ctx_;
+    rsreg_cloud *h_ = nullptr;
+};
+
 namespace detail {
 template <typename PointT> void copy_aligned(const PointCloud<PointT> &src, PointCloud<PointT> &out)
 {
@@ -178,8 +237,8 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     void setTransformationEpsilon(double e) { prm_.transformation_epsilon = e; }
     void setTransformationRotationEpsilon(double e) { prm_.transformation_rotation_epsilon = e; }
     void setEuclideanFitnessEpsilon(double e) { prm_.euclidean_fitness_epsilon = e; }
-    void setInputSource(const SourcePtr &cloud) { source_ = cloud; source_dirty_ = true; }
-    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; target_dirty_ = true; }  // PCL rebuilds its kd-tree here too
+    void setInputSource(const SourcePtr &cloud) { source_ = cloud; dsource_ = nullptr; source_dirty_ = true; }
+    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; dtarget_ = nullptr; target_dirty_ = true; }  // PCL rebuilds its kd-tree here too
     // engine knobs without a PCL counterpart
     void setFixedIterationCount(bool on) { prm_.criteria_mode = on ? RSREG_CRITERIA_FIXED : RSREG_CRITERIA_PCL; }
     void setPipelineMode(int mode) { prm_.pipeline_mode = mode; }
@@ -206,6 +265,28 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
         std::memcpy(final_.m, res_.transform, sizeof(final_.m));
         output = std::move(tmp);
     }
+    // the same calls on clouds resident in HBM: nothing is uploaded or downloaded (the handles must
+    // stay alive and unchanged until align has returned); output may be the source cloud itself
+    void setInputSource(const DeviceCloud<PointSource> &cloud) { dsource_ = &cloud; source_.reset(); source_dirty_ = true; }
+    void setInputTarget(const DeviceCloud<PointTarget> &cloud) { dtarget_ = &cloud; target_.reset(); target_dirty_ = true; }
+    void align(DeviceCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
+    void align(DeviceCloud<PointSource> &output, const Matrix4f &guess)
+    {
+        if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
+        rsreg_ctx *c = ctx_->get();
+        if (target_dirty_ || ctx_->icp_target_owner != this) {
+            check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
+            target_dirty_ = false;
+            ctx_->icp_target_owner = this;
+        }
+        if (source_dirty_ || ctx_->icp_source_owner != this) {
+            check(rsreg_icp_set_source_cloud(c, dsource_->handle()), c);
+            source_dirty_ = false;
+            ctx_->icp_source_owner = this;
+        }
+        check(rsreg_icp_align_cloud(c, guess.data(), &prm_, &res_, output.handle()), c);
+        std::memcpy(final_.m, res_.transform, sizeof(final_.m));
+    }
     bool hasConverged() const { return res_.converged != 0; }
     Matrix4f getFinalTransformation() const { return final_; }
     int getConvergenceState() const { return res_.state; }
@@ -218,6 +299,8 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     Matrix4f final_;
     SourcePtr source_;
     TargetPtr target_;
+    const DeviceCloud<PointSource> *dsource_ = nullptr;
+    const DeviceCloud<PointTarget> *dtarget_ = nullptr;
     bool source_dirty_ = true, target_dirty_ = true;
 };
 
@@ -240,8 +323,8 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
         prm_.resolution = r;
     }
     void setMaximumIterations(int n) { prm_.max_iterations = n; }
-    void setInputSource(const SourcePtr &cloud) { source_ = cloud; }
-    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; target_dirty_ = true; }
+    void setInputSource(const SourcePtr &cloud) { source_ = cloud; dsource_ = nullptr; }
+    void setInputTarget(const TargetPtr &cloud) { target_ = cloud; dtarget_ = nullptr; target_dirty_ = true; }
 
     void align(PointCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
     void align(PointCloud<PointSource> &output, const Matrix4f &guess)
@@ -261,6 +344,21 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
         std::memcpy(final_.m, res_.transform, sizeof(final_.m));
         output = std::move(tmp);
     }
+    void setInputSource(const DeviceCloud<PointSource> &cloud) { dsource_ = &cloud; source_.reset(); }
+    void setInputTarget(const DeviceCloud<PointTarget> &cloud) { dtarget_ = &cloud; target_.reset(); target_dirty_ = true; }
+    void align(DeviceCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
+    void align(DeviceCloud<PointSource> &output, const Matrix4f &guess)
+    {
+        if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
+        rsreg_ctx *c = ctx_->get();
+        if (target_dirty_ || ctx_->ndt_target_owner != this) {
+            check(rsreg_ndt_set_target_cloud(c, dtarget_->handle(), prm_.resolution), c);
+            target_dirty_ = false;
+            ctx_->ndt_target_owner = this;
+        }
+        check(rsreg_ndt_align_cloud(c, dsource_->handle(), guess.data(), &prm_, &res_, output.handle()), c);
+        std::memcpy(final_.m, res_.transform, sizeof(final_.m));
+    }
     bool hasConverged() const { return res_.converged != 0; }
     Matrix4f getFinalTransformation() const { return final_; }
     double getTransformationProbability() const { return res_.trans_probability; }
@@ -274,6 +372,8 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
     Matrix4f final_;
     SourcePtr source_;
     TargetPtr target_;
+    const DeviceCloud<PointSource> *dsource_ = nullptr;
+    const DeviceCloud<PointTarget> *dtarget_ = nullptr;
     bool target_dirty_ = true;
 };
 
@@ -302,6 +402,11 @@ template <typename PointT> class ApproximateVoxelGrid {
         output.height = 1;
         output.is_dense = false;
     }
+    // the filter on a cloud resident in HBM (always the GPU filter); output may be the input
+    void filter(const DeviceCloud<PointT> &input, DeviceCloud<PointT> &output)
+    {
+        check(rsreg_cloud_filter(input.context()->get(), input.handle(), leaf_, output.handle()), input.context()->get());
+    }
   private:
     float leaf_[3] = {1.f, 1.f, 1.f};  // PCL default: IncrementalICP never sets it (incremental_icp.hpp:36)
     typename PointCloud<PointT>::Ptr input_;
@@ -322,6 +427,11 @@ void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, 
     out.width = w;
     out.height = h;
     out.is_dense = dense;
+}
+
+template <typename PointT> void transformPointCloud(const DeviceCloud<PointT> &in, DeviceCloud<PointT> &out, const Matrix4f &T)
+{
+    check(rsreg_cloud_transform(in.context()->get(), in.handle(), T.data(), out.handle()), in.context()->get());
 }
 
 // ---- pcl::io: PCD files with FIELDS x y z rgb (ascii, binary, binary_compressed), as the reference reads/writes

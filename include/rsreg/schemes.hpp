@@ -34,11 +34,17 @@ struct float3 {
     void add(float t1, float t2, float t3) { x += t1; y += t2; z += t3; }
 };
 
+using rgb_device_cloud = DeviceCloud<rgb_point>;
+
 class RegistrationScheme {
   public:
     virtual ~RegistrationScheme() = default;
     virtual rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) = 0;
     bool verbose = false;  // the reference prints progress lines to stdout
+    // true (default): the frame loop runs on clouds resident in HBM -- a frame is uploaded once, every
+    // step takes and leaves its clouds on the GPU, only what the caller gets back is downloaded.
+    // false: every step on host clouds (one upload + download per step).  Same records either way.
+    bool device_resident = true;
 };
 
 class TwoPhaseRegistrationScheme : public RegistrationScheme {
@@ -78,6 +84,34 @@ class IncrementalICP : public RegistrationScheme {
   public:
     rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
     {
+        if (device_resident) return registration_device(clouds);
+        return registration_host(clouds);
+    }
+    std::vector<Matrix4f> transforms;  // per merged frame (engine extra, for tests)
+
+  private:
+    rgb_point_cloud_pointer registration_device(std::vector<rgb_point_cloud_pointer> &clouds)
+    {
+        ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
+        IterativeClosestPoint<rgb_point, rgb_point> icp;
+        detail::reference_icp_parameters(icp);
+        rgb_device_cloud model(*clouds[0]), reduced, aligned, frame, moved;
+        for (size_t k = 1; k < clouds.size(); ++k) {
+            frame.upload(*clouds[k]);
+            voxel.filter(frame, reduced);
+            icp.setInputSource(reduced);
+            icp.setInputTarget(model);
+            icp.align(aligned);
+            if (!icp.hasConverged()) continue;
+            transformPointCloud(frame, moved, icp.getFinalTransformation());
+            model += moved;
+            transforms.push_back(icp.getFinalTransformation());
+        }
+        model.download(*clouds[0]);   // the caller's frame 0 has become the merged cloud (incremental_icp.hpp:40,64)
+        return clouds[0];
+    }
+    rgb_point_cloud_pointer registration_host(std::vector<rgb_point_cloud_pointer> &clouds)
+    {
         ApproximateVoxelGrid<rgb_point> voxel(Context::Default());  // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
@@ -98,7 +132,6 @@ class IncrementalICP : public RegistrationScheme {
         }
         return model;
     }
-    std::vector<Matrix4f> transforms;  // per merged frame (engine extra, for tests)
 };
 
 // Shared skeleton of the two edge-based schemes: a coarse aligner that takes an initial
@@ -110,6 +143,61 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     explicit EdgeBasedRegistrationBase(float usr_def_rads) : rads(usr_def_rads) {}
 
     rgb_point_cloud_pointer global_registration(PairList &clouds) override
+    {
+        if (device_resident) return global_registration_device(clouds);
+        return global_registration_host(clouds);
+    }
+    std::vector<std::pair<Matrix4f, Matrix4f>> frame_transforms;  // (coarse, refine) per merged frame
+
+  protected:
+    Matrix4f next_guess(size_t k, float &acc_rads)
+    {
+        if (use_imu) {
+            const float3 rel = thetas[0] * -1.0f;
+            thetas[k].add(rel.x, rel.y, rel.z);  // the reference mutates thetas in place
+            return imu_guess(thetas[k]);
+        }
+        acc_rads += rads;
+        return Matrix4f::RotationY(acc_rads);
+    }
+
+    rgb_point_cloud_pointer global_registration_device(PairList &clouds)
+    {
+        if (use_imu) assert(clouds.size() == thetas.size());
+        IterativeClosestPoint<rgb_point, rgb_point> icp;
+        detail::reference_icp_parameters(icp);
+        ApproximateVoxelGrid<rgb_point> voxel;
+        voxel.setLeafSize(0.01f, 0.01f, 0.01f);
+        configure_coarse();
+        rgb_device_cloud target(*clouds[0].first), merged(*clouds[0].second), features, reduced, coarse_out, refined, full, moved;
+        voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
+        float acc_rads = 0.f;
+        frame_transforms.clear();
+        for (size_t k = 1; k < clouds.size(); ++k) {
+            features.upload(*clouds[k].first);
+            voxel.filter(features, reduced);
+            const Matrix4f guess = next_guess(k, acc_rads);
+            const Matrix4f t_coarse = coarse_align_device(reduced, target, coarse_out, guess);
+            icp.setInputSource(coarse_out);
+            icp.setInputTarget(target);
+            icp.align(refined);
+            if (!icp.hasConverged()) continue;   // frame dropped silently, like the reference
+            full.upload(*clouds[k].second);
+            transformPointCloud(full, moved, t_coarse);
+            transformPointCloud(moved, moved, icp.getFinalTransformation());
+            rgb_device_cloud::concatenate(refined, target, target);   // new points first
+            merged += moved;
+            frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
+        }
+        target.download(*clouds[0].first);   // the caller's frame-0 feature cloud has become the grown target
+        auto out = std::make_shared<rgb_point_cloud>();
+        merged.download(*out);
+        out->width = (uint32_t)out->size();   // `*merged = *merged + ...`: an unorganized cloud whatever came in
+        out->height = 1;
+        return out;
+    }
+
+    rgb_point_cloud_pointer global_registration_host(PairList &clouds)
     {
         if (use_imu) assert(clouds.size() == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
@@ -131,15 +219,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             rgb_point_cloud refined;
             voxel.setInputCloud(clouds[k].first);
             voxel.filter(*reduced);
-            Matrix4f guess;
-            if (use_imu) {
-                const float3 rel = thetas[0] * -1.0f;
-                thetas[k].add(rel.x, rel.y, rel.z);  // the reference mutates thetas in place
-                guess = imu_guess(thetas[k]);
-            } else {
-                acc_rads += rads;
-                guess = Matrix4f::RotationY(acc_rads);
-            }
+            const Matrix4f guess = next_guess(k, acc_rads);
             const Matrix4f t_coarse = coarse_align(reduced, target, *coarse_out, guess);
             icp.setInputSource(coarse_out);
             icp.setInputTarget(target);
@@ -154,12 +234,12 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         }
         return merged;
     }
-    std::vector<std::pair<Matrix4f, Matrix4f>> frame_transforms;  // (coarse, refine) per merged frame
 
-  protected:
     virtual void configure_coarse() = 0;
     virtual Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
                                   const Matrix4f &guess) = 0;
+    virtual Matrix4f coarse_align_device(const rgb_device_cloud &src, const rgb_device_cloud &tgt, rgb_device_cloud &out,
+                                         const Matrix4f &guess) = 0;
     virtual Matrix4f imu_guess(const float3 &theta) const = 0;
 
     std::vector<float3> thetas;
@@ -174,6 +254,13 @@ class ICPEdgeBasedRegistration : public EdgeBasedRegistrationBase {
     void configure_coarse() override { detail::reference_icp_parameters(coarse_); }
     Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
                           const Matrix4f &guess) override
+    {
+        coarse_.setInputSource(src);
+        coarse_.setInputTarget(tgt);
+        coarse_.align(out, guess);
+        return coarse_.getFinalTransformation();
+    }
+    Matrix4f coarse_align_device(const rgb_device_cloud &src, const rgb_device_cloud &tgt, rgb_device_cloud &out, const Matrix4f &guess) override
     {
         coarse_.setInputSource(src);
         coarse_.setInputTarget(tgt);
@@ -202,6 +289,13 @@ class NDTEdgeBasedRegistration : public EdgeBasedRegistrationBase {
     }
     Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
                           const Matrix4f &guess) override
+    {
+        ndt_.setInputSource(src);
+        ndt_.setInputTarget(tgt);
+        ndt_.align(out, guess);
+        return ndt_.getFinalTransformation();
+    }
+    Matrix4f coarse_align_device(const rgb_device_cloud &src, const rgb_device_cloud &tgt, rgb_device_cloud &out, const Matrix4f &guess) override
     {
         ndt_.setInputSource(src);
         ndt_.setInputTarget(tgt);

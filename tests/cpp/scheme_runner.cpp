@@ -34,18 +34,23 @@ int main(int argc, char **argv)
         }
         FILE *f = std::fopen((prefix + ".txt").c_str(), "w");
         rgb_point_cloud_pointer out;
+        // RSREG_SCHEME_HOST_LOOP=1: every step of the frame loop on host clouds instead of cloud handles in HBM
+        const bool host_loop = std::getenv("RSREG_SCHEME_HOST_LOOP") && std::getenv("RSREG_SCHEME_HOST_LOOP")[0] == '1';
         if (mode == "incremental") {
             IncrementalICP s;
+            s.device_resident = !host_loop;
             out = s.registration(clouds);
             for (auto &T : s.transforms) dump(f, T);
         } else if (mode == "icp_edge" || mode == "ndt_edge") {
             const float rads = -0.0261799f;  // -1.5 deg per frame: the synthetic "bench" preset's yaw
             if (mode == "icp_edge") {
                 ICPEdgeBasedRegistration s(rads);
+                s.device_resident = !host_loop;
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             } else {
                 NDTEdgeBasedRegistration s(rads);
+                s.device_resident = !host_loop;
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             }

@@ -147,6 +147,11 @@ def test_cpp_host_layer_matches_python_path(env, frames, runner, tmp_path, rs):
                       ("ndt_edge", schemes.NDTEdgeBasedRegistration)):
         pre = str(tmp_path / mode)
         subprocess.run([runner, mode, pre] + paths, check=True)
+        # the C++ layer's two frame loops (cloud handles in HBM, the default; host clouds) write the same files
+        pre_h = str(tmp_path / (mode + "_hostloop"))
+        subprocess.run([runner, mode, pre_h] + paths, check=True, env=dict(os.environ, RSREG_SCHEME_HOST_LOOP="1"))
+        assert open(pre + ".pcd", "rb").read() == open(pre_h + ".pcd", "rb").read()
+        assert open(pre + ".txt").read() == open(pre_h + ".txt").read()
         s = cls() if mode == "incremental" else cls(rads=RADS)
         merged = s.registration([f.copy() for f in frames])
         got = rs.load_pcd(pre + ".pcd")

@@ -46,7 +46,125 @@ def parse():
                          "even with one rank, e.g. under `torch.distributed.run --nproc-per-node 1`")
     ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
+    ap.add_argument("--workload", default="pair", choices=["pair", "chain"],
+                    help="pair: ONE 1M pair, source sharded over the ranks (configs[1]/[3], the headline line); "
+                         "chain: 2 x N frames of 300k points as consecutive pairs, one pair per GPU at a time (configs[4])")
     return ap.parse_args()
+
+
+def run_chain(a, rank, world, local_rank, dist):
+    """BASELINE configs[4]: a chain of frames as independent consecutive pairs (k-1, k), dealt round-robin
+    to the ranks, pair transforms gathered and composed on the host (rsreg_amd/chain.py).  Weak scaling:
+    2 x N frames (16 at N = 8), i.e. about two pairs per GPU whatever N.  No collective on the data path."""
+    import ctypes as C
+
+    import torch
+
+    from rsreg_amd import api, chain, lib, synth
+
+    size = "N300" if a.size == "N1M" else a.size     # the config's frame size unless another one is asked for
+    n_frames = 2 * world
+    mine = chain.pair_assignment(n_frames, rank, world)
+    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=not a.no_events)
+    need = sorted({k for k in mine} | {k - 1 for k in mine})
+    host = {k: synth.render_frame(k, size, "bench") for k in need}
+    dev = {k: api.DeviceCloud(host[k], ctx) for k in need}      # frames resident in HBM before the clock starts
+    perturb = synth.small_transform(0.5, (0.005, -0.004, 0.005))   # the guess a pose prior would give: truth off by 0.5 deg / 8 mm
+    guess = {k: np.ascontiguousarray((perturb @ synth.ground_truth(k, k - 1, "bench")).astype(np.float32).T) for k in mine}
+    L = lib.lib()
+    prm = api.icp_params(max_iterations=a.iterations, criteria_mode=1, pipeline_mode=a.pipeline, max_correspondence_distance=a.max_dist)
+    res = lib.IcpResult()
+    gi = lib.GridInfo()
+    n_pts = len(next(iter(host.values()))) if host else 0
+
+    def allgather(buf):
+        if dist is None:
+            return [buf]
+        t = torch.from_numpy(buf).cuda()
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [o.cpu().numpy() for o in outs]
+
+    stats = {"ms_nn": 0.0, "launch": 0, "ms_build": 0.0}
+
+    def step(collect=False):
+        local = {}
+        for k in mine:
+            lib.check(L.rsreg_icp_set_target_cloud(ctx.h, dev[k - 1].h, a.max_dist), ctx.h)
+            lib.check(L.rsreg_icp_set_source_cloud(ctx.h, dev[k].h), ctx.h)
+            lib.check(L.rsreg_icp_align(ctx.h, guess[k].ctypes.data, C.byref(prm), C.byref(res), None, 0), ctx.h)
+            local[k] = api._rowmajor(res.transform)
+            if collect:
+                stats["ms_nn"] += res.ms_nn
+                stats["launch"] += res.n_nn_launches
+                L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
+                stats["ms_build"] += gi.ms_build
+        return chain.compose_chain(chain.gather_pairs(local, n_frames, allgather), n_frames), local
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        poses, local = step(collect=True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    n_pairs = n_frames - 1
+    pairs = float(n_pts) * a.iterations * n_pairs * a.steps
+    n_unique, n_distinct = int(gi.n_unique_points), int(gi.n_source_distinct) or n_pts
+    alg_bytes = 32 * n_distinct + 16 * n_unique
+    avg_ms = stats["ms_nn"] / max(stats["launch"], 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    gt = [np.linalg.inv(synth.frame_pose(0, "bench")) @ synth.frame_pose(k, "bench") for k in range(n_frames)]
+    out = {
+        "metric": "point-pairs/sec per ICP iteration", "value": pairs / elapsed, "unit": "point-pairs/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "icp_chain_%dx%s_%dit_consecutive_pairs" % (n_frames, size, a.iterations), "n_frames": n_frames,
+            "points_per_frame": n_pts, "pairs": n_pairs, "iterations": a.iterations, "max_corr_dist": a.max_dist, "criteria": "fixed",
+            "sharding": "pairs (k-1, k) dealt round-robin to %d ranks, no collective on the data path; 4x4s gathered and composed on the host" % world,
+            "step": "every pair: index build + source load + %d iterations from frames resident in HBM; gather + composition of the chain" % a.iterations,
+            "deviation": "consecutive pairs instead of the reference's frame-to-model chain (incremental_icp.hpp:51-66 is sequential)",
+        },
+        "roofline": {"bound": "hbm", "kernel": "k_icp_fused_dense", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_ms": avg_ms, "launches": stats["launch"]},
+        "chain_pose_error_vs_ground_truth_frobenius_max": float(max(np.linalg.norm(poses[k] - gt[k]) for k in range(n_frames))),
+    }
+    if not a.no_cpu_baseline:
+        import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product
+
+        oracle.build()
+        k = mine[0]
+        o = oracle.IcpOracle()
+        p = oracle.IcpParams.default()
+        p.max_iterations, p.criteria_mode, p.max_correspondence_distance, p.num_threads = a.cpu_iterations, 1, a.max_dist, 1
+        tc = time.perf_counter()
+        o.set_target(host[k - 1].points, dedup=True)
+        o.set_source(host[k].points)
+        r = o.align(guess[k].T, p)
+        cpu_s = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": float(n_pts) * a.cpu_iterations / cpu_s, "unit": "point-pairs/s", "cores": 1, "kind": "port",
+                               "sample": "pair (%d, %d) of the chain, kd-tree build + %d of %d iterations, 1 thread" % (k - 1, k, a.cpu_iterations, a.iterations),
+                               "seconds": cpu_s, "host_cpus": os.cpu_count()}
+        prm2 = api.icp_params(max_iterations=a.cpu_iterations, criteria_mode=1, pipeline_mode=a.pipeline, max_correspondence_distance=a.max_dist)
+        lib.check(L.rsreg_icp_set_target_cloud(ctx.h, dev[k - 1].h, a.max_dist), ctx.h)
+        lib.check(L.rsreg_icp_set_source_cloud(ctx.h, dev[k].h), ctx.h)
+        lib.check(L.rsreg_icp_align(ctx.h, guess[k].ctypes.data, C.byref(prm2), C.byref(res), None, 0), ctx.h)
+        out["transform_error_vs_cpu_frobenius"] = float(np.linalg.norm(api._rowmajor(res.transform) - r.T))
+    return out
 
 
 def main():
@@ -79,6 +197,15 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if a.workload == "chain":
+        out = run_chain(a, rank, world, local_rank, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic D435i-like pair, identical on every rank
     tgt = synth.render_frame(0, a.size, "bench")

@@ -46,6 +46,20 @@ def test_bench_multi_rank_path_with_one_rank():
     assert j["n_gpus"] == 1 and j["value"] > 0
 
 
+def test_bench_chain_workload():
+    """BASELINE configs[4] as bench.py runs it: consecutive pairs, one per GPU at a time, frames resident in HBM."""
+    j = run(["bench.py", "--workload", "chain", "--size", "50k", "--steps", "2", "--warmup", "1", "--cpu-iterations", "2"])
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["scaling"] == "weak" and j["n_gpus"] == 1 and j["config"]["n_frames"] == 2 and j["config"]["pairs"] == 1
+    assert j["value"] > 0 and j["transform_error_vs_cpu_frobenius"] < 1e-4
+    assert j["chain_pose_error_vs_ground_truth_frobenius_max"] < 0.05
+    j2 = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+              str(29900 + os.getpid() % 90), "bench.py", "--gpus", "1", "--workload", "chain", "--size", "50k", "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline", "--force-dist"])
+    assert j2["config"]["workload"] == j["config"]["workload"] and j2["value"] > 0
+
+
 def test_device_resident_inputs_match_host_inputs():
     """rsreg_icp_set_{source,target}_device with record strides 12, 16 and 32 (tests/device_inputs_check.py)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "device_inputs_check.py")], cwd=ROOT, stdout=subprocess.PIPE,

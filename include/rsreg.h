@@ -302,6 +302,16 @@ int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
                            const float *guess, const rsreg_ndt_params *params, rsreg_ndt_result *result,
                            void *d_aligned_out);
 
+/* ---- edge features: extract_edge_features (src/edge_extractor.hpp:7-39) -------------------- */
+/* The reference's TwoPhaseRegistrationScheme::extract_features (icp_edge...hpp:21-23, ndt_edge...hpp:18-20).
+ * Of everything that function computes it returns only the points labelled EDGELABEL_RGB_CANNY
+ * (label_indices[4]): pcl::Edge::detectEdgeCanny (thresholds 40 / 100) on the gray image
+ * float((r + g + b) / 3) of the ORGANIZED cloud (width x height records, rgb at byte 16).  out must
+ * hold width*height records; indices_out (nullable) receives the edge points' indices, ascending. */
+int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t width, uint32_t height, size_t stride,
+                                void *out, int32_t *indices_out, size_t *n_out);
+int rsreg_cloud_edge_features(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
+
 /* ---- PCD files: the LZF coder of "DATA binary_compressed" bodies (host only, no ctx) ------ */
 /* pcl::io::loadPCDFile / savePCDFileBinaryCompressed as reached from main.cpp:53,81,87: the body
  * is u32 compressed size, u32 uncompressed size, then one LZF stream over the fields laid out one

@@ -434,6 +434,24 @@ template <typename PointT> void transformPointCloud(const DeviceCloud<PointT> &i
     check(rsreg_cloud_transform(in.context()->get(), in.handle(), T.data(), out.handle()), in.context()->get());
 }
 
+// ---- extract_edge_features (src/edge_extractor.hpp:7-39): the RGB-Canny edge points of an organized cloud
+inline std::shared_ptr<PointCloud<PointXYZRGB>> extract_edge_features(const std::shared_ptr<PointCloud<PointXYZRGB>> &cloud,
+                                                                      const std::shared_ptr<Context> &ctx = Context::Default())
+{
+    auto out = std::make_shared<PointCloud<PointXYZRGB>>();
+    if ((size_t)cloud->width * cloud->height != cloud->size()) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: edge extraction needs an organized cloud");
+    std::vector<PointXYZRGB> pts(cloud->size());
+    size_t n = 0;
+    check(rsreg_extract_edge_features(ctx->get(), cloud->points.data(), cloud->width, cloud->height, sizeof(PointXYZRGB), pts.data(), nullptr, &n),
+          ctx->get());
+    pts.resize(n);
+    out->points = std::move(pts);
+    out->width = (uint32_t)n;
+    out->height = 1;
+    out->is_dense = cloud->is_dense;
+    return out;
+}
+
 // ---- pcl::io: PCD files with FIELDS x y z rgb (ascii, binary, binary_compressed), as the reference reads/writes
 // (src/main.cpp:53,81,87)
 namespace io {

@@ -10,8 +10,8 @@
 // mutated (frame 0 IS the accumulating target), the hard-coded parameters, the order of
 // concatenation, frames whose ICP does not converge being skipped silently.
 //
-// Out of scope here: the RGB-Canny edge extractor.  `extract_features`
-// forwards to a user-supplied functor; the default hands the cloud through unchanged.
+// `extract_features` is the reference's extract_edge_features (src/edge_extractor.hpp:7-39: the RGB-Canny
+// edge points of the organized frame, rsreg_extract_edge_features) unless a `feature_fn` is plugged in.
 #pragma once
 
 #include <cassert>
@@ -55,7 +55,7 @@ class TwoPhaseRegistrationScheme : public RegistrationScheme {
     virtual rgb_point_cloud_pointer extract_features(rgb_point_cloud_pointer cloud)
     {
         if (feature_fn) return feature_fn(cloud);
-        return std::make_shared<rgb_point_cloud>(*cloud);  // stand-in for extract_edge_features
+        return extract_edge_features(cloud);   // icp_edge_based_registration.hpp:21-23, ndt_edge...hpp:18-20
     }
     // given (feature cloud, original cloud) pairs, compute the merged global cloud
     virtual rgb_point_cloud_pointer global_registration(PairList &clouds) = 0;

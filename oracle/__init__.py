@@ -11,6 +11,7 @@ from .oracle import (  # noqa: F401
     NdtParams,
     approx_voxel_grid,
     build,
+    edge_features,
     lib,
     mat4_mul,
     transform_cloud,

@@ -6,7 +6,7 @@ reference holds no fixtures — SURVEY.md §8c), so these vectors do NOT come fr
 reference: they come from a second, independently written implementation of the same
 published algorithms (brute-force float32 nearest neighbour + scipy cKDTree sanity check,
 numpy.linalg.svd Umeyama, pure-Python ApproximateVoxelGrid, numpy NDT score with finite-
-difference gradient/Hessian).  The C oracle (oracle/*.c) and the HIP path are both checked
+difference gradient/Hessian, numpy/scipy.ndimage Canny for the edge extractor).  The C oracle (oracle/*.c) and the HIP path are both checked
 against them.  Parity with PCL itself stays unpinned.
 
 Run:  python oracle/make_golden.py        (writes tests/golden/, a few seconds)
@@ -290,6 +290,53 @@ def fd_grad_hess(src, vox, pose, res):
 
 
 # ---------------------------------------------------------------- cases
+def rgb_canny_np(rgba, w, h, t_low=40.0, t_high=100.0):
+    """pcl::Edge::detectEdgeCanny on gray = (r + g + b) // 3 (what src/edge_extractor.hpp:7-39 returns the
+    points of): float32 shifted-add convolutions with clamped borders, numpy arctan2, non-maximum
+    suppression by boolean masks, hysteresis by scipy.ndimage.label -- written independently of
+    oracle/edge_oracle.c.  Returns the ascending indices of the edge pixels."""
+    from scipy import ndimage
+    r, g, b = (rgba >> 16) & 255, (rgba >> 8) & 255, rgba & 255
+    gray = ((r.astype(np.int64) + g + b) // 3).astype(f32).reshape(h, w)
+
+    def conv(img, k):
+        pad = np.pad(img, 1, mode="edge")
+        out = np.zeros_like(img)
+        for kr in range(3):
+            for kc in range(3):
+                out = (out + f32(k[kr][kc]) * pad[kr:kr + h, kc:kc + w]).astype(f32)
+        return out
+
+    kg = np.array([[np.exp(-(i * i + j * j) / 2.0) for j in (-1, 0, 1)] for i in (-1, 0, 1)]).astype(f32)   # exp in double, rounded once
+    tot = f32(0)
+    for v in kg.reshape(-1):
+        tot = f32(tot + v)
+    sm = conv(gray, (kg / tot).astype(f32))
+    gx = conv(sm, [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    gy = conv(sm, [[-1, -2, -1], [0, 0, 0], [1, 2, 1]])
+    mag = np.sqrt(gx * gx + gy * gy).astype(f32)
+    # (the angle as the correctly rounded float of the true angle: see oracle/edge_oracle.c on atan2f)
+    ang = (np.arctan2(gy.astype(np.float64), gx.astype(np.float64)).astype(f32) * f32(57.29578)).astype(f32)
+    d = np.full((h, w), -1)
+    d[((ang <= 22.5) & (ang >= -22.5)) | (ang >= 157.5) | (ang <= -157.5)] = 0
+    d[(d < 0) & (((ang > 22.5) & (ang < 67.5)) | ((ang < -112.5) & (ang > -157.5)))] = 45
+    d[(d < 0) & (((ang >= 67.5) & (ang <= 112.5)) | ((ang <= -67.5) & (ang >= -112.5)))] = 90
+    d[(d < 0) & (((ang > 112.5) & (ang < 157.5)) | ((ang < -22.5) & (ang > -67.5)))] = 135
+    mx = np.zeros((h, w), f32)
+    if h > 2 and w > 2:
+        nb = {0: ((0, -1), (0, 1)), 45: ((-1, -1), (1, 1)), 90: ((-1, 0), (1, 0)), 135: ((-1, 1), (1, -1))}
+        m = mag[1:h - 1, 1:w - 1]
+        for k, ((a0, a1), (b0, b1)) in nb.items():
+            A = mag[1 + a0:h - 1 + a0, 1 + a1:w - 1 + a1]
+            B = mag[1 + b0:h - 1 + b0, 1 + b1:w - 1 + b1]
+            sel = (d[1:h - 1, 1:w - 1] == k) & (m >= t_low) & (m >= A) & (m >= B)
+            mx[1:h - 1, 1:w - 1][sel] = m[sel]
+    lab, _ = ndimage.label(mx > 0, structure=np.ones((3, 3)))
+    strong = np.unique(lab[mx >= t_high])
+    keep = np.isin(lab, strong[strong > 0])
+    return np.nonzero(keep.reshape(-1))[0].astype(np.int32)
+
+
 def pack_trace(res, prefix, out, max_keep=3):
     for k, rec in enumerate(res["trace"][:max_keep]):
         out["%s_it%d_index" % (prefix, k)] = rec["index"]
@@ -373,6 +420,30 @@ def main():
            "vox_cov": np.array([v[2] for v in vox]), "vox_icov": np.array([v[3] for v in vox])}
     np.savez_compressed(os.path.join(OUT, "ndt_small.npz"), **out)
     print("ndt: voxels", len(vox), "score", s0)
+
+    # 6. edge extractor (RGB Canny of an organized cloud): a 160 x 120 frame, and two hand-made images: a step
+    # whose contrast fades along the edge from strong to weak (the hysteresis keeps the weak rows, they hang
+    # on the strong ones) beside a weak isolated blob (dropped); and the weak rows of that step alone (dropped)
+    c = synth.render_frame(1, (160, 120), "bench")
+    idx = rgb_canny_np(c.points["rgba"], 160, 120)
+
+    def fading_step(from_row):
+        img = np.full((40, 60), 90, np.int64)
+        for r in range(from_row, 40):
+            img[r, 30:] = 200 - (5 * r) // 2
+        img[5:9, 5:9] = 104
+        rec = np.zeros(img.size, rsreg_amd.POINT_DTYPE)
+        rec["rgba"] = (0xFF000000 | (img.reshape(-1) << 16) | (img.reshape(-1) << 8) | img.reshape(-1)).astype(np.uint32)
+        rec["w"] = 1.0
+        return rec
+
+    syn, weak = fading_step(0), fading_step(31)
+    idx2, idx3 = rgb_canny_np(syn["rgba"], 60, 40), rgb_canny_np(weak["rgba"], 60, 40)
+    assert len(idx3) == 0 and set(idx2 // 60) == set(range(1, 39))
+    out = {"frame": c.points, "frame_wh": np.array([160, 120]), "frame_edges": idx, "synthetic": syn, "synthetic_wh": np.array([60, 40]),
+           "synthetic_edges": idx2, "weak_only": weak, "weak_only_edges": idx3}
+    np.savez_compressed(os.path.join(OUT, "edge_canny.npz"), **out)
+    print("edges: frame", len(idx), "of", len(c), "; fading step", len(idx2), "; its weak rows alone", len(idx3))
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ NUM_SUMS = 17
 
 def build(force=False):
     """Compile the C restatement with gcc (Makefile in this directory)."""
-    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "ndt_oracle.c", "rsreg_oracle.h", "orc_linalg.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "ndt_oracle.c", "edge_oracle.c", "rsreg_oracle.h", "orc_linalg.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -111,6 +111,7 @@ def lib():
         L.orc_mat4_mul.restype = None
         L.orc_transform_cloud.argtypes = [vp, vp, sz, sz, i32, vp]
         L.orc_approx_voxel_grid.argtypes = [vp, sz, sz, vp, vp, C.POINTER(sz)]
+        L.orc_edge_rgb_canny.argtypes = [vp, sz, C.c_uint32, C.c_uint32, C.c_float, C.c_float, vp, C.POINTER(sz)]
         L.orc_ndt_create.restype = vp
         L.orc_ndt_destroy.argtypes = [vp]
         L.orc_ndt_set_centroid_mode.argtypes = [vp, i32]
@@ -289,3 +290,13 @@ def approx_voxel_grid(pts, leaf):
     n_out = C.c_size_t(0)
     assert lib().orc_approx_voxel_grid(p, n, s, leaf.ctypes.data, out.ctypes.data, C.byref(n_out)) == 0
     return out[: n_out.value].copy()
+
+
+def edge_features(pts, width, height, t_low=40.0, t_high=100.0):
+    """Indices of the RGB-Canny edge points of an organized cloud (src/edge_extractor.hpp:7-39)."""
+    a, p, n, s = _pts(pts)
+    assert n == width * height and s >= 20
+    idx = np.zeros(n, np.int32)
+    cnt = C.c_size_t(0)
+    assert lib().orc_edge_rgb_canny(p, s, width, height, t_low, t_high, idx.ctypes.data, C.byref(cnt)) == 0
+    return idx[: cnt.value].copy()

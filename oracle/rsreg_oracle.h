@@ -88,6 +88,12 @@ int orc_transform_cloud(const void *in, void *out, size_t n, size_t stride, int 
 int orc_approx_voxel_grid(const void *in, size_t n, size_t stride, const float leaf[3],
                           void *out, size_t *n_out);
 
+/* ---- edge extractor (src/edge_extractor.hpp:7-39: only the RGB-Canny edges are returned) ---- */
+/* indices (ascending) of the points of an organized cloud whose colour image has a Canny edge;
+ * indices_out must hold width*height entries (or be NULL to count only) */
+int orc_edge_rgb_canny(const void *pts, size_t stride, uint32_t width, uint32_t height, float t_low,
+                       float t_high, int32_t *indices_out, size_t *n_out);
+
 /* ---- NDT ---- */
 typedef struct orc_ndt_params {
     int32_t max_iterations, reserved;

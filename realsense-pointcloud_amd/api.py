@@ -484,6 +484,27 @@ def transformPointCloud(cloud, T, ctx=None):
     return PointCloud(out, width=cloud.width, height=cloud.height, is_dense=cloud.is_dense)
 
 
+def extract_edge_features(cloud, ctx=None, want_indices=False):
+    """extract_edge_features(cloud) of the reference (src/edge_extractor.hpp:7-39): the RGB-Canny edge points
+    of an ORGANIZED cloud, in index order.  A DeviceCloud in gives a DeviceCloud out."""
+    if isinstance(cloud, DeviceCloud):
+        out = DeviceCloud(ctx=cloud.ctx)
+        _l.check(_l.lib().rsreg_cloud_edge_features(cloud.ctx.h, cloud.h, out.h), cloud.ctx.h)
+        return out
+    ctx = ctx or default_context()
+    pts = np.ascontiguousarray(cloud.points)
+    if cloud.width * cloud.height != len(pts):
+        raise ValueError("edge extraction needs an organized cloud (width x height points)")
+    out = np.zeros_like(pts)
+    idx = np.zeros(len(pts), np.int32)
+    n_out = C.c_size_t(0)
+    _l.check(_l.lib().rsreg_extract_edge_features(ctx.h, pts.ctypes.data, cloud.width, cloud.height, pts.dtype.itemsize,
+                                                  out.ctypes.data, idx.ctypes.data, C.byref(n_out)), ctx.h)
+    n = n_out.value
+    res = PointCloud(out[:n].copy(), width=n, height=1, is_dense=cloud.is_dense)
+    return (res, idx[:n].copy()) if want_indices else res
+
+
 def umeyama_from_sums(sums):
     sums = np.ascontiguousarray(sums, np.float64)
     t = np.zeros(16, np.float32)

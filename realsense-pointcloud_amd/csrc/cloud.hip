@@ -131,6 +131,16 @@ int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *
 
 const void *rsreg_cloud_device_ptr(const rsreg_cloud *c) { return c ? c->buf.ptr : nullptr; }
 
+// (internal, edges.hip) the cloud takes a copy of the first n records of `buf`
+int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
+{
+    rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, c->buf.reserve(n * stride + 16));
+    if (n) RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, buf->ptr, n * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    c->n = n; c->stride = stride; c->width = width; c->height = height; c->is_dense = is_dense;
+    return RSREG_OK;
+}
+
 int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
 {
     int rc = check_pair(ctx, in, out);

@@ -1,0 +1,318 @@
+// edges.hip — the reference's edge extractor on the GPU (C ABI: include/rsreg.h, "edge features").
+//
+// Reference: src/edge_extractor.hpp:7-39.  extract_edge_features() runs integral-image normals and
+// pcl::OrganizedEdgeFromRGBNormals with all five edge types on, but returns only label_indices[4]
+// (:36-38), the points labelled EDGELABEL_RGB_CANNY.  That label comes from
+// OrganizedEdgeFromRGB::extractEdges alone: pcl::Edge::detectEdgeCanny (thresholds 40 / 100) on the
+// gray image float((r + g + b) / 3) of the organized cloud -- the normals, the depth discontinuities
+// and the curvature edges never reach the returned cloud, so they are not computed here.
+//
+// Stages (each pixel one thread; float operations un-fused and in PCL's order, file built with
+// -ffp-contract=off):  gray + 3x3 Gaussian (clamped borders)  ->  Sobel x / y, magnitude, direction
+// class  ->  non-maximum suppression on the interior  ->  hysteresis as connected components
+// (8-neighbourhood union-find; a component is kept if it holds a pixel >= the high threshold:
+// the set PCL's recursive tracing reaches, independent of its visiting order)  ->  ordered
+// compaction of the edge points' records.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "records.hpp"
+
+using namespace rsreg;
+
+struct rsreg_cloud;
+extern "C" {
+const void *rsreg_cloud_device_ptr(const rsreg_cloud *c);
+int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *width, uint32_t *height, int *is_dense);
+int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense);   // cloud.hip
+}
+
+namespace {
+
+struct Kernel3 {
+    float k[9];
+};
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// gray image, then pcl::Convolution with the 3x3 Gaussian: correlation, borders clamped, float sum over kernel rows then columns
+__global__ __launch_bounds__(kBlock) void k_edge_smooth(const char *rec, size_t stride, int w, int h, Kernel3 kg, float *sm)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w * h) return;
+    const int i = p / w, j = p - i * w;
+    float s = 0.0f;
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const int r = clampi(i + kr - 1, h - 1), c = clampi(j + kc - 1, w - 1);
+            const uint32_t col = *reinterpret_cast<const uint32_t *>(rec + (size_t)(r * w + c) * stride + 16);   // b g r a
+            const float g = (float)(((int)((col >> 16) & 255u) + (int)((col >> 8) & 255u) + (int)(col & 255u)) / 3);
+            s = __fadd_rn(s, __fmul_rn(kg.k[kr * 3 + kc], g));
+        }
+    sm[p] = s;
+}
+
+// Sobel x / y (same convolution), magnitude, direction discretised like pcl::Edge::discretizeAngles
+// (class 0 / 1 / 2 / 3 = 0 / 45 / 90 / 135 degrees, 255 = none of them: a NaN direction)
+__global__ __launch_bounds__(kBlock) void k_edge_sobel(const float *sm, int w, int h, float *mag, uint8_t *dir)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w * h) return;
+    const int i = p / w, j = p - i * w;
+    const float kx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, ky[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1};
+    float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const float v = sm[clampi(i + kr - 1, h - 1) * w + clampi(j + kc - 1, w - 1)];
+            gx = __fadd_rn(gx, __fmul_rn(kx[kr * 3 + kc], v));
+            gy = __fadd_rn(gy, __fmul_rn(ky[kr * 3 + kc], v));
+        }
+    mag[p] = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));   // (sqrtf is correctly rounded under hipcc's default; __fsqrt_rn is the 1-ulp native one)
+    // the angle as the correctly rounded float of atan2 (PCL's atan2f is libm-dependent in its last ulp: the
+    // double-precision result rounded once is what a correctly rounded atan2f returns, on every platform)
+    const float angle = __fmul_rn((float)atan2((double)gy, (double)gx), 57.29578f);   // pcl::rad2deg(float)
+    uint8_t d = 255;
+    if (((angle <= 22.5f) && (angle >= -22.5f)) || (angle >= 157.5f) || (angle <= -157.5f)) d = 0;
+    else if (((angle > 22.5f) && (angle < 67.5f)) || ((angle < -112.5f) && (angle > -157.5f))) d = 1;
+    else if (((angle >= 67.5f) && (angle <= 112.5f)) || ((angle <= -67.5f) && (angle >= -112.5f))) d = 2;
+    else if (((angle > 112.5f) && (angle < 157.5f)) || ((angle < -22.5f) && (angle > -67.5f))) d = 3;
+    dir[p] = d;
+}
+
+// pcl::Edge::suppressNonMaxima: interior pixels at or above the low threshold that are no smaller than
+// their two neighbours along the gradient keep their magnitude, everything else is 0.
+// label[p] = p for a kept pixel (its own component to start with), -1 otherwise.
+__global__ __launch_bounds__(kBlock) void k_edge_nms(const float *mag, const uint8_t *dir, int w, int h, float t_low, float *mx, int *label)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w * h) return;
+    const int i = p / w, j = p - i * w;
+    float out = 0.0f;
+    if (i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
+        const float m = mag[p];
+        const uint8_t d = dir[p];
+        if (!(m < t_low) && d != 255) {
+            const int o = d == 0 ? 1 : (d == 1 ? w + 1 : (d == 2 ? w : w - 1));   // (j-1, j+1) / (i-1 j-1, i+1 j+1) / (i-1, i+1) / (i-1 j+1, i+1 j-1)
+            if (m >= mag[p - o] && m >= mag[p + o]) out = m;
+        }
+    }
+    mx[p] = out;
+    label[p] = out != 0.0f ? p : -1;
+}
+
+__device__ __forceinline__ int cc_find(const int *label, int i)
+{
+    int l = label[i];
+    while (l != i) {
+        i = l;
+        l = label[i];
+    }
+    return i;
+}
+
+__device__ __forceinline__ void cc_union(int *label, int a, int b)
+{
+    bool done = false;
+    while (!done) {
+        a = cc_find(label, a);
+        b = cc_find(label, b);
+        if (a < b) {
+            const int old = atomicMin(&label[b], a);
+            done = old == b;
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&label[a], b);
+            done = old == a;
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+
+// 8-neighbourhood components of the kept pixels: every pixel joins its W, NW, N and NE neighbours
+__global__ __launch_bounds__(kBlock) void k_edge_cc_merge(const float *mx, int w, int h, int *label)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w * h || mx[p] == 0.0f) return;
+    const int i = p / w, j = p - i * w;
+    if (j > 0 && mx[p - 1] != 0.0f) cc_union(label, p, p - 1);
+    if (i > 0) {
+        if (j > 0 && mx[p - w - 1] != 0.0f) cc_union(label, p, p - w - 1);
+        if (mx[p - w] != 0.0f) cc_union(label, p, p - w);
+        if (j < w - 1 && mx[p - w + 1] != 0.0f) cc_union(label, p, p - w + 1);
+    }
+}
+
+// root of every kept pixel; a root whose component holds a pixel at or above the high threshold is marked strong
+__global__ __launch_bounds__(kBlock) void k_edge_cc_roots(const float *mx, int n, float t_high, int *label, uint32_t *strong)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || mx[p] == 0.0f) return;
+    const int r = cc_find(label, p);
+    if (!(mx[p] < t_high)) strong[r] = 1u;
+    __builtin_nontemporal_store(r, &label[p]);   // (a pixel's label only ever points at a smaller index of its own component)
+}
+
+__global__ __launch_bounds__(kBlock) void k_edge_flags(const float *mx, const int *label, const uint32_t *strong, int n, uint32_t *flag)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t f = 0;
+    if (mx[p] != 0.0f) f = strong[cc_find(label, p)];
+    flag[p] = f;
+}
+
+// pcl::copyPointCloud(cloud, indices, out): the edge points' records, in index order
+__global__ __launch_bounds__(kBlock) void k_edge_gather(const char *rec, size_t stride, int n, const uint32_t *flag, const uint32_t *pos,
+                                                        char *out, int32_t *indices)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || !flag[p]) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(rec + (size_t)p * stride);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)pos[p] * stride);
+    for (uint32_t k = 0; k < stride / 4; ++k) dst[k] = src[k];
+    if (indices) indices[pos[p]] = p;
+}
+
+// records in HBM -> edge points in ctx->d_vox_out (+ their indices in ctx->d_vals_alt); one host sync
+int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint32_t width, uint32_t height, uint32_t *n_out)
+{
+    *n_out = 0;
+    const size_t n = (size_t)width * height;
+    if (n == 0) return RSREG_OK;
+    if (n > 0x3fffffffull) return fail(ctx, RSREG_ERR_INVALID_ARG, "image too large");
+    hipStream_t st = ctx->stream;
+    const int w = (int)width, h = (int)height, N = (int)n;
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));       // smoothed | magnitude
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));   // maxima | labels
+    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));       // strong flags per root
+    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4 + 16));
+    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4 + 16));
+    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));   // indices of the edge points
+    RSREG_HIP(ctx, ctx->d_brick.reserve(n + 16));     // direction classes
+    RSREG_HIP(ctx, ctx->d_vox_out.reserve(n * stride));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(2048));
+    float *sm = ctx->d_keys.as<float>(), *mag = sm + n, *mx = ctx->d_keys_alt.as<float>();
+    int *label = reinterpret_cast<int *>(mx + n);
+    uint32_t *strong = ctx->d_vals.as<uint32_t>(), *flag = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
+    uint8_t *dir = ctx->d_brick.as<uint8_t>();
+    // pcl::kernel::gaussianKernel(size 3, sigma 1): exp of -(i^2 + j^2) / (2 sigma^2) as a float, normalised by the float
+    // sum.  (PCL calls expf at run time -- libm-dependent in the last ulp; here the correctly rounded float: exp in
+    // double, rounded once, the same on every platform and in the checker.)
+    Kernel3 kg;
+    float sum = 0.0f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int iks = i - 1, jks = j - 1;
+            kg.k[i * 3 + j] = (float)std::exp(-(double)(iks * iks + jks * jks) / 2.0);
+            sum += kg.k[i * 3 + j];
+        }
+    for (int i = 0; i < 9; ++i) kg.k[i] /= sum;
+    const float t_low = 40.0f, t_high = 100.0f;   // OrganizedEdgeFromRGB: th_rgb_canny_low_ / _high_ (never changed by the reference)
+    const uint32_t nb = div_up((uint32_t)N, kBlock);
+    k_edge_smooth<<<nb, kBlock, 0, st>>>(d_rec, stride, w, h, kg, sm);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_edge_sobel<<<nb, kBlock, 0, st>>>(sm, w, h, mag, dir);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_edge_nms<<<nb, kBlock, 0, st>>>(mag, dir, w, h, t_low, mx, label);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_edge_cc_merge<<<nb, kBlock, 0, st>>>(mx, w, h, label);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, hipMemsetAsync(strong, 0, n * 4, st));
+    k_edge_cc_roots<<<nb, kBlock, 0, st>>>(mx, N, t_high, label, strong);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_edge_flags<<<nb, kBlock, 0, st>>>(mx, label, strong, N, flag);
+    RSREG_HIP(ctx, hipGetLastError());
+    size_t scan_bytes = 0;
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(scan_bytes + 256));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+    k_edge_gather<<<nb, kBlock, 0, st>>>(d_rec, stride, N, flag, pos, ctx->d_vox_out.as<char>(), ctx->d_vals_alt.as<int32_t>());
+    RSREG_HIP(ctx, hipGetLastError());
+    if (const char *dump = std::getenv("RSREG_EDGE_DUMP")) {   // dev: the stage images, for a stage-by-stage comparison
+        std::vector<float> hbuf(n * 3);
+        std::vector<uint8_t> hdir(n);
+        (void)hipMemcpyAsync(hbuf.data(), sm, n * 4, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(hbuf.data() + n, mag, n * 4, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(hbuf.data() + 2 * n, mx, n * 4, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(hdir.data(), dir, n, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        if (FILE *f = std::fopen(dump, "wb")) {
+            std::fwrite(hbuf.data(), 4, hbuf.size(), f);
+            std::fwrite(hdir.data(), 1, n, f);
+            std::fclose(f);
+        }
+    }
+    uint32_t *hb = ctx->h_sums.as<uint32_t>() + 200;
+    RSREG_HIP(ctx, hipMemcpyAsync(hb, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipMemcpyAsync(hb + 1, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    *n_out = hb[0] + hb[1];
+    return RSREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// extract_edge_features(cloud) for an organized cloud handed over on the host
+int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t width, uint32_t height, size_t stride, void *out,
+                                int32_t *indices_out, size_t *n_out)
+{
+    const size_t n = (size_t)width * height;
+    if (!ctx || !n_out || (n && (!points || !out)) || stride < 20 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (n == 0) return RSREG_OK;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, ctx->d_vox_in.reserve(n * stride));
+    RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
+    {
+        char *stage = ctx->h_stage.as<char>();
+        const char *src = static_cast<const char *>(points);
+        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+    }
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t ne = 0;
+    int rc = edge_features_device(ctx, ctx->d_vox_in.as<char>(), stride, width, height, &ne);
+    if (rc || ne == 0) return rc;
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_vox_out.ptr, (size_t)ne * stride, hipMemcpyDeviceToHost, ctx->stream));
+    if (indices_out) RSREG_HIP(ctx, hipMemcpyAsync(indices_out, ctx->d_vals_alt.ptr, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_stage.ptr, (size_t)ne * stride);
+    *n_out = ne;
+    return RSREG_OK;
+}
+
+// the same on a cloud resident in HBM; out: width = number of edge points, height = 1, is_dense as the input's
+// (pcl::copyPointCloud (cloud, indices, out))
+int rsreg_cloud_edge_features(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
+{
+    if (!ctx || !in || !out) return RSREG_ERR_INVALID_ARG;
+    size_t n = 0, stride = 0;
+    uint32_t w = 0, h = 0;
+    int dense = 0;
+    int rc = rsreg_cloud_info(in, &n, &stride, &w, &h, &dense);
+    if (rc) return rc;
+    if ((size_t)w * h != n || stride < 20) return fail(ctx, RSREG_ERR_INVALID_ARG, "edge extraction needs an organized XYZRGB cloud");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t ne = 0;
+    rc = edge_features_device(ctx, static_cast<const char *>(rsreg_cloud_device_ptr(in)), stride, w, h, &ne);
+    if (rc) return rc;
+    return rsreg_cloud_adopt_(out, &ctx->d_vox_out, ne, stride, ne, 1, dense);
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip"]
+SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip", "edges.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
 UNIQUE_ID_BYTES = 128
@@ -31,6 +31,7 @@ EXPORTS = [
     "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_transform", "rsreg_cloud_concat",
     "rsreg_icp_set_target_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
+    "rsreg_extract_edge_features", "rsreg_cloud_edge_features",
     "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
 ]
 
@@ -185,6 +186,8 @@ def lib():
     L.rsreg_ndt_align_cloud.argtypes = [vp, vp, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp]
     L.rsreg_ndt_set_target_device.argtypes = [vp, vp, sz, sz, i32, dbl]
     L.rsreg_ndt_align_device.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp]
+    L.rsreg_extract_edge_features.argtypes = [vp, vp, u32, u32, sz, vp, vp, C.POINTER(sz)]
+    L.rsreg_cloud_edge_features.argtypes = [vp, vp, vp]
     L.rsreg_lzf_max_encoded_size.argtypes = [sz]
     L.rsreg_lzf_max_encoded_size.restype = sz
     for f in ("rsreg_lzf_encode", "rsreg_lzf_decode"):

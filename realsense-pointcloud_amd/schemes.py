@@ -4,8 +4,8 @@ Same surface and observable behaviour as the reference classes: ``IncrementalICP
 (src/incremental_icp.hpp:33-70), ``ICPEdgeBasedRegistration``
 (src/icp_edge_based_registration.hpp:10-136), ``NDTEdgeBasedRegistration``
 (src/ndt_edge_based_registration.hpp:7-123) and the two-phase driver (src/types.hpp:22-44).
-The RGB-Canny edge extractor is out of scope: ``extract_features`` calls a
-user-supplied function, by default the identity.
+``extract_features`` is the reference's ``extract_edge_features`` (src/edge_extractor.hpp:7-39: the
+RGB-Canny edge points of the organized frame) unless a ``feature_fn`` is plugged in.
 
 The numeric building blocks are injectable (``backend``): the default and only backend in
 this package is the HIP engine; tests/ plug a CPU checker into the very same scheme logic to
@@ -72,6 +72,9 @@ class HipBackend:
     def transform(self, cloud, T):
         return self.api.transformPointCloud(cloud, T, self.ctx)
 
+    def edge_features(self, cloud):
+        return self.api.extract_edge_features(cloud, self.ctx)
+
     # what a scheme does with whole clouds between the steps (host clouds here: nothing to move)
     def upload(self, cloud):
         return cloud
@@ -113,7 +116,7 @@ class TwoPhaseRegistrationScheme(RegistrationScheme):
     feature_fn = None
 
     def extract_features(self, cloud):
-        return self.feature_fn(cloud) if self.feature_fn else cloud.copy()
+        return self.feature_fn(cloud) if self.feature_fn else self.backend.edge_features(cloud)
 
     def global_registration(self, pairs):
         raise NotImplementedError

@@ -78,6 +78,11 @@ class OracleBackend:
         out = oracle.transform_cloud(np.ascontiguousarray(cloud.points), T, is_dense=cloud.is_dense)
         return PointCloud(out, cloud.width, cloud.height, cloud.is_dense)
 
+    def edge_features(self, cloud):
+        idx = oracle.edge_features(np.ascontiguousarray(cloud.points), cloud.width, cloud.height)
+        pts = np.ascontiguousarray(cloud.points[idx])
+        return PointCloud(pts, width=len(pts), height=1, is_dense=cloud.is_dense)
+
     def upload(self, cloud):
         return cloud
 

@@ -86,12 +86,6 @@ def test_icp_and_ndt_on_handles_match_host_clouds(api, rs, frames):
     _same_records(out[0][0], out[1][0])
 
 
-def _subsample(rs, cloud):
-    c = cloud.crop(0, 0, cloud.width, cloud.height, step=2)
-    pts = np.ascontiguousarray(c.points[c.points["z"] != 0])
-    return rs.PointCloud(pts, width=len(pts), height=1, is_dense=False)
-
-
 @pytest.mark.parametrize("kind", ["incremental", "icp_edge", "ndt_edge"])
 def test_schemes_device_loop_equals_host_loop(api, rs, kind):
     from rsreg_amd import schemes
@@ -103,7 +97,6 @@ def test_schemes_device_loop_equals_host_loop(api, rs, kind):
         else:
             cls = schemes.ICPEdgeBasedRegistration if kind == "icp_edge" else schemes.NDTEdgeBasedRegistration
             s = cls(rads=-0.0261799, backend=backend)
-            s.feature_fn = lambda c: _subsample(rs, c)
         clouds = [f.copy() for f in frames]
         merged = s.registration(clouds)
         tr = s.transforms if kind == "incremental" else [t for pair in s.frame_transforms for t in pair]

@@ -26,16 +26,8 @@ def env(rs):
 
 @pytest.fixture(scope="module")
 def frames(rs):
-    """Three organized 50k frames (BASELINE configs[0] shape) + a subsampled 'feature' view."""
+    """Three organized 50k frames (BASELINE configs[0] shape); the schemes take their RGB-Canny edge points as features."""
     return [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
-
-
-def subsample(cloud):
-    """Stand-in for the out-of-scope edge extractor: every 2nd pixel of the valid points."""
-    import rsreg_amd
-    c = cloud.crop(0, 0, cloud.width, cloud.height, step=2)
-    pts = np.ascontiguousarray(c.points[c.points["z"] != 0])
-    return rsreg_amd.PointCloud(pts, width=len(pts), height=1, is_dense=False)
 
 
 @pytest.fixture(scope="module")
@@ -83,7 +75,6 @@ def test_edge_schemes_match_checker(env, frames, kind):
     res = []
     for backend in (None, OracleBackend()):
         s = cls(rads=RADS, backend=backend)
-        s.feature_fn = subsample
         merged = s.registration([f.copy() for f in frames])
         res.append((merged, s.frame_transforms))
     (ma, ta), (mb, tb) = res
@@ -102,7 +93,6 @@ def test_imu_guess_variant(env, frames):
     out = []
     for backend in (None, OracleBackend()):
         s = schemes.ICPEdgeBasedRegistration(thetas=thetas, backend=backend)
-        s.feature_fn = subsample
         out.append((s.registration([f.copy() for f in frames]), s.frame_transforms, s.thetas))
     assert len(out[0][1]) == len(out[1][1])
     for (ca, ra), (cb, rb) in zip(out[0][1], out[1][1]):

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define RSREG_VERSION_MAJOR 0
-#define RSREG_VERSION_MINOR 1
+#define RSREG_VERSION_MINOR 2
 
 typedef struct rsreg_ctx rsreg_ctx;
 
@@ -93,6 +93,16 @@ typedef struct rsreg_icp_params {
     double transformation_epsilon;
     double transformation_rotation_epsilon;  /* <= 0: use 1 - transformation_epsilon (PCL) */
     double euclidean_fitness_epsilon;
+    /* Optional correspondence filters (both off by default and in rsreg_icp_params_reference: the reference
+     * constructs a CorrespondenceRejectorTrimmed and never attaches it, incremental_icp.hpp:38,
+     * icp_edge_based_registration.hpp:36, ndt_edge_based_registration.hpp:33).  Either one makes the
+     * iteration run as RSREG_PIPELINE_STAGED. */
+    int32_t use_reciprocal_correspondences;  /* icp.setUseReciprocalCorrespondences(true): a pair (s, t) is kept only if s
+                                                is also the nearest source point of t (lowest index among equidistant ones) */
+    int32_t reserved1;
+    double trim_overlap_ratio;               /* CorrespondenceRejectorTrimmed::setOverlapRatio(r), 0 < r < 1: of the gated
+                                                pairs the floor(r * count) closest are kept (equal distances: lowest
+                                                source index first); <= 0 or >= 1: no rejector */
 } rsreg_icp_params;
 
 /*

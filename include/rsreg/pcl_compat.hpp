@@ -239,6 +239,10 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     void setEuclideanFitnessEpsilon(double e) { prm_.euclidean_fitness_epsilon = e; }
     void setInputSource(const SourcePtr &cloud) { source_ = cloud; dsource_ = nullptr; source_dirty_ = true; }
     void setInputTarget(const TargetPtr &cloud) { target_ = cloud; dtarget_ = nullptr; target_dirty_ = true; }  // PCL rebuilds its kd-tree here too
+    // optional correspondence filters (off by default; the reference constructs a trimmed rejector and never attaches it)
+    void setUseReciprocalCorrespondences(bool on) { prm_.use_reciprocal_correspondences = on ? 1 : 0; }
+    // addCorrespondenceRejector (CorrespondenceRejectorTrimmed with setOverlapRatio (ratio)); <= 0 or >= 1: none
+    void setTrimmedRejectorOverlapRatio(double ratio) { prm_.trim_overlap_ratio = ratio; }
     // engine knobs without a PCL counterpart
     void setFixedIterationCount(bool on) { prm_.criteria_mode = on ? RSREG_CRITERIA_FIXED : RSREG_CRITERIA_PCL; }
     void setPipelineMode(int mode) { prm_.pipeline_mode = mode; }

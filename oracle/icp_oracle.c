@@ -483,6 +483,60 @@ int orc_icp_begin(orc_icp *o, const float *guess, const orc_icp_params *params)
     return 0;
 }
 
+/* CorrespondenceEstimation::determineReciprocalCorrespondences [PCL: registration/impl/correspondence_estimation.hpp,
+ * recalled]: a pair (i, t) survives only if i is the nearest source point of t (k-d tree over the CURRENT source,
+ * nearestKSearch (tgt[t], 1); here the lowest index among equidistant source points, like every search of this oracle) */
+static void recip_filter(orc_icp *o)
+{
+    int nv = 0;
+    float *pts = (float *)malloc((size_t)(o->ns ? o->ns : 1) * 12);
+    int *map = (int *)malloc((size_t)(o->ns ? o->ns : 1) * sizeof(int));
+    for (int i = 0; i < o->ns; i++)
+        if (o->svalid[i]) {
+            memcpy(pts + 3 * nv, o->cur + 3 * i, 12);
+            map[nv++] = i;
+        }
+    kd_tree *st = nv ? kd_build(pts, nv) : NULL;
+    for (int i = 0; i < o->ns; i++) {
+        if (o->cidx[i] < 0) continue;
+        int back = -1;
+        float d2 = 0.0f;
+        if (!st || !kd_nearest(st, o->txyz + 3 * o->cidx[i], &back, &d2) || map[back] != i) o->cidx[i] = -1;
+    }
+    if (st) kd_free(st);
+    free(pts);
+    free(map);
+}
+
+/* CorrespondenceRejectorTrimmed::getRemainingCorrespondences [PCL: registration/src/correspondence_rejection_trimmed.cpp,
+ * recalled]: number_valid = int (floor (overlap_ratio * float (size))); if smaller than size, std::nth_element by
+ * distance and resize: the number_valid closest pairs remain (which of several equidistant pairs nth_element keeps is
+ * unspecified; here: lowest source index first) */
+typedef struct trim_rec { float d2; int i; } trim_rec;
+static int trim_cmp(const void *a, const void *b)
+{
+    const trim_rec *x = (const trim_rec *)a, *y = (const trim_rec *)b;
+    if (x->d2 != y->d2) return x->d2 < y->d2 ? -1 : 1;
+    return x->i - y->i;
+}
+static void trim_filter(orc_icp *o)
+{
+    int n = 0;
+    trim_rec *r = (trim_rec *)malloc((size_t)(o->ns ? o->ns : 1) * sizeof(trim_rec));
+    for (int i = 0; i < o->ns; i++)
+        if (o->cidx[i] >= 0) {
+            r[n].d2 = o->cd2[i];
+            r[n].i = i;
+            n++;
+        }
+    const unsigned int keep = (unsigned int)(int)floorf((float)o->prm.trim_overlap_ratio * (float)n);
+    if (keep < (unsigned int)n) {
+        qsort(r, (size_t)n, sizeof(trim_rec), trim_cmp);
+        for (int k = (int)keep; k < n; k++) o->cidx[r[k].i] = -1;
+    }
+    free(r);
+}
+
 /* CorrespondenceEstimation::determineCorrespondences (A.1 + A.7a) */
 int orc_icp_search(orc_icp *o, int32_t *index_out, float *sqr_dist_out)
 {
@@ -519,6 +573,8 @@ int orc_icp_search(orc_icp *o, int32_t *index_out, float *sqr_dist_out)
             o->cd2[i] = ok ? d2 : 0.0f;
         }
     }
+    if (o->prm.use_reciprocal) recip_filter(o);
+    if (o->prm.trim_overlap_ratio > 0.0 && o->prm.trim_overlap_ratio < 1.0) trim_filter(o);
     uint64_t nc = 0;
     for (int i = 0; i < o->ns; i++) nc += o->cidx[i] >= 0;
     o->ncorr = nc;

@@ -28,6 +28,7 @@ class IcpParams(C.Structure):
         ("nn_mode", C.c_int32), ("dedup_target", C.c_int32), ("num_threads", C.c_int32),
         ("max_correspondence_distance", C.c_double), ("transformation_epsilon", C.c_double),
         ("transformation_rotation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
+        ("use_reciprocal", C.c_int32), ("reserved2", C.c_int32), ("trim_overlap_ratio", C.c_double),
     ]
 
     @classmethod

@@ -48,6 +48,11 @@ typedef struct orc_icp_params {
     double transformation_epsilon;
     double transformation_rotation_epsilon;
     double euclidean_fitness_epsilon;
+    /* optional correspondence filters (off in the reference: its CorrespondenceRejectorTrimmed is constructed and
+     * never attached, incremental_icp.hpp:38) */
+    int32_t use_reciprocal;      /* CorrespondenceEstimation::determineReciprocalCorrespondences               */
+    int32_t reserved2;
+    double trim_overlap_ratio;   /* CorrespondenceRejectorTrimmed::setOverlapRatio, 0 < r < 1; else no rejector  */
 } orc_icp_params;
 
 typedef struct orc_icp_result {

@@ -216,6 +216,14 @@ class IterativeClosestPoint:
     def setEuclideanFitnessEpsilon(self, e):
         self.params.euclidean_fitness_epsilon = float(e)
 
+    # optional correspondence filters of pcl::IterativeClosestPoint (off by default and in the reference)
+    def setUseReciprocalCorrespondences(self, on):
+        self.params.use_reciprocal_correspondences = int(bool(on))
+
+    def setTrimmedRejectorOverlapRatio(self, ratio):
+        """addCorrespondenceRejector(CorrespondenceRejectorTrimmed with setOverlapRatio(ratio)); <= 0 or >= 1: none."""
+        self.params.trim_overlap_ratio = float(ratio)
+
     # engine knobs (not in PCL)
     def setCriteriaMode(self, mode):
         self.params.criteria_mode = int(mode)

@@ -588,6 +588,88 @@ uint32_t *tile_stats(rsreg_ctx *ctx)
     return on ? ctx->d_misc.as<uint32_t>() + 32 : nullptr;
 }
 
+bool filters_on(const rsreg_icp_params &p)
+{
+    return p.use_reciprocal_correspondences != 0 || (p.trim_overlap_ratio > 0.0 && p.trim_overlap_ratio < 1.0);
+}
+
+// reciprocal check of one matched pair: is the source point the nearest source point of its target point?
+template <bool kDense>
+__global__ __launch_bounds__(kBlock) void k_recip_filter(const float4 *tgt, int *corr_pos, uint32_t *cw, uint32_t n, DenseDev gd, GridDev gh,
+                                                         const float4 *child_pts, const uint32_t *perm, const uint32_t *first)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int pos = corr_pos[u];
+    if (pos < 0) return;
+    const float4 t = tgt[pos];
+    const Best b = kDense ? nn_query_dense(gd, t.x, t.y, t.z, -1) : nn_query(gh, t.x, t.y, t.z, -1);
+    // the index over the source keeps the lowest original index of equal points and prefers it among equidistant ones:
+    // of the copies of a distinct source point only the first can be its target's nearest source point
+    const bool ok = b.pos >= 0 && __float_as_uint(child_pts[b.pos].w) == perm[first[u]];
+    cw[u] = ok ? 1u : 0u;
+    if (!ok) corr_pos[u] = -1;
+}
+
+// the optional filters PCL's ICP applies between determineCorrespondences and the transformation estimate:
+// reciprocal correspondences (CorrespondenceEstimation::determineReciprocalCorrespondences) and the trimmed rejector
+int apply_filters(rsreg_ctx *ctx)
+{
+    IcpState &s = ctx->icp;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)ctx->n_work, ns = (uint32_t)ctx->n_source;
+    if (!n) return RSREG_OK;
+    RSREG_HIP(ctx, ctx->d_corr_w.reserve((size_t)n * 4 + 16));
+    uint32_t *cw = ctx->d_corr_w.as<uint32_t>();
+    int *corr_pos = ctx->d_corr_pos.as<int>();
+    const uint32_t nb = div_up(n, kBlock);
+    k_corr_weights<<<nb, kBlock, 0, st>>>(corr_pos, ctx->d_cur.as<float4>(), n, cw);
+    RSREG_HIP(ctx, hipGetLastError());
+    if (s.prm.use_reciprocal_correspondences) {
+        // index the CURRENT source (it moves every iteration; PCL rebuilds its reciprocal kd-tree too), in the caller's order
+        if (!ctx->recip) {
+            int rc = rsreg_ctx_create(ctx->device, ctx->stream, &ctx->recip);
+            if (rc) return fail(ctx, rc, "context of the reciprocal index");
+        }
+        RSREG_HIP(ctx, ctx->d_recip_pts.reserve(((size_t)ns + 1) * sizeof(float4)));
+        k_recip_points<<<div_up(ns, kBlock), kBlock, 0, st>>>(ctx->d_cur.as<float4>(), ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(), ns,
+                                                           ctx->d_recip_pts.as<float4>());
+        RSREG_HIP(ctx, hipGetLastError());
+        rsreg_ctx *c = ctx->recip;
+        int rc = build_grid(c, ctx->d_recip_pts.as<char>(), ns, sizeof(float4), s.prm.max_correspondence_distance, 1.0);
+        if (rc) return fail(ctx, rc, c->last_error.c_str());
+        if (c->grid.n_points) {
+            const DenseDev gd = c->grid.dense ? dense_dev(c, s.prm.max_correspondence_distance) : DenseDev{};
+            const GridDev gh = grid_dev(c, s.prm.max_correspondence_distance);
+            auto kern = c->grid.dense ? k_recip_filter<true> : k_recip_filter<false>;
+            kern<<<nb, kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), corr_pos, cw, n, gd, gh, c->d_tgt_sorted.as<float4>(),
+                                        ctx->d_perm.as<uint32_t>(), ctx->d_first.as<uint32_t>());
+            RSREG_HIP(ctx, hipGetLastError());
+        }
+    }
+    if (s.prm.trim_overlap_ratio > 0.0 && s.prm.trim_overlap_ratio < 1.0) {
+        RSREG_HIP(ctx, ctx->d_keys.reserve((size_t)n * 8));
+        RSREG_HIP(ctx, ctx->d_keys_alt.reserve((size_t)n * 8));
+        RSREG_HIP(ctx, ctx->d_vals.reserve((size_t)n * 4));
+        RSREG_HIP(ctx, ctx->d_vals_alt.reserve((size_t)n * 4));
+        uint32_t *keys = ctx->d_keys.as<uint32_t>(), *vals = keys + n, *keys2 = ctx->d_keys_alt.as<uint32_t>(), *order = keys2 + n;
+        uint32_t *ws = ctx->d_vals.as<uint32_t>(), *cum = ctx->d_vals_alt.as<uint32_t>();
+        k_trim_keys<<<nb, kBlock, 0, st>>>(cw, ctx->d_corr_d2.as<float>(), n, keys, vals);
+        RSREG_HIP(ctx, hipGetLastError());
+        size_t sort_bytes = 0, scan_bytes = 0;
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));
+        RSREG_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));   // stable: ties by position
+        k_trim_gather<<<nb, kBlock, 0, st>>>(cw, order, n, ws);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, rocprim::inclusive_scan(ctx->d_tmp.ptr, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
+        k_trim_apply<<<nb, kBlock, 0, st>>>(order, ws, cum, n, (float)s.prm.trim_overlap_ratio, cw, corr_pos);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
+    return RSREG_OK;
+}
+
 int launch_search(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
@@ -610,6 +692,10 @@ int launch_search(rsreg_ctx *ctx)
                                                                        ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), seed_ptr(ctx));
         RSREG_HIP(ctx, hipGetLastError());
         s.n_nn_launches++;
+    }
+    if (filters_on(s.prm)) {
+        int rc = apply_filters(ctx);
+        if (rc) return rc;
     }
     s.have_search = true;
     return RSREG_OK;
@@ -635,9 +721,14 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
     const uint32_t n = (uint32_t)ctx->n_work;
     {
         ScopedEvents ev(ctx, &ctx->ev_reduce);
-        k_cov_reduce<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
-                                                                ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
-                                                                ctx->d_partials.as<double>());
+        if (filters_on(ctx->icp.prm))
+            k_cov_reduce_w<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
+                                                                      ctx->d_corr_d2.as<float>(), ctx->d_corr_w.as<uint32_t>(),
+                                                                      ctx->d_tgt_sorted.as<float4>(), n, ctx->d_partials.as<double>());
+        else
+            k_cov_reduce<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), ctx->d_corr_pos.as<int>(),
+                                                                    ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
+                                                                    ctx->d_partials.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
         k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
@@ -843,10 +934,14 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     rsreg_comm_destroy(ctx);
+    if (ctx->recip) {   // the child context of the reciprocal index runs on this context's stream: it goes first
+        rsreg_ctx_destroy(ctx->recip);
+        ctx->recip = nullptr;
+    }
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
-                      &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
+                      &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
@@ -990,9 +1085,14 @@ int rsreg_icp_search(rsreg_ctx *ctx, int32_t *index_out, float *sqr_dist_out)
         RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 8 + 32));
         int *d_idx = ctx->d_tmp.as<int>();
         float *d_d2 = reinterpret_cast<float *>(d_idx + n);
-        k_export_corr<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
-            ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), ctx->d_perm.as<uint32_t>(),
-            ctx->d_uniq_of.as<uint32_t>(), (uint32_t)n, d_idx, d_d2);
+        if (filters_on(ctx->icp.prm))
+            k_export_corr_w<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
+                ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), ctx->d_corr_w.as<uint32_t>(), ctx->d_tgt_sorted.as<float4>(),
+                ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(), ctx->d_first.as<uint32_t>(), (uint32_t)n, d_idx, d_d2);
+        else
+            k_export_corr<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(
+                ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), ctx->d_perm.as<uint32_t>(),
+                ctx->d_uniq_of.as<uint32_t>(), (uint32_t)n, d_idx, d_d2);
         RSREG_HIP(ctx, hipGetLastError());
         if (index_out) RSREG_HIP(ctx, hipMemcpyAsync(index_out, d_idx, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (sqr_dist_out) RSREG_HIP(ctx, hipMemcpyAsync(sqr_dist_out, d_d2, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1116,8 +1216,9 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     if (rc) return rc;
     int done = 0;
     double sums[RSREG_NUM_SUMS];
-    const bool fused = params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP;
-    if (params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
+    const bool filtered = filters_on(*params);   // the optional correspondence filters run between the staged kernels
+    const bool fused = !filtered && (params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP);
+    if (!filtered && params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
         !(!ctx->grid.dense && use_tile_kernel())) {
         rc = run_device_loop(ctx);
         if (rc) return rc;

@@ -712,9 +712,8 @@ __device__ __forceinline__ void halve_sums(const double (&v)[N], double (&out)[(
 // accumulate one accepted pair (p = source, q = target) into the 17 sums; w = how many
 // identical source points this one stands for (exact duplicates are searched once)
 __device__ __forceinline__ void accum_pair(double *a, float px, float py, float pz, float qx, float qy, float qz, float d2,
-                                           float w)
+                                           double W)
 {
-    const double W = (double)w;
     const double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
     a[0] += W;
     for (int k = 0; k < 3; ++k) { a[1 + k] += W * P[k]; a[4 + k] += W * Q[k]; }
@@ -902,6 +901,89 @@ __global__ __launch_bounds__(kBlock) void k_export_corr(const int *corr_pos, con
     const int pos = corr_pos[u];
     const uint32_t o = perm ? perm[j] : j;
     index_out[o] = pos >= 0 ? (int)__float_as_uint(tgt[pos].w) : -1;
+    d2_out[o] = corr_d2[u];
+}
+
+// ------------------------------------------------------------------------ optional correspondence filters
+// (rsreg_icp_params.use_reciprocal_correspondences / trim_overlap_ratio; staged pipeline only)
+
+// how many of the copies of distinct source point u take part: all of them once it has a match
+__global__ __launch_bounds__(kBlock) void k_corr_weights(const int *corr_pos, const float4 *cur, uint32_t n, uint32_t *cw)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) cw[u] = corr_pos[u] >= 0 ? (uint32_t)cur[u].w : 0u;
+}
+
+// the current source in the caller's order (one record per ORIGINAL point): what the reciprocal search indexes
+__global__ __launch_bounds__(kBlock) void k_recip_points(const float4 *cur, const uint32_t *perm, const uint32_t *uniq_of, uint32_t n_source,
+                                                         float4 *out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_source) out[perm[j]] = cur[uniq_of[j]];
+}
+
+// CorrespondenceRejectorTrimmed: sort keys (squared distance of the matched points, unmatched ones last)
+__global__ __launch_bounds__(kBlock) void k_trim_keys(const uint32_t *cw, const float *corr_d2, uint32_t n, uint32_t *keys, uint32_t *vals)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    keys[u] = cw[u] ? __float_as_uint(corr_d2[u]) : 0xffffffffu;   // (squared distances are >= 0: their bits order like the values)
+    vals[u] = u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_trim_gather(const uint32_t *cw, const uint32_t *order, uint32_t n, uint32_t *ws)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) ws[j] = cw[order[j]];
+}
+
+// of the pairs in order of distance, the first floor(ratio * count) are kept; cum = inclusive sums of ws
+__global__ __launch_bounds__(kBlock) void k_trim_apply(const uint32_t *order, const uint32_t *ws, const uint32_t *cum, uint32_t n, float ratio,
+                                                       uint32_t *cw, int *corr_pos)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t total = cum[n - 1];
+    const uint32_t k = (uint32_t)floorf(ratio * (float)total);   // (int)(floor(overlap_ratio_ * float(size))), in float like PCL
+    if (k >= total) return;                                       // "number_valid >= size": nothing to trim
+    const uint32_t before = cum[j] - ws[j];
+    const uint32_t keep = before >= k ? 0u : min(ws[j], k - before);
+    const uint32_t u = order[j];
+    cw[u] = keep;
+    if (!keep) corr_pos[u] = -1;
+}
+
+// the sums of k_cov_reduce with the copies-in-play of every pair given explicitly
+__global__ __launch_bounds__(kTile) void k_cov_reduce_w(const float4 *cur, const int *corr_pos, const float *corr_d2, const uint32_t *cw,
+                                                        const float4 *tgt, uint32_t n, double *partials)
+{
+    double a[RSREG_NUM_SUMS];
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int pos = corr_pos[i];
+        const uint32_t w = cw[i];
+        if (pos >= 0 && w) {
+            const float4 p = cur[i];
+            const float4 q = tgt[pos];
+            accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i], (double)w);
+        }
+    }
+    tile_reduce_store(a, partials, gridDim.x);
+}
+
+// determineCorrespondences' list with the filters applied: of the copies of a distinct point the first cw[u] (lowest indices) keep their match
+__global__ __launch_bounds__(kBlock) void k_export_corr_w(const int *corr_pos, const float *corr_d2, const uint32_t *cw, const float4 *tgt,
+                                                          const uint32_t *perm, const uint32_t *uniq_of, const uint32_t *first, uint32_t n,
+                                                          int *index_out, float *d2_out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t u = uniq_of[j];
+    const int pos = corr_pos[u];
+    const uint32_t o = perm ? perm[j] : j;
+    const bool kept = pos >= 0 && (j - first[u]) < cw[u];
+    index_out[o] = kept ? (int)__float_as_uint(tgt[pos].w) : -1;
     d2_out[o] = corr_d2[u];
 }
 

@@ -140,6 +140,10 @@ struct rsreg_ctx {
     rsreg::DevBuf d_partials;     // double[blocks][17]
     rsreg::DevBuf d_sums;         // double[17]
     rsreg::DevBuf d_icp_state;    // IcpDevState of the device-resident loop
+    // optional correspondence filters (reciprocal correspondences, trimmed rejector)
+    rsreg::DevBuf d_corr_w;       // uint32 per distinct source point: how many of its copies keep their match
+    rsreg::DevBuf d_recip_pts;    // float4 per ORIGINAL source point: the current source in the caller's order
+    rsreg_ctx *recip = nullptr;   // child context holding the index over the current source (reciprocal search)
     rsreg::PinnedBuf h_sums;      // pinned double[64]
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     rsreg::IcpState icp;

@@ -47,7 +47,8 @@ class IcpParams(C.Structure):
         ("max_iterations", C.c_int32), ("criteria_mode", C.c_int32), ("pipeline_mode", C.c_int32),
         ("reserved0", C.c_int32), ("max_correspondence_distance", C.c_double),
         ("transformation_epsilon", C.c_double), ("transformation_rotation_epsilon", C.c_double),
-        ("euclidean_fitness_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double), ("use_reciprocal_correspondences", C.c_int32), ("reserved1", C.c_int32),
+        ("trim_overlap_ratio", C.c_double),
     ]
 
 

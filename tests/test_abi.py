@@ -27,14 +27,14 @@ def test_header_and_exports_agree(L):
 
 
 def test_version_and_status_strings(L):
-    assert L.lib().rsreg_version() == 1
+    assert L.lib().rsreg_version() == 2          # 0.2: rsreg_icp_params grew the optional correspondence filters
     assert L.status_string(0) == "ok"
     assert "device" in L.status_string(-6)
 
 
 def test_struct_layouts_match_header(L):
     # sizes the C compiler gives the same structs
-    assert C.sizeof(L.IcpParams) == 48
+    assert C.sizeof(L.IcpParams) == 64
     assert C.sizeof(L.NdtParams) == 40
     assert C.sizeof(L.IcpResult) == 64 + 16 + 8 + 8 + 17 * 8 + 4 * 8 + 8
     assert C.sizeof(L.GridInfo) == 72
@@ -43,6 +43,7 @@ def test_struct_layouts_match_header(L):
 def test_reference_presets(rs, L):
     from rsreg_amd import api
     p = api.icp_params(reference=True)
+    assert p.use_reciprocal_correspondences == 0 and p.trim_overlap_ratio == 0.0   # the reference attaches no rejector
     # src/incremental_icp.hpp:46-49
     assert (p.max_iterations, p.max_correspondence_distance, p.transformation_epsilon, p.euclidean_fitness_epsilon) == (100, 0.01, 1.0, 1000.0)
     q = api.ndt_params(reference=True)

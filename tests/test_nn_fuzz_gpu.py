@@ -4,6 +4,8 @@ the target's box, gates from a fraction of a cell to unbounded -- each checked a
 brute force that follows FLANN's L2_Simple order ((dx^2 + dy^2) + dz^2) with the canonical
 tie-break (lowest target index), and PCL's gate (reject iff d^2 > max_dist^2 in double).
 Two search rounds per scene: the second starts from the seeds the first one left."""
+import os
+
 import numpy as np
 import pytest
 
@@ -149,3 +151,33 @@ def test_tiny_and_identical_clouds(api, rs):
         icp.end()
         icp.align()
         assert icp.hasConverged() == (n >= 3)        # PCL: fewer than 3 correspondences is a failure
+
+
+def test_long_grid_many_points_in_one_x_bucket(api, rs):
+    """The early exit of an x-sorted walk allows for what the sort order can be off by: one 2^-16 bucket
+    of the sort key plus the float rounding of the in-grid position, which grows with the grid (at
+    x - x0 = 16..32 m one ulp is 1.9 um).  A 30 m long target with thousands of points whose x differ
+    by fractions of an ulp-sized bucket, and queries a hair off them: still the brute-force answer."""
+    rng = np.random.default_rng(99)
+    n = 6000
+    base = np.zeros((n, 3))
+    base[:, 0] = 29.5 + rng.integers(0, 40, n) * 1.9e-6          # a few dozen distinct x values, all inside one or two sort buckets
+    base[:, 1] = rng.uniform(0, 0.012, n)
+    base[:, 2] = rng.uniform(0, 0.012, n)
+    anchor = np.array([[0.0, 0.0, 0.0], [30.0, 0.02, 0.02]])     # stretches the grid to 30 m
+    tgt = np.concatenate([base, anchor]).astype(np.float32)
+    src = (base[rng.permutation(n)[:1500]] + rng.normal(0, 4e-6, (1500, 3)) + np.array([0.0, 1e-4, -1e-4])).astype(np.float32)
+    for gate in (0.01, 0.0005):
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(max_iterations=2, criteria_mode=1, pipeline_mode=0, max_correspondence_distance=gate)
+        icp.setInputSource(rs.PointCloud.from_xyz(src))
+        icp.setInputTarget(rs.PointCloud.from_xyz(tgt))
+        icp.begin()
+        want_idx, want_d2 = brute(src, tgt, gate)
+        for _ in range(2):
+            idx, d2 = icp.search()
+            if not os.environ.get("RSREG_FORCE_HASH") and not os.environ.get("RSREG_DENSE_MAX_CELLS"):
+                assert icp.grid_info().index_kind == 1           # the dense table, the index with the x-sorted walks
+            assert np.array_equal(idx.astype(np.int64), want_idx)
+            assert np.array_equal(d2[want_idx >= 0], want_d2[want_idx >= 0])
+        icp.end()

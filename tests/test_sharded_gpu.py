@@ -98,3 +98,45 @@ def test_native_rccl_transport_single_rank(rs):
             out.append((bytes(icp.result.transform), bytes(icp.result.sums_last), icp.result.iterations, icp.result.state))
     assert out[0] == out[1] == out[2] == out[3]
     assert lib.lib().rsreg_comm_destroy(ctx.h) == 0
+
+
+def test_ndt_shards_by_source_blocks(rs):
+    """NDT shards like ICP: the score / gradient / Hessian of source blocks add up to the whole cloud's (what N
+    ranks all-reduce: 28 doubles per pass), and with a communicator attached rsreg_ndt_align runs that all-reduce
+    on the stream in every pass (here over one rank: RCCL refuses two ranks on the one device of the box)."""
+    from rsreg_amd import api, lib, synth
+    lib.build()
+    tgt = synth.render_frame(0, "50k", "bench")
+    src = synth.render_frame(1, "50k", "bench")
+    pose = np.array([0.01, -0.005, 0.008, 0.002, 0.03, -0.001])
+    whole = api.NormalDistributionsTransform(api.Context(0))
+    whole.params = api.ndt_params(reference=True)
+    whole.setInputSource(src)
+    whole.setInputTarget(tgt)
+    s_all, g_all, h_all = whole.derivatives(pose)
+    n = len(src)
+    acc = [0.0, np.zeros(6), np.zeros((6, 6))]
+    for lo, hi in ((0, n // 3), (n // 3, n // 2), (n // 2, n)):
+        part = api.NormalDistributionsTransform(api.Context(0))
+        part.params = api.ndt_params(reference=True)
+        part.setInputSource(np.ascontiguousarray(src.points[lo:hi]))
+        part.setInputTarget(tgt)
+        s, g, h = part.derivatives(pose)
+        acc[0] += s
+        acc[1] += g
+        acc[2] += h
+    assert abs(acc[0] - s_all) < 1e-9 * abs(s_all)
+    np.testing.assert_allclose(acc[1], g_all, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(acc[2], h_all, rtol=1e-9, atol=1e-7)
+    # the collective inside rsreg_ndt_align (one-rank communicator): same result as without one
+    ctx = api.Context(0)
+    ctx.comm_init(api.comm_unique_id(), 0, 1)
+    a = api.NormalDistributionsTransform(ctx)
+    a.params = api.ndt_params(reference=True)
+    a.setInputSource(src)
+    a.setInputTarget(tgt)
+    a.align(synth.small_transform(1.0, (0, 0, 0)).astype(np.float32))
+    whole.align(synth.small_transform(1.0, (0, 0, 0)).astype(np.float32))
+    np.testing.assert_array_equal(a.getFinalTransformation(), whole.getFinalTransformation())
+    assert (a.result.iterations, a.result.n_derivative_passes) == (whole.result.iterations, whole.result.n_derivative_passes)
+    assert lib.lib().rsreg_comm_destroy(ctx.h) == 0

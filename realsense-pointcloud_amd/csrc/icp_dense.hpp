@@ -179,7 +179,11 @@ __device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u
     const f32x2 sq = dxy * dxy;
     const float dz = __fsub_rn(qz, __uint_as_float(t.z));
     const float d = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
-    const bool better = (d < b.d) | ((d == b.d) & (t.w < b.idx));
+    // (distance, original index) ordered as one 64-bit key: squared distances are >= 0, so their bit patterns
+    // order like their values, and the lower index wins among equal distances
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | t.w;
+    const unsigned long long bkey = ((unsigned long long)__float_as_uint(b.d) << 32) | b.idx;
+    const bool better = key < bkey;
     b.d = better ? d : b.d;
     b.idx = better ? t.w : b.idx;
     b.off = better ? off : b.off;

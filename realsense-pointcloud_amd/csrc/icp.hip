@@ -172,6 +172,7 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.n_pts = p.n_points;
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
     g.nbr = ctx->d_nbr.as<uint32_t>();
+    g.pos_of = ctx->d_pos_of.as<uint32_t>();
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
     // how far the x order of a sorted run can be off: one 2^-16 bucket of the sort key, plus the float
@@ -213,6 +214,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4));
     RSREG_HIP(ctx, ctx->d_nbr.reserve((total + 2) * 4));
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_pos_of.reserve((n + 1) * 4));
     k_dense_fill_sentinels<<<div_up(nfin + 4, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), nfin + 4);
     RSREG_HIP(ctx, hipGetLastError());
     const DenseDev g = dense_dev(ctx, max_dist);
@@ -243,7 +245,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, pos, cid, ctx->d_tgt_sorted.as<float4>(),
-                                            cellslot, cellpos, d_misc + 8);
+                                            ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
     RSREG_HIP(ctx, hipGetLastError());
@@ -266,7 +268,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     gi.n_cells = gp.n_cells;
     gi.max_points_per_cell = 0;   // dense mode: computed on demand by rsreg_icp_grid_info
     gi.index_kind = 1;
-    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t);
+    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t) + (uint64_t)n * sizeof(uint32_t);
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -939,7 +941,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ctx->recip = nullptr;
     }
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_pos_of, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm};

@@ -38,6 +38,7 @@ struct DenseDev {
                              // cell assignment, which grows with the grid (6e-7 x its largest dimension, >= 0.004)
     float x_slack;           // metres: slack on the x order of a sorted run (sort-key bucket + float rounding of the position)
     const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
+    const uint32_t *pos_of;  // original index -> position in pts (kept points only)
 };
 
 __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int y, int z)
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill_sentinels(float4 *sorted,
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long long *keys, const uint32_t *vals, const char *pts,
                                                           size_t stride, uint32_t nfin, const uint32_t *keep,
                                                           const uint32_t *cstart, const uint32_t *pos, const uint32_t *cid,
-                                                          float4 *sorted, uint32_t *cellslot, uint32_t *cellpos,
-                                                          uint32_t *stats)
+                                                          float4 *sorted, uint32_t *pos_of, uint32_t *cellslot,
+                                                          uint32_t *cellpos, uint32_t *stats)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         const uint32_t v = vals[i];
         const float *p = rec_xyz(pts, stride, v);
         sorted[pos[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(v));
+        pos_of[v] = pos[i];
     }
     if (cstart[i]) {
         cellslot[cid[i]] = (uint32_t)(keys[i] >> 16);
@@ -162,17 +164,17 @@ __device__ __forceinline__ float sel3(float a, float b, float c, int i) { return
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
-// running best: squared distance, original index (the tie-break) and the byte offset of the
-// winning point; starts at "+inf, no point" so that the far-away sentinel points never win
+// running best: squared distance and original index (the tie-break) of the winning point -- its
+// place in the sorted array is looked up once at the end (pos_of), not carried through every
+// comparison; starts at "+inf, no point" so that the far-away sentinel points never win
 struct DBest {
     float d;
     uint32_t idx;
-    uint32_t off;
 };
 
 // FLANN L2_Simple in its own order ((dx^2 + dy^2) + dz^2, nothing fused); x and y go through
 // the packed f32 pipe straight out of the loaded register pair
-__device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u32x4 &t, uint32_t off)
+__device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u32x4 &t)
 {
     const f32x2 txy = {__uint_as_float(t.x), __uint_as_float(t.y)};
     const f32x2 dxy = qxy - txy;
@@ -186,7 +188,6 @@ __device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u
     const bool better = key < bkey;
     b.d = better ? d : b.d;
     b.idx = better ? t.w : b.idx;
-    b.off = better ? off : b.off;
 }
 
 // score 4 consecutive points starting at byte offset `po` (reading past the end of a cell
@@ -197,10 +198,10 @@ __device__ __forceinline__ void dscan4(DBest &b, __amdgpu_buffer_rsrc_t pts, uin
     const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 16, 0, 0);
     const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 32, 0, 0);
     const u32x4 t3 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 48, 0, 0);
-    dconsider(b, qxy, qz, t0, po);
-    dconsider(b, qxy, qz, t1, po + 16);
-    dconsider(b, qxy, qz, t2, po + 32);
-    dconsider(b, qxy, qz, t3, po + 48);
+    dconsider(b, qxy, qz, t0);
+    dconsider(b, qxy, qz, t1);
+    dconsider(b, qxy, qz, t2);
+    dconsider(b, qxy, qz, t3);
 }
 
 __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, f32x2 qxy, float qz)
@@ -244,10 +245,10 @@ __device__ __forceinline__ void dwalk_step(DWalk &w, DBest &b, __amdgpu_buffer_r
     const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 16, 0, 0);
     const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 32, 0, 0);
     const u32x4 t3 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 48, 0, 0);
-    dconsider(b, qxy, qz, t0, po);
-    dconsider(b, qxy, qz, t1, po + 16);
-    dconsider(b, qxy, qz, t2, po + 32);
-    dconsider(b, qxy, qz, t3, po + 48);
+    dconsider(b, qxy, qz, t0);
+    dconsider(b, qxy, qz, t1);
+    dconsider(b, qxy, qz, t2);
+    dconsider(b, qxy, qz, t3);
     limit2 = fminf(limit2, b.d);
     // beyond this chunk (in walking direction) every point of the cell is at least `gap` away in x
     const float gap = (w.back ? qxy.x - __uint_as_float(t0.x) : __uint_as_float(t3.x) - qxy.x) - x_slack;
@@ -295,7 +296,7 @@ __device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int 
 {
     if (seed_pos >= 0) {
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs.pts, (uint32_t)seed_pos * 16u, 0, 0);
-        dconsider(b, f32x2{q.qx, q.qy}, q.qz, t, (uint32_t)seed_pos * 16u);
+        dconsider(b, f32x2{q.qx, q.qy}, q.qz, t);
         limit2 = fminf(limit2, b.d);
     }
 }
@@ -455,12 +456,12 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
     }
 }
 
-__device__ __forceinline__ Best dense_result(const DBest &b)
+__device__ __forceinline__ Best dense_result(const DenseDev &g, const DBest &b)
 {
     Best out{~0ull, -1, FLT_MAX};
-    if (b.off != 0xffffffffu) {
+    if (b.idx != 0xffffffffu) {
         out.key = ((unsigned long long)__float_as_uint(b.d) << 32) | b.idx;
-        out.pos = (int)(b.off >> 4);
+        out.pos = (int)g.pos_of[b.idx];
         out.d2 = b.d;
     }
     return out;
@@ -474,13 +475,13 @@ __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, floa
     const DRes rs = dense_res(g);
     const DQuery q = dense_query(g, qx, qy, qz);
     float limit2 = g.prune2;
-    DBest b{__uint_as_float(0x7f800000u), 0xffffffffu, 0xffffffffu};
+    DBest b{__uint_as_float(0x7f800000u), 0xffffffffu};
     dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, dg);
     if (kDiag) dg->t_near = wall_clock64();
     const bool far = dense_needs_far(g, limit2);
     if (far) dense_far<kDiag>(g, rs, q, b, limit2, dg);
     if (kDiag) dg->t_far = wall_clock64();
-    return dense_result(b);
+    return dense_result(g, b);
 }
 
 __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, uint32_t n, DenseDev g, double gate2,

@@ -213,7 +213,10 @@ __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts
 // from the end that is nearer to the query in x and stops as soon as the x distance alone
 // exceeds the best so far: everything behind that point is farther still.
 struct DWalk {
-    uint32_t cur, lo;   // forward: next chunk starts at cur; backward: the chunk before cur; lo = the cell's first byte
+    uint32_t cur;       // first byte of the next chunk to read, in either direction
+    uint32_t floor64;   // backward: the cell's first byte + 64 (the last chunk of a backward walk starts at the cell's
+                        // first point); forward: 0.  next = max(cur, floor64) + step in both directions
+    uint32_t step;      // +64 / -64 (mod 2^32)
     int left;           // chunks still to read (0: nothing)
     bool back;
     float yz2;          // what every point of this cell is away from the query in y and z at least, squared
@@ -222,24 +225,28 @@ struct DWalk {
 __device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back, float yz2)
 {
     w.yz2 = yz2;
-    w.lo = se.x * 16u;
     w.left = (int)((se.y - se.x + 3u) >> 2);
     w.back = back;
-    w.cur = back ? se.y * 16u : w.lo;
+    w.floor64 = back ? se.x * 16u + 64u : 0u;
+    w.step = back ? 0u - 64u : 64u;
+    w.cur = back ? max(se.y * 16u, w.floor64) - 64u : se.x * 16u;
+}
+
+// running limit = min(limit, best): one v_min (both are squared distances or +inf, never NaN, so the
+// canonicalising max pair the compiler puts around fminf is not needed)
+__device__ __forceinline__ float min_nn(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // one chunk; x_slack = how far the x order inside a cell can be off (quantisation of the sort key)
 __device__ __forceinline__ void dwalk_step(DWalk &w, DBest &b, __amdgpu_buffer_rsrc_t pts, f32x2 qxy, float qz, float x_slack,
                                            float &limit2)
 {
-    uint32_t po;
-    if (w.back) {
-        po = (w.cur - w.lo >= 64u) ? w.cur - 64u : w.lo;   // the last chunk of a backward walk starts at the cell's first point
-        w.cur = po;
-    } else {
-        po = w.cur;
-        w.cur += 64u;
-    }
+    const uint32_t po = w.cur;
+    w.cur = max(po, w.floor64) + w.step;
     --w.left;
     const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(pts, po, 0, 0);
     const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(pts, po + 16, 0, 0);
@@ -249,7 +256,7 @@ __device__ __forceinline__ void dwalk_step(DWalk &w, DBest &b, __amdgpu_buffer_r
     dconsider(b, qxy, qz, t1);
     dconsider(b, qxy, qz, t2);
     dconsider(b, qxy, qz, t3);
-    limit2 = fminf(limit2, b.d);
+    limit2 = min_nn(limit2, b.d);
     // beyond this chunk (in walking direction) every point of the cell is at least `gap` away in x
     const float gap = (w.back ? qxy.x - __uint_as_float(t0.x) : __uint_as_float(t3.x) - qxy.x) - x_slack;
     if (gap > 0.0f && gap * gap + w.yz2 > limit2) w.left = 0;

@@ -605,10 +605,10 @@ __global__ __launch_bounds__(kBlock) void k_recip_filter(const float4 *tgt, int 
     const int pos = corr_pos[u];
     if (pos < 0) return;
     const float4 t = tgt[pos];
-    const Best b = kDense ? nn_query_dense(gd, t.x, t.y, t.z, -1) : nn_query(gh, t.x, t.y, t.z, -1);
+    const Best b = kDense ? nn_query_dense(gd, t.x, t.y, tgt_z(t), -1) : nn_query(gh, t.x, t.y, tgt_z(t), -1);
     // the index over the source keeps the lowest original index of equal points and prefers it among equidistant ones:
     // of the copies of a distinct source point only the first can be its target's nearest source point
-    const bool ok = b.pos >= 0 && __float_as_uint(child_pts[b.pos].w) == perm[first[u]];
+    const bool ok = b.pos >= 0 && tgt_idx(child_pts[b.pos]) == perm[first[u]];
     cw[u] = ok ? 1u : 0u;
     if (!ok) corr_pos[u] = -1;
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long 
 __global__ __launch_bounds__(kBlock) void k_dense_fill_sentinels(float4 *sorted, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sorted[i] = make_float4(1e30f, 1e30f, 1e30f, __uint_as_float(0xffffffffu));
+    if (i < n) sorted[i] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
 }
 
 // the sorted point array, and for every occupied cell (in sorted order) its table slot and the
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
     if (keep[i]) {
         const uint32_t v = vals[i];
         const float *p = rec_xyz(pts, stride, v);
-        sorted[pos[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(v));
+        sorted[pos[i]] = tgt_rec(p[0], p[1], p[2], v);
         pos_of[v] = pos[i];
     }
     if (cstart[i]) {
@@ -173,21 +173,21 @@ struct DBest {
 };
 
 // FLANN L2_Simple in its own order ((dx^2 + dy^2) + dz^2, nothing fused); x and y go through
-// the packed f32 pipe straight out of the loaded register pair
+// the packed f32 pipe straight out of the loaded register pair; a record is (x, y, index, z), see tgt_rec
 __device__ __forceinline__ void dconsider(DBest &b, f32x2 qxy, float qz, const u32x4 &t)
 {
     const f32x2 txy = {__uint_as_float(t.x), __uint_as_float(t.y)};
     const f32x2 dxy = qxy - txy;
     const f32x2 sq = dxy * dxy;
-    const float dz = __fsub_rn(qz, __uint_as_float(t.z));
+    const float dz = __fsub_rn(qz, __uint_as_float(t.w));
     const float d = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
     // (distance, original index) ordered as one 64-bit key: squared distances are >= 0, so their bit patterns
     // order like their values, and the lower index wins among equal distances
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | t.w;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | t.z;
     const unsigned long long bkey = ((unsigned long long)__float_as_uint(b.d) << 32) | b.idx;
     const bool better = key < bkey;
     b.d = better ? d : b.d;
-    b.idx = better ? t.w : b.idx;
+    b.idx = better ? t.z : b.idx;
 }
 
 // score 4 consecutive points starting at byte offset `po` (reading past the end of a cell
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
         const float4 t = g.pts[pos];
-        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
+        accum_pair(a, q.x, q.y, q.z, t.x, t.y, tgt_z(t), d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
     if (kDiag) {

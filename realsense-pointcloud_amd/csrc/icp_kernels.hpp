@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_sorted(const unsigned long l
     const unsigned long long k = keys[i];
     if (keep[i]) {
         const float *p = rec_xyz(pts, stride, v);
-        sorted[pos[i]] = make_float4(p[0], p[1], p[2], __uint_as_float(v));
+        sorted[pos[i]] = tgt_rec(p[0], p[1], p[2], v);
     }
     if (cstart[i]) {
         cellpos[cid[i]] = pos[i];
@@ -466,10 +466,10 @@ __device__ __forceinline__ void scan_points(const float4 *pts, uint32_t s, uint3
     for (uint32_t p = s; p < e; p += 4) {
         const uint32_t p1 = min(p + 1, last), p2 = min(p + 2, last), p3 = min(p + 3, last);
         const float4 t0 = pts[p], t1 = pts[p1], t2 = pts[p2], t3 = pts[p3];
-        consider(b, l2_simple(qx, qy, qz, t0.x, t0.y, t0.z), __float_as_uint(t0.w), p);
-        consider(b, l2_simple(qx, qy, qz, t1.x, t1.y, t1.z), __float_as_uint(t1.w), p1);
-        consider(b, l2_simple(qx, qy, qz, t2.x, t2.y, t2.z), __float_as_uint(t2.w), p2);
-        consider(b, l2_simple(qx, qy, qz, t3.x, t3.y, t3.z), __float_as_uint(t3.w), p3);
+        consider(b, l2_simple(qx, qy, qz, t0.x, t0.y, tgt_z(t0)), tgt_idx(t0), p);
+        consider(b, l2_simple(qx, qy, qz, t1.x, t1.y, tgt_z(t1)), tgt_idx(t1), p1);
+        consider(b, l2_simple(qx, qy, qz, t2.x, t2.y, tgt_z(t2)), tgt_idx(t2), p2);
+        consider(b, l2_simple(qx, qy, qz, t3.x, t3.y, tgt_z(t3)), tgt_idx(t3), p3);
     }
 }
 
@@ -656,7 +656,7 @@ __device__ __forceinline__ Best nn_query(const GridDev &g, float qx, float qy, f
     float limit2 = g.prune2;  // nothing farther than this can be accepted or improve the best
     if (seed_pos >= 0) {
         const float4 t = g.pts[seed_pos];
-        consider(b, l2_simple(qx, qy, qz, t.x, t.y, t.z), __float_as_uint(t.w), (uint32_t)seed_pos);
+        consider(b, l2_simple(qx, qy, qz, t.x, t.y, tgt_z(t)), tgt_idx(t), (uint32_t)seed_pos);
         limit2 = fminf(limit2, b.d2);
     }
     nn_near_global(g, qg, qx, qy, qz, b, limit2);
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const i
         if (pos >= 0) {
             const float4 p = cur[i];
             const float4 q = tgt[pos];
-            accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i], p.w);
+            accum_pair(a, p.x, p.y, p.z, q.x, q.y, tgt_z(q), corr_d2[i], p.w);
         }
     }
     tile_reduce_store(a, partials, gridDim.x);
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Ma
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
         const float4 t = g.pts[pos];
-        accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
+        accum_pair(a, q.x, q.y, q.z, t.x, t.y, tgt_z(t), d2, q.w);
     }
     tile_reduce_store(a, partials, gridDim.x);
 }
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void k_export_corr(const int *corr_pos, con
     const uint32_t u = uniq_of[j];
     const int pos = corr_pos[u];
     const uint32_t o = perm ? perm[j] : j;
-    index_out[o] = pos >= 0 ? (int)__float_as_uint(tgt[pos].w) : -1;
+    index_out[o] = pos >= 0 ? (int)tgt_idx(tgt[pos]) : -1;
     d2_out[o] = corr_d2[u];
 }
 
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce_w(const float4 *cur, const
         if (pos >= 0 && w) {
             const float4 p = cur[i];
             const float4 q = tgt[pos];
-            accum_pair(a, p.x, p.y, p.z, q.x, q.y, q.z, corr_d2[i], (double)w);
+            accum_pair(a, p.x, p.y, p.z, q.x, q.y, tgt_z(q), corr_d2[i], (double)w);
         }
     }
     tile_reduce_store(a, partials, gridDim.x);
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(kBlock) void k_export_corr_w(const int *corr_pos, c
     const int pos = corr_pos[u];
     const uint32_t o = perm ? perm[j] : j;
     const bool kept = pos >= 0 && (j - first[u]) < cw[u];
-    index_out[o] = kept ? (int)__float_as_uint(tgt[pos].w) : -1;
+    index_out[o] = kept ? (int)tgt_idx(tgt[pos]) : -1;
     d2_out[o] = corr_d2[u];
 }
 

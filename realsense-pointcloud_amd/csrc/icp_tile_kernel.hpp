@@ -51,10 +51,10 @@ __device__ __forceinline__ void scan_points_lds(const float4 *pts, uint32_t s, u
     for (uint32_t p = s; p < e; p += 4) {
         const uint32_t p1 = min(p + 1, last), p2 = min(p + 2, last), p3 = min(p + 3, last);
         const float4 t0 = pts[p], t1 = pts[p1], t2 = pts[p2], t3 = pts[p3];
-        consider(b, l2_simple(qx, qy, qz, t0.x, t0.y, t0.z), __float_as_uint(t0.w), gpos0 + (p - s));
-        consider(b, l2_simple(qx, qy, qz, t1.x, t1.y, t1.z), __float_as_uint(t1.w), gpos0 + (p1 - s));
-        consider(b, l2_simple(qx, qy, qz, t2.x, t2.y, t2.z), __float_as_uint(t2.w), gpos0 + (p2 - s));
-        consider(b, l2_simple(qx, qy, qz, t3.x, t3.y, t3.z), __float_as_uint(t3.w), gpos0 + (p3 - s));
+        consider(b, l2_simple(qx, qy, qz, t0.x, t0.y, tgt_z(t0)), tgt_idx(t0), gpos0 + (p - s));
+        consider(b, l2_simple(qx, qy, qz, t1.x, t1.y, tgt_z(t1)), tgt_idx(t1), gpos0 + (p1 - s));
+        consider(b, l2_simple(qx, qy, qz, t2.x, t2.y, tgt_z(t2)), tgt_idx(t2), gpos0 + (p2 - s));
+        consider(b, l2_simple(qx, qy, qz, t3.x, t3.y, tgt_z(t3)), tgt_idx(t3), gpos0 + (p3 - s));
     }
 }
 
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
         const int seed_pos = seed ? seed[i] : -1;
         if (seed_pos >= 0) {
             const float4 t = g.pts[seed_pos];
-            consider(b, l2_simple(q.x, q.y, q.z, t.x, t.y, t.z), __float_as_uint(t.w), (uint32_t)seed_pos);
+            consider(b, l2_simple(q.x, q.y, q.z, t.x, t.y, tgt_z(t)), tgt_idx(t), (uint32_t)seed_pos);
             limit2 = fminf(limit2, b.d2);
         }
         if (staged) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kTile) void k_icp_tile(float4 *cur, uint32_t n, Mat
         for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
         if (pos >= 0) {
             const float4 t = g.pts[pos];
-            accum_pair(a, q.x, q.y, q.z, t.x, t.y, t.z, d2, q.w);
+            accum_pair(a, q.x, q.y, q.z, t.x, t.y, tgt_z(t), d2, q.w);
         }
         tile_reduce_store(a, partials, gridDim.x);
     }

@@ -41,4 +41,11 @@ __device__ __forceinline__ const float *rec_xyz(const char *base, size_t stride,
     return reinterpret_cast<const float *>(base + i * stride);
 }
 
+// A record of the sorted target array (both index kinds): x, y, ORIGINAL INDEX, z.  The index sits in the third
+// word so that a 128-bit load leaves (index, z) in an aligned register pair: the dense search overwrites z with the
+// squared distance and compares (distance, index) as one 64-bit key without moving anything.
+__device__ __forceinline__ float4 tgt_rec(float x, float y, float z, uint32_t idx) { return make_float4(x, y, __uint_as_float(idx), z); }
+__device__ __forceinline__ float tgt_z(const float4 &t) { return t.w; }
+__device__ __forceinline__ uint32_t tgt_idx(const float4 &t) { return __float_as_uint(t.z); }
+
 }  // namespace rsreg

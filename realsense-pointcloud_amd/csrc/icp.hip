@@ -464,6 +464,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
     RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
+    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 9 * 4 + 256));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     ctx->n_source = n;
@@ -568,7 +569,7 @@ unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
 {
     static const bool on = std::getenv("RSREG_WAVE_TIMES") != nullptr;
     if (!on) return nullptr;
-    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 128 + (size_t)n * 4 + 64) != hipSuccess) return nullptr;
+    if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 256 + (size_t)n * 4 + 64) != hipSuccess) return nullptr;   // (a scheduled launch has up to 2x the waves)
     return ctx->d_brick.as<unsigned long long>();
 }
 
@@ -738,6 +739,94 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
     return fetch_sums(ctx, sums, global);
 }
 
+// ---- tile schedule of the fused dense kernel (icp_dense.hpp: TileSched) -------------------------------------
+// A launch of ~14 k waves on 8 k wave slots ends with a long tail: a few waves run 3x longer than the mean,
+// they all sit on the same (near, densely sampled) surfaces in every iteration, and nothing is left to fill
+// the slots around them.  The second launch of an alignment times every wave; from then on the tiles
+// are launched longest first, and the longest few per cent are searched by 2 or 4 lanes per query.
+// What is summed, and in which order, does not change.
+struct SchedCfg {
+    bool on = true;
+    double f4 = 0.0, f2 = 0.10;    // fractions of the tiles searched with 4 and with 2 lanes per query (swept on the bench pair)
+    uint32_t min_tiles = 1024;     // below this a launch does not even fill the wave slots once
+    int at_launch = 1;             // the launch that is timed (0 = the first, which runs without seeds)
+};
+
+SchedCfg sched_cfg()   // (read per launch: a handful of getenv calls; lets one process compare settings)
+{
+    const SchedCfg cfg = [] {
+        SchedCfg c;
+        if (const char *e = std::getenv("RSREG_SCHED")) c.on = e[0] != '0';
+        if (const char *e = std::getenv("RSREG_SCHED_F4")) c.f4 = std::atof(e);
+        if (const char *e = std::getenv("RSREG_SCHED_F2")) c.f2 = std::atof(e);
+        if (const char *e = std::getenv("RSREG_SCHED_MIN_TILES")) c.min_tiles = (uint32_t)std::atoll(e);
+        if (const char *e = std::getenv("RSREG_SCHED_AT")) c.at_launch = std::atoi(e);
+        c.f4 = std::min(std::max(c.f4, 0.0), 0.25);
+        c.f2 = std::min(std::max(c.f2, 0.0), 0.25);
+        return c;
+    }();
+    return cfg;
+}
+
+struct SchedBufs {
+    uint32_t *items, *cost, *done, *keys, *keys_alt, *vals, *vals_alt;
+};
+
+SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
+{
+    uint32_t *p = ctx->d_sched.as<uint32_t>();
+    const size_t t = n_tiles;
+    return SchedBufs{p, p + 2 * t, p + 4 * t, p + 5 * t, p + 6 * t, p + 7 * t, p + 8 * t};
+}
+
+// sort key of a tile: how long its slower wave ran in the timed launch, in steps of 0.64 us, longest first
+// (the sort is stable: tiles of one step keep their spatial order)
+__global__ __launch_bounds__(kBlock) void k_sched_keys(const uint32_t *cost, uint32_t n_tiles, uint32_t *keys, uint32_t *vals)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t c = 0;
+    for (int w = 0; w < kTileWaves; ++w) c = max(c, cost[t * kTileWaves + w]);
+    keys[t] = 1023u - min(c >> 6, 1023u);
+    vals[t] = t;
+}
+
+// rank r of the sorted tiles -> its workgroups: the first n4 tiles get four, the next n2 two, the others one
+__global__ __launch_bounds__(kBlock) void k_sched_emit(const uint32_t *vals, uint32_t n_tiles, uint32_t n4, uint32_t n2, uint32_t *items)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_tiles) return;
+    const uint32_t tile = vals[r];
+    uint32_t lg, base;
+    if (r < n4) { lg = 2; base = 4 * r; }
+    else if (r < n4 + n2) { lg = 1; base = 4 * n4 + 2 * (r - n4); }
+    else { lg = 0; base = 4 * n4 + 2 * n2 + (r - n4 - n2); }
+    for (uint32_t p = 0; p < (1u << lg); ++p) items[base + p] = tile | p << 24 | lg << 28;
+}
+
+int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
+{
+    const SchedCfg cfg = sched_cfg();
+    const SchedBufs sb = sched_bufs(ctx, n_tiles);
+    hipStream_t st = ctx->stream;
+    const uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
+    size_t bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, sb.keys, sb.keys_alt, sb.vals, sb.vals_alt, (size_t)n_tiles, 0, 10, st));
+    if (bytes > ctx->d_tmp.cap) return RSREG_OK;   // (never on the paths that get here: the index build sorted far more; no schedule then)
+    RSREG_HIP(ctx, hipMemsetAsync(sb.done, 0, (size_t)n_tiles * 4, st));
+    k_sched_keys<<<div_up(n_tiles, kBlock), kBlock, 0, st>>>(sb.cost, n_tiles, sb.keys, sb.vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, bytes, sb.keys, sb.keys_alt, sb.vals, sb.vals_alt, (size_t)n_tiles, 0, 10, st));
+    k_sched_emit<<<div_up(n_tiles, kBlock), kBlock, 0, st>>>(sb.vals_alt, n_tiles, n4, n2, sb.items);
+    RSREG_HIP(ctx, hipGetLastError());
+    ctx->icp.sched_items = n_tiles + 3 * n4 + n2;
+    if (std::getenv("RSREG_SCHED_VERBOSE"))
+        std::fprintf(stderr, "[rsreg] tile schedule: %u tiles, %u searched by 4 lanes per query, %u by 2, %u workgroups\n", n_tiles, n4, n2,
+                     ctx->icp.sched_items);
+    ctx->icp.sched_ready = true;
+    return RSREG_OK;
+}
+
 // fused pass: applies the pending increment (if any), searches, gates and reduces
 int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop = false)
 {
@@ -750,11 +839,36 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
         if (ctx->grid.dense) {
             unsigned long long *wt = wave_times_ptr(ctx, n);
-            auto kern = wt ? k_icp_fused_dense<true> : k_icp_fused_dense<false>;
-            kern<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
+            static const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
+            auto kern = wt ? (light ? k_icp_fused_dense<2> : k_icp_fused_dense<1>) : k_icp_fused_dense<0>;
+            const SchedCfg cfg = sched_cfg();
+            const uint32_t n_tiles = reduce_blocks(n);
+            const bool sched_ok = cfg.on && (!wt || light) && n_tiles >= cfg.min_tiles && n_tiles < (1u << 24);
+            TileSched sc{};
+            sc.n_tiles = n_tiles;
+            uint32_t grid = n_tiles;
+            if (sched_ok) {
+                const SchedBufs sb = sched_bufs(ctx, n_tiles);
+                sc.done = sb.done;
+                sc.pos = ctx->d_corr_pos.as<int>();
+                sc.d2 = ctx->d_corr_d2.as<float>();
+                if (s.sched_ready) {
+                    sc.items = sb.items;
+                    grid = s.sched_items;
+                } else if (s.fused_launches == cfg.at_launch) {
+                    sc.cost = sb.cost;
+                }
+            }
+            kern<<<grid, kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
-                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev);
+                ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev, sc);
+            RSREG_HIP(ctx, hipGetLastError());
+            if (sc.cost) {
+                int rc = build_schedule(ctx, n_tiles);
+                if (rc) return rc;
+            }
+            s.fused_launches++;
         }
         else if (use_tile_kernel())
             k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
@@ -941,7 +1055,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ctx->recip = nullptr;
     }
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_pos_of, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm};
@@ -1148,8 +1262,10 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
         if (ctx->grid.dense && ctx->n_work) {
-            const size_t nw = (ctx->n_work + 63) / 64;
-            std::vector<unsigned long long> h(16 * nw + (ctx->n_work + 1) / 2);   // wave records, then a uint32 of step counts per lane
+            const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
+            const size_t nw = light ? (size_t)(ctx->icp.sched_ready ? ctx->icp.sched_items : reduce_blocks(ctx->n_work)) * kTileWaves
+                                    : (ctx->n_work + 63) / 64;
+            std::vector<unsigned long long> h(16 * nw + (light ? 0 : (ctx->n_work + 1) / 2));   // wave records, then a uint32 of step counts per lane
             (void)hipMemcpy(h.data(), ctx->d_brick.ptr, h.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = std::fopen(wt_path, "wb")) {
                 std::fwrite(h.data(), 8, h.size(), f);

@@ -204,9 +204,17 @@ __device__ __forceinline__ void dscan4(DBest &b, __amdgpu_buffer_rsrc_t pts, uin
     dconsider(b, qxy, qz, t3);
 }
 
-__device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, f32x2 qxy, float qz)
+// A query of a split tile is searched by 2^lg lanes: lane `sub` of them scores the chunks sub, sub + 2^lg, ... of
+// every run of points; the lanes' bests are merged at the end (nn_query_dense).  {0, 0}: one lane does it all
+// (a compile-time constant on the ordinary path, where none of this costs anything).
+struct DSplit {
+    uint32_t lg, sub;
+};
+
+__device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, f32x2 qxy, float qz,
+                                            DSplit sp)
 {
-    for (; po < pe; po += 64) dscan4(b, pts, po, qxy, qz);
+    for (po += sp.sub * 64u; po < pe; po += 64u << sp.lg) dscan4(b, pts, po, qxy, qz);
 }
 
 // A cell's points are sorted by x (to 2^-16 of a cell).  A walk reads a cell 4 points at a time
@@ -214,22 +222,24 @@ __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts
 // exceeds the best so far: everything behind that point is farther still.
 struct DWalk {
     uint32_t cur;       // first byte of the next chunk to read, in either direction
-    uint32_t floor64;   // backward: the cell's first byte + 64 (the last chunk of a backward walk starts at the cell's
+    uint32_t floor64;   // backward: the cell's first byte + |step| (the last chunk of a backward walk starts at the cell's
                         // first point); forward: 0.  next = max(cur, floor64) + step in both directions
-    uint32_t step;      // +64 / -64 (mod 2^32)
+    uint32_t step;      // +64 / -64 (mod 2^32), times the lanes a split query is spread over
     int left;           // chunks still to read (0: nothing)
     bool back;
     float yz2;          // what every point of this cell is away from the query in y and z at least, squared
 };
 
-__device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back, float yz2)
+__device__ __forceinline__ void dwalk_open(DWalk &w, const u32x2 &se, bool back, float yz2, DSplit sp)
 {
+    const uint32_t chunks = (se.y - se.x + 3u) >> 2, stride = 64u << sp.lg, first = 64u * (sp.sub + 1u);
     w.yz2 = yz2;
-    w.left = (int)((se.y - se.x + 3u) >> 2);
+    w.left = chunks > sp.sub ? (int)((chunks - sp.sub + (1u << sp.lg) - 1u) >> sp.lg) : 0;   // chunks sub, sub + 2^lg, ...
     w.back = back;
-    w.floor64 = back ? se.x * 16u + 64u : 0u;
-    w.step = back ? 0u - 64u : 64u;
-    w.cur = back ? max(se.y * 16u, w.floor64) - 64u : se.x * 16u;
+    w.floor64 = back ? se.x * 16u + stride : 0u;
+    w.step = back ? 0u - stride : stride;
+    // backward, chunk k starts at max(end - 64 (k + 1), first byte of the cell)
+    w.cur = back ? max(se.y * 16u, se.x * 16u + first) - first : se.x * 16u + first - 64u;
 }
 
 // running limit = min(limit, best): one v_min (both are squared distances or +inf, never NaN, so the
@@ -311,7 +321,7 @@ __device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int 
 // rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
 template <bool kDiag = false>
 __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b,
-                                               float &limit2, DDiag *dg = nullptr)
+                                               float &limit2, DSplit sp, DDiag *dg = nullptr)
 {
     const f32x2 qxy = {q.qx, q.qy};
     const float qz = q.qz;
@@ -326,7 +336,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     const float x_slack = g.x_slack;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
     DWalk w;
-    dwalk_open(w, se, right_half, 0.0f);
+    dwalk_open(w, se, right_half, 0.0f, sp);
     while (w.left > 0) {
         if (kDiag) ++dg->own;
         dwalk_step(w, b, rs.pts, qxy, qz, x_slack, limit2);
@@ -361,7 +371,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     for (;;) {
         if (w.left <= 0) {
             if (!nvalid && !mask) break;
-            if (nvalid && nlb2 <= limit2) dwalk_open(w, nse, nback, nyz2);   // (the limit may have tightened since that range was asked for)
+            if (nvalid && nlb2 <= limit2) dwalk_open(w, nse, nback, nyz2, sp);   // (the limit may have tightened since that range was asked for)
             nvalid = false;
             if (mask) {
                 if (kDiag) ++dg->r1_cells;
@@ -402,7 +412,7 @@ __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
 // (rho <= 1) have had their cells cx-1..cx+1 searched already: only their two outer parts remain.
 template <bool kDiag = false>
 __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs, const DQuery &q, int dy, int dz, bool central,
-                                              float inv_cell2, f32x2 qxy, DBest &b, float &limit2, DDiag *dg)
+                                              float inv_cell2, f32x2 qxy, DBest &b, float &limit2, DSplit sp, DDiag *dg)
 {
     const int y = q.cy + dy, z = q.cz + dz;
     if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
@@ -423,7 +433,7 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
         const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
         const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
         if (kDiag) dg->far_scans += (e - s + 3) / 4;
-        dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, q.qz);
+        dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, q.qz, sp);
     } else {
         // [xa, cx-2] and [cx+2, xb]; an empty part reads the same table entry twice
         const int l1 = min(q.cx - 1, xb + 1), r0 = max(q.cx + 2, xa);
@@ -432,9 +442,9 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
         const uint32_t s1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + min(r0, xb + 1)) * 4u, 0, 0);
         const uint32_t e1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
         if (kDiag) dg->far_scans += (e0 - s0 + 3) / 4 + (e1 - s1 + 3) / 4;
-        dwalk_open(w, u32x2{s0, e0}, true, yz2);    // the part to the left, from its right end
+        dwalk_open(w, u32x2{s0, e0}, true, yz2, sp);    // the part to the left, from its right end
         while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
-        dwalk_open(w, u32x2{s1, e1}, false, yz2);   // the part to the right, from its left end
+        dwalk_open(w, u32x2{s1, e1}, false, yz2, sp);   // the part to the right, from its left end
         while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
     }
     limit2 = fminf(limit2, b.d);
@@ -442,7 +452,7 @@ __device__ __forceinline__ void dense_far_row(const DenseDev &g, const DRes &rs,
 
 template <bool kDiag = false>
 __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
-                                          DDiag *dg = nullptr)
+                                          DSplit sp, DDiag *dg = nullptr)
 {
     const f32x2 qxy = {q.qx, q.qy};
     const float inv_cell2 = 1.0f / (g.cell * g.cell);
@@ -454,10 +464,10 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
         const bool central = rho <= 1;
         for (int dz = -rho; dz <= rho; ++dz) {
             if (dz == -rho || dz == rho) {
-                for (int dy = -rho; dy <= rho; ++dy) dense_far_row<kDiag>(g, rs, q, dy, dz, central, inv_cell2, qxy, b, limit2, dg);
+                for (int dy = -rho; dy <= rho; ++dy) dense_far_row<kDiag>(g, rs, q, dy, dz, central, inv_cell2, qxy, b, limit2, sp, dg);
             } else {
-                dense_far_row<kDiag>(g, rs, q, -rho, dz, central, inv_cell2, qxy, b, limit2, dg);
-                dense_far_row<kDiag>(g, rs, q, rho, dz, central, inv_cell2, qxy, b, limit2, dg);
+                dense_far_row<kDiag>(g, rs, q, -rho, dz, central, inv_cell2, qxy, b, limit2, sp, dg);
+                dense_far_row<kDiag>(g, rs, q, rho, dz, central, inv_cell2, qxy, b, limit2, sp, dg);
             }
         }
     }
@@ -476,18 +486,26 @@ __device__ __forceinline__ Best dense_result(const DenseDev &g, const DBest &b)
 
 // Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
 template <bool kDiag = false>
-__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos, DDiag *dg = nullptr)
+__device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos, DDiag *dg = nullptr,
+                                               DSplit sp = DSplit{0u, 0u})
 {
     if (g.nx <= 0) return Best{~0ull, -1, FLT_MAX};
     const DRes rs = dense_res(g);
     const DQuery q = dense_query(g, qx, qy, qz);
     float limit2 = g.prune2;
     DBest b{__uint_as_float(0x7f800000u), 0xffffffffu};
-    dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, dg);
+    dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, sp, dg);
     if (kDiag) dg->t_near = wall_clock64();
     const bool far = dense_needs_far(g, limit2);
-    if (far) dense_far<kDiag>(g, rs, q, b, limit2, dg);
+    if (far) dense_far<kDiag>(g, rs, q, b, limit2, sp, dg);
     if (kDiag) dg->t_far = wall_clock64();
+    // the lanes of a split query hold the bests of disjoint parts of the candidate set: the smallest
+    // (distance, index) key among them is the query's (every lane of the group ends up with it)
+    for (uint32_t m = 1; m < (1u << sp.lg); m <<= 1) {
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(b.d) << 32) | b.idx;
+        const unsigned long long other = (unsigned long long)__shfl_xor((long long)mine, (int)m);
+        if (other < mine) { b.d = __uint_as_float((uint32_t)(other >> 32)); b.idx = (uint32_t)other; }
+    }
     return dense_result(g, b);
 }
 
@@ -511,26 +529,131 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
     corr_d2[i] = d2;
 }
 
+// How the workgroups of a fused launch map to tiles (icp.hip: build_schedule).  All null: workgroup b is tile b.
+// With a schedule, the tiles that took longest in an earlier iteration come first, and the longest of
+// them are split: 2 or 4 workgroups share the tile's 128 queries, 2 or 4 lanes search each query (DSplit),
+// and whichever of those workgroups finishes last adds up the tile's 17 sums in the usual order.
+struct TileSched {
+    const uint32_t *items;   // per workgroup: tile | part << 24 | log2(lanes per query) << 28
+    uint32_t *cost;          // per wave of an unsplit tile: how long it ran in this launch (100 MHz ticks), or null
+    uint32_t *done;          // per tile: parts finished so far (split tiles; goes back to 0 by itself)
+    int *pos;                // per query: where the parts of a split tile leave their matches
+    float *d2;
+    uint32_t n_tiles;        // slabs of `partials`
+};
+
+// device-wide visible accesses for what the parts of a split tile hand to each other inside one launch
+// (they may run on different XCDs, whose L2s are not coherent for ordinary accesses)
+__device__ __forceinline__ void coherent_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t *p)
+{
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(float4 *p, const float4 &v)
+{
+    auto *u = reinterpret_cast<unsigned long long *>(p);
+    __hip_atomic_store(u, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 coherent_load(const float4 *p)
+{
+    auto *u = reinterpret_cast<unsigned long long *>(const_cast<float4 *>(p));
+    const unsigned long long a = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b),
+                       __uint_as_float((uint32_t)(b >> 32)));
+}
+
+// One part of a split tile: 128 >> lg queries, 2^lg lanes each.  Returns true in the workgroup that finishes
+// the tile last (it then adds the tile's sums up from what all parts have left in sched.pos / sched.d2 / cur).
+__device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, const Mat34 &T, int apply_t, const DenseDev &g, double gate2,
+                                                       int *seed, const TileSched &sched, uint32_t tile, uint32_t part, uint32_t lg)
+{
+    const DSplit sp{lg, threadIdx.x & ((1u << lg) - 1u)};
+    const uint32_t i = tile * kTile + part * (kTile >> lg) + (threadIdx.x >> lg);
+    if (i < n) {
+        float4 q = cur[i];
+        int pos = -1;
+        float d2 = 0.0f;
+        if (q.w != 0.0f) {
+            if (apply_t) {
+                const float3 t = xform(T, q.x, q.y, q.z);
+                q = make_float4(t.x, t.y, t.z, q.w);
+            }
+            const int seed_in = seed ? seed[i] : -1;
+            const Best b = nn_query_dense<false>(g, q.x, q.y, q.z, seed_in, nullptr, sp);
+            if (sp.sub == 0) {
+                if (apply_t) coherent_store(&cur[i], q);
+                if (seed && b.pos != seed_in) seed[i] = b.pos;
+            }
+            if (b.pos >= 0 && !((double)b.d2 > gate2)) {
+                pos = b.pos;
+                d2 = b.d2;
+            }
+        }
+        if (sp.sub == 0) {
+            coherent_store(reinterpret_cast<uint32_t *>(sched.pos) + i, (uint32_t)pos);
+            coherent_store(reinterpret_cast<uint32_t *>(sched.d2) + i, __float_as_uint(d2));
+        }
+    }
+    __shared__ uint32_t s_last;
+    __syncthreads();   // (waits for this workgroup's stores, too)
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(&sched.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before + 1u == (1u << lg);
+        if (s_last) __hip_atomic_store(&sched.done[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// RSREG_WAVE_TIMES_LIGHT: start, end and hardware slot of this wave (one record per launched wave)
+__device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsigned long long t_start, uint32_t lg)
+{
+    unsigned long long *w = wave_times + 16ull * (blockIdx.x * kTileWaves + (threadIdx.x >> 6));
+    w[0] = t_start;
+    w[4] = wall_clock64();
+    w[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13 */ | 1ull << 63;
+    w[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID: 3:0 */ | (unsigned long long)lg << 8;
+}
+
 // One ICP iteration in one pass over the dense index: apply the previous increment, search,
 // gate, accumulate (same contract and summation order as k_icp_fused).  kDiag: the diagnostic
-// instantiation (RSREG_WAVE_TIMES) also writes 8 clock stamps per wave.
-template <bool kDiag>
-__global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
+// instantiation (RSREG_WAVE_TIMES) also writes clock stamps and step counts per wave (1), or only the start and
+// end stamp and the hardware slot of each wave, at the product kernel's own occupancy (2: RSREG_WAVE_TIMES_LIGHT=1).
+template <int kDiag>
+__global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
-                                                           int *seed, unsigned long long *wave_times, const IcpDevState *dev)
+                                                           int *seed, unsigned long long *wave_times, const IcpDevState *dev,
+                                                           TileSched sched)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t item = sched.items ? sched.items[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = item & 0xffffffu, lg = (item >> 28) & 3u;
+    const uint32_t i = tile * kTile + threadIdx.x;
     if (dev) {   // device-resident loop: the increment comes from the previous k_icp_solve
         T = dev->t_inc;
         apply_t = dev->apply;
     }
     unsigned long long t_start = 0, t_search = 0;
     DDiag dg;
-    if (kDiag) t_start = wall_clock64();
+    if (kDiag || sched.cost) t_start = wall_clock64();
+    constexpr bool kFull = kDiag == 1;
     int pos = -1;
     float d2 = 0.0f;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) {
+    if (lg != 0) {
+        if (!fused_dense_split_part(cur, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
+            if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg);
+            return;
+        }
+        if (i < n) {   // the tile is complete: this workgroup adds it up, one query per thread as on the ordinary path
+            q = coherent_load(&cur[i]);
+            if (q.w != 0.0f) {
+                pos = (int)coherent_load(reinterpret_cast<const uint32_t *>(sched.pos) + i);
+                d2 = __uint_as_float(coherent_load(reinterpret_cast<const uint32_t *>(sched.d2) + i));
+            }
+        }
+    } else if (i < n) {
         q = cur[i];
         if (q.w != 0.0f) {
             if (apply_t) {
@@ -539,7 +662,7 @@ __global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4
                 cur[i] = q;
             }
             const int seed_in = seed ? seed[i] : -1;
-            const Best b = nn_query_dense<kDiag>(g, q.x, q.y, q.z, seed_in, &dg);
+            const Best b = nn_query_dense<kFull>(g, q.x, q.y, q.z, seed_in, &dg);
             if (seed && b.pos != seed_in) seed[i] = b.pos;   // (most matches do not change once the clouds have settled)
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
@@ -548,15 +671,18 @@ __global__ __launch_bounds__(kTile, kDiag ? 4 : 8) void k_icp_fused_dense(float4
         }
         if (corr_pos) { corr_pos[i] = pos; corr_d2[i] = d2; }
     }
-    if (kDiag) t_search = wall_clock64();
+    if (kFull) t_search = wall_clock64();
+    if (sched.cost && lg == 0 && (threadIdx.x & 63) == 0)
+        sched.cost[tile * kTileWaves + (threadIdx.x >> 6)] = (uint32_t)min(wall_clock64() - t_start, 0xffffffffull);
     double a[RSREG_NUM_SUMS];
     for (int k = 0; k < RSREG_NUM_SUMS; ++k) a[k] = 0.0;
     if (pos >= 0) {
         const float4 t = g.pts[pos];
         accum_pair(a, q.x, q.y, q.z, t.x, t.y, tgt_z(t), d2, q.w);
     }
-    tile_reduce_store(a, partials, gridDim.x);
-    if (kDiag) {
+    tile_reduce_store(a, partials, sched.n_tiles, tile);
+    if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg);
+    if (kFull) {
         // per wave: start, end of rings 0-1 (latest lane), end of far rings, end of search, end,
         // then max-over-lanes | sum-over-lanes (<< 32) of the step counts
         unsigned long long near_end = dg.t_near, far_end = dg.t_far;

@@ -728,7 +728,9 @@ constexpr int kTileWaves = kTile / 64;
 // Block-level reduction of per-thread sums into partials[k][blockIdx] (transposed slabs: the
 // final reduction reads each sum contiguously).  Fixed order, so the result depends only on
 // the number of source points, never on the GPU or on timing.
-__device__ __forceinline__ void tile_reduce_store(double *a, double *partials, uint32_t nblocks)
+__device__ __forceinline__ void tile_reduce_store(double *a, double *partials, uint32_t nblocks, uint32_t slot);
+__device__ __forceinline__ void tile_reduce_store(double *a, double *partials, uint32_t nblocks) { tile_reduce_store(a, partials, nblocks, blockIdx.x); }
+__device__ __forceinline__ void tile_reduce_store(double *a, double *partials, uint32_t nblocks, uint32_t slot)
 {
     __shared__ double shr[kTileWaves][RSREG_NUM_SUMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -753,7 +755,7 @@ __device__ __forceinline__ void tile_reduce_store(double *a, double *partials, u
     if (threadIdx.x < RSREG_NUM_SUMS) {
         double v = shr[0][threadIdx.x];
         for (int w = 1; w < kTileWaves; ++w) v += shr[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * nblocks + blockIdx.x] = v;
+        partials[(size_t)threadIdx.x * nblocks + slot] = v;
     }
 }
 

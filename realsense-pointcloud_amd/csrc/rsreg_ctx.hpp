@@ -96,6 +96,9 @@ struct IcpState {
     bool pending_transform = false;  // fused mode: t_inc not yet applied to d_cur
     double ms_nn = 0, ms_reduce = 0, ms_transform = 0;
     int n_nn_launches = 0;
+    int fused_launches = 0;        // fused dense launches of this alignment so far
+    bool sched_ready = false;      // d_sched holds a tile schedule for this alignment
+    uint32_t sched_items = 0;      // workgroups of a scheduled launch
 };
 
 }  // namespace rsreg
@@ -119,6 +122,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell
     rsreg::DevBuf d_nbr;          // dense mode: uint32 per cell, occupancy of its 27-cell neighbourhood
     rsreg::DevBuf d_pos_of;       // dense mode: uint32 per target record, its position in d_tgt_sorted
+    rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items | wave costs | done counters | sort scratch
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     size_t n_target_raw = 0;

@@ -1,0 +1,93 @@
+"""The tile schedule of the fused search kernel (csrc/icp.hip: build_schedule): tiles launched longest first,
+the longest ones searched by 2 or 4 lanes per query.  It may change WHEN a query is searched and by how many
+lanes, never what is found or how the 17 sums are added up: every result must be bit-identical to the
+unscheduled launch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(rs):
+    from rsreg_amd import api as a, lib
+    lib.build()
+    if a.device_count() < 1:
+        pytest.fail("no HIP device: the product has no CPU fallback")
+    return a
+
+
+@pytest.fixture(scope="module")
+def frames(rs):
+    return {("50k", "parity"): (rs.synth.render_frame(1, "50k", "parity"), rs.synth.render_frame(0, "50k", "parity"))}
+
+
+def _run(api, src, tgt, pipeline, iters, gate, guess=None):
+    icp = api.IterativeClosestPoint(api.Context(0))
+    icp.params = api.icp_params(max_iterations=iters, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=gate)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    out = icp.align(guess) if guess is not None else icp.align()
+    r = icp.result
+    kind = icp.grid_info().index_kind
+    return (bytes(r.transform), bytes(r.sums_last), r.n_correspondences, r.iterations, r.state, r.converged, r.mse,
+            np.stack([out.points[k] for k in "xyz"]).tobytes()), kind
+
+
+@pytest.mark.parametrize("f4,f2,at", [(0.0, 0.10, 1), (0.25, 0.25, 1), (0.25, 0.0, 0), (0.0, 0.25, 2), (0.02, 0.08, 1)])
+def test_scheduled_launches_change_nothing(api, frames, monkeypatch, capfd, f4, f2, at):
+    src, tgt = frames[("50k", "parity")]
+    monkeypatch.setenv("RSREG_SCHED", "0")
+    base, kind = _run(api, src, tgt, 2, 8, 0.02)
+    if kind != 1:
+        pytest.skip("the schedule belongs to the dense-table search")
+    monkeypatch.setenv("RSREG_SCHED", "1")
+    monkeypatch.setenv("RSREG_SCHED_MIN_TILES", "1")
+    monkeypatch.setenv("RSREG_SCHED_F4", str(f4))
+    monkeypatch.setenv("RSREG_SCHED_F2", str(f2))
+    monkeypatch.setenv("RSREG_SCHED_AT", str(at))
+    monkeypatch.setenv("RSREG_SCHED_VERBOSE", "1")
+    capfd.readouterr()
+    for pipeline in (1, 2):
+        got, _ = _run(api, src, tgt, pipeline, 8, 0.02)
+        assert "tile schedule:" in capfd.readouterr().err, "the schedule was not built"
+        assert got == base, (pipeline, f4, f2)
+
+
+def test_schedule_on_ragged_and_invalid_input(api, rs, monkeypatch, capfd):
+    """A source whose size is not a multiple of the tile, with invalid and duplicate records; every tile split."""
+    rng = np.random.default_rng(5)
+    tgt = rs.synth.render_frame(0, "50k", "parity")
+    src = rs.synth.render_frame(1, "50k", "parity")
+    pts = src.points.copy()
+    n = (len(pts) // 128) * 128 - 37
+    pts = pts[:n]
+    bad = rng.integers(0, n, n // 40)
+    pts["x"][bad] = np.nan
+    pts[rng.integers(0, n, n // 30)] = pts[0]
+    src = rs.PointCloud(pts, width=n, height=1, is_dense=False)
+    monkeypatch.setenv("RSREG_SCHED", "0")
+    base, kind = _run(api, src, tgt, 2, 6, 0.03)
+    if kind != 1:
+        pytest.skip("the schedule belongs to the dense-table search")
+    monkeypatch.setenv("RSREG_SCHED", "1")
+    monkeypatch.setenv("RSREG_SCHED_MIN_TILES", "1")
+    monkeypatch.setenv("RSREG_SCHED_F4", "0.25")
+    monkeypatch.setenv("RSREG_SCHED_F2", "0.25")
+    monkeypatch.setenv("RSREG_SCHED_VERBOSE", "1")
+    capfd.readouterr()
+    got, _ = _run(api, src, tgt, 2, 6, 0.03)
+    assert "tile schedule:" in capfd.readouterr().err
+    assert got == base
+
+
+def test_schedule_at_bench_size(api, rs, monkeypatch):
+    """The default settings on a 300 k pair (the schedule switches itself on from 1024 tiles)."""
+    tgt, src = rs.synth.render_frame(0, "N300", "bench"), rs.synth.render_frame(1, "N300", "bench")
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    monkeypatch.setenv("RSREG_SCHED", "0")
+    base, _ = _run(api, src, tgt, 2, 12, 0.05, guess)
+    monkeypatch.delenv("RSREG_SCHED")
+    for _ in range(3):   # (the parts of a split tile meet through device-scope atomics: repeat)
+        got, _ = _run(api, src, tgt, 2, 12, 0.05, guess)
+        assert got == base

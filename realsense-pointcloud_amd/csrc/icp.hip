@@ -25,6 +25,10 @@ using namespace rsreg;
 
 namespace {
 
+// rocPRIM sorts up to 2^20 items by merge sort whatever the bit range asked for; the keys here have ~40
+// significant bits, and from ~10^5 items on the onesweep radix sort is the faster one (same result: both are stable)
+using RadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
 inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n + kTile - 1) / kTile, 1); }  // depends on n only
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -234,11 +238,11 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     while ((1ull << id_bits) <= total) ++id_bits;   // all-ones (non-finite) stays above every valid id
     const unsigned end_bit = (unsigned)std::min(64, 16 + id_bits);
     size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     const uint32_t nbf = div_up(nfin, kBlock);
     k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart);
     RSREG_HIP(ctx, hipGetLastError());
@@ -502,10 +506,10 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), keys, vals);
         RSREG_HIP(ctx, hipGetLastError());
         size_t sort_bytes = 0, scan_bytes = 0;
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr);
         RSREG_HIP(ctx, hipGetLastError());
         k_source_flag<<<nb, kBlock, 0, st>>>(keys2, ctx->d_src_all.as<float4>(), (uint32_t)n, keep);

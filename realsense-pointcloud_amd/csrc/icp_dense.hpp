@@ -608,13 +608,14 @@ __device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, 
 }
 
 // RSREG_WAVE_TIMES_LIGHT: start, end and hardware slot of this wave (one record per launched wave)
-__device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsigned long long t_start, uint32_t lg)
+__device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsigned long long t_start, uint32_t lg, uint32_t item)
 {
     unsigned long long *w = wave_times + 16ull * (blockIdx.x * kTileWaves + (threadIdx.x >> 6));
     w[0] = t_start;
     w[4] = wall_clock64();
     w[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13 */ | 1ull << 63;
     w[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID: 3:0 */ | (unsigned long long)lg << 8;
+    w[12] = item;
 }
 
 // One ICP iteration in one pass over the dense index: apply the previous increment, search,
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lg != 0) {
         if (!fused_dense_split_part(cur, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
-            if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg);
+            if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg, item);
             return;
         }
         if (i < n) {   // the tile is complete: this workgroup adds it up, one query per thread as on the ordinary path
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
         accum_pair(a, q.x, q.y, q.z, t.x, t.y, tgt_z(t), d2, q.w);
     }
     tile_reduce_store(a, partials, sched.n_tiles, tile);
-    if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg);
+    if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg, item);
     if (kFull) {
         // per wave: start, end of rings 0-1 (latest lane), end of far rings, end of search, end,
         // then max-over-lanes | sum-over-lanes (<< 32) of the step counts

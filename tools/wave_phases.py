@@ -51,6 +51,9 @@ print("lanes %d: steps per lane mean near %.2f far %.2f; lanes needing far rows 
 print("per-lane cost percentiles p50/p90/p99/p99.9/max: %s" % [int(np.percentile(cost, p)) for p in (50, 90, 99, 99.9, 100)])
 base = wave_steps(near).sum() + wave_steps(far).sum()
 print("wave-steps as launched: near %d + far %d (sum of lanes / 64 would be %d)" % (wave_steps(near).sum(), wave_steps(far).sum(), cost.sum() // 64))
+print("one flat loop over all phases (a wave pays the maximum of its lanes' totals): own %d + ring-1 scans %d + far %d as three loops -> %d as one (%.2f x)"
+      % (wave_steps(own).sum(), wave_steps(r1).sum(), wave_steps(far).sum(), wave_steps(cost).sum(),
+         (wave_steps(own).sum() + wave_steps(r1).sum() + wave_steps(far).sum()) / max(wave_steps(cost).sum(), 1)))
 for win in (128, 512, 1024, 4096, 1 << 30):
     key = (np.arange(nq) // win) * 100000 - np.minimum(cost, 99999)
     o = np.argsort(key, kind="stable")

@@ -1,8 +1,9 @@
 set -o pipefail
-for v in rows blocks; do for sc in 0 1; do
-  echo "far $v sched $sc"
-  if [ $v = rows ]; then export RSREG_FAR_ROWS=1; else unset RSREG_FAR_ROWS; fi
-  RSREG_SCHED=$sc timeout -k 10 120 python tools/iter_times.py N1M 30 2 2>&1 | tail -1 || exit 1
-done; done
-unset RSREG_FAR_ROWS
-timeout -k 10 300 python tools/wave_timeline.py N1M 30 2>&1 | head -5
+mkdir -p gpurun_out/r2t
+for c in 0 1 2 4 0; do
+echo "sort cfg $c"
+RSREG_SORT_CFG=$c timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r2t/b.json 2> gpurun_out/r2t/b.err || { tail -20 gpurun_out/r2t/b.err; exit 1; }
+python -c "
+import json
+d=json.load(open('gpurun_out/r2t/b.json')); print(d['ms_per_step'], d['breakdown_ms_per_step'])"
+done

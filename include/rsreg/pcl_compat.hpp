@@ -456,6 +456,12 @@ inline std::shared_ptr<PointCloud<PointXYZRGB>> extract_edge_features(const std:
     return out;
 }
 
+// the same on a frame that already lies in HBM (out: width = number of edge points, height = 1)
+inline void extract_edge_features(const DeviceCloud<PointXYZRGB> &cloud, DeviceCloud<PointXYZRGB> &out)
+{
+    check(rsreg_cloud_edge_features(cloud.context()->get(), cloud.handle(), out.handle()), cloud.context()->get());
+}
+
 // ---- pcl::io: PCD files with FIELDS x y z rgb (ascii, binary, binary_compressed), as the reference reads/writes
 // (src/main.cpp:53,81,87)
 namespace io {

@@ -144,8 +144,16 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
 
     rgb_point_cloud_pointer global_registration(PairList &clouds) override
     {
-        if (device_resident) return global_registration_device(clouds);
+        if (device_resident) return global_registration_device(&clouds, nullptr);
         return global_registration_host(clouds);
+    }
+    // both phases (types.hpp:30-43).  With the frame loop resident in HBM and the built-in feature extractor a frame is
+    // uploaded ONCE: its edge points are extracted where it lies and both stay there (the feature clouds never exist
+    // on the host); a plugged-in feature_fn is a host function and goes the reference's way through host pairs.
+    rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
+    {
+        if (!device_resident || feature_fn) return TwoPhaseRegistrationScheme::registration(clouds);
+        return global_registration_device(nullptr, &clouds);
     }
     std::vector<std::pair<Matrix4f, Matrix4f>> frame_transforms;  // (coarse, refine) per merged frame
 
@@ -161,20 +169,28 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         return Matrix4f::RotationY(acc_rads);
     }
 
-    rgb_point_cloud_pointer global_registration_device(PairList &clouds)
+    // `pairs` (features and frames on the host) or `frames` (frames only: features extracted on the GPU), one of the two
+    rgb_point_cloud_pointer global_registration_device(PairList *pairs, std::vector<rgb_point_cloud_pointer> *frames)
     {
-        if (use_imu) assert(clouds.size() == thetas.size());
+        const size_t n_frames = pairs ? pairs->size() : frames->size();
+        if (use_imu) assert(n_frames == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
         ApproximateVoxelGrid<rgb_point> voxel;
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
-        rgb_device_cloud target(*clouds[0].first), merged(*clouds[0].second), features, reduced, coarse_out, refined, full, moved;
+        rgb_device_cloud target, merged(pairs ? *(*pairs)[0].second : *(*frames)[0]), features, reduced, coarse_out, refined, full, moved;
+        if (pairs) target.upload(*(*pairs)[0].first);
+        else extract_edge_features(merged, target);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
         float acc_rads = 0.f;
         frame_transforms.clear();
-        for (size_t k = 1; k < clouds.size(); ++k) {
-            features.upload(*clouds[k].first);
+        for (size_t k = 1; k < n_frames; ++k) {
+            if (pairs) features.upload(*(*pairs)[k].first);
+            else {
+                full.upload(*(*frames)[k]);
+                extract_edge_features(full, features);
+            }
             voxel.filter(features, reduced);
             const Matrix4f guess = next_guess(k, acc_rads);
             const Matrix4f t_coarse = coarse_align_device(reduced, target, coarse_out, guess);
@@ -182,14 +198,14 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             icp.setInputTarget(target);
             icp.align(refined);
             if (!icp.hasConverged()) continue;   // frame dropped silently, like the reference
-            full.upload(*clouds[k].second);
+            if (pairs) full.upload(*(*pairs)[k].second);
             transformPointCloud(full, moved, t_coarse);
             transformPointCloud(moved, moved, icp.getFinalTransformation());
             rgb_device_cloud::concatenate(refined, target, target);   // new points first
             merged += moved;
             frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
         }
-        target.download(*clouds[0].first);   // the caller's frame-0 feature cloud has become the grown target
+        if (pairs) target.download(*(*pairs)[0].first);   // the caller's frame-0 feature cloud has become the grown target
         auto out = std::make_shared<rgb_point_cloud>();
         merged.download(*out);
         out->width = (uint32_t)out->size();   // `*merged = *merged + ...`: an unorganized cloud whatever came in

@@ -92,6 +92,8 @@ class HipDeviceBackend(HipBackend):
     caller gets back is downloaded.  Same records, same order as HipBackend."""
 
     def upload(self, cloud):
+        if isinstance(cloud, self.api.DeviceCloud):   # (already there: the two-phase driver uploads a frame once)
+            return cloud
         return self.api.DeviceCloud(cloud, self.ctx or self.api.default_context())
 
     def download(self, cloud):
@@ -122,7 +124,10 @@ class TwoPhaseRegistrationScheme(RegistrationScheme):
         raise NotImplementedError
 
     def registration(self, clouds):
-        pairs = [(self.extract_features(c), c) for c in clouds]
+        # a frame goes to the GPU once: its features are extracted there and both stay there for the frame loop
+        # (a plugged-in feature_fn is a host function: it gets, and returns, host clouds)
+        frames = clouds if self.feature_fn else [self.backend.upload(c) for c in clouds]
+        pairs = [(self.extract_features(f), f) for f in frames]
         return self.global_registration(pairs)
 
 
@@ -199,7 +204,8 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             target = b.concat(refined, target)     # new points first
             merged = b.concat(merged, moved)
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
-        _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
+        if isinstance(pairs[0][0], PointCloud):
+            _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
         out = b.download(merged)
         return PointCloud(out.points, width=len(out), height=1, is_dense=out.is_dense)
 

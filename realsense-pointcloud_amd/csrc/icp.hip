@@ -332,6 +332,10 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         int parts = std::max(1, (int)std::ceil(padded / (cap * refine)));
         parts = std::min(parts, 8);   // the far phase walks (2*parts/4+3)^3 bricks for an unmatched query
         cell = padded / parts;
+        // a gate below the cap (the reference's 1 cm on sparse edge clouds): cells as large as the cap still need one
+        // ring only, and the table (cleared and scanned on every build) shrinks with the cube of the cell
+        static const bool wide = !(std::getenv("RSREG_NO_WIDE_CELLS") && std::getenv("RSREG_NO_WIDE_CELLS")[0] == '1');
+        if (wide && parts == 1 && cap * refine > padded) cell = cap * refine;
     } else {
         cell = cap * refine;
     }

@@ -472,7 +472,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
     RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
-    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 9 * 4 + 256));
+    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     ctx->n_source = n;
@@ -769,8 +769,8 @@ SchedCfg sched_cfg()   // (read per launch: a handful of getenv calls; lets one 
         if (const char *e = std::getenv("RSREG_SCHED_F2")) c.f2 = std::atof(e);
         if (const char *e = std::getenv("RSREG_SCHED_MIN_TILES")) c.min_tiles = (uint32_t)std::atoll(e);
         if (const char *e = std::getenv("RSREG_SCHED_AT")) c.at_launch = std::atoi(e);
-        c.f4 = std::min(std::max(c.f4, 0.0), 0.25);
-        c.f2 = std::min(std::max(c.f2, 0.0), 0.25);
+        c.f4 = std::min(std::max(c.f4, 0.0), 1.0);
+        c.f2 = std::min(std::max(c.f2, 0.0), 1.0 - c.f4);   // (every tile at most once: up to 4 workgroups per tile)
         return c;
     }();
     return cfg;
@@ -784,7 +784,7 @@ SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
 {
     uint32_t *p = ctx->d_sched.as<uint32_t>();
     const size_t t = n_tiles;
-    return SchedBufs{p, p + 2 * t, p + 4 * t, p + 5 * t, p + 6 * t, p + 7 * t, p + 8 * t};
+    return SchedBufs{p, p + 4 * t, p + 6 * t, p + 7 * t, p + 8 * t, p + 9 * t, p + 10 * t};
 }
 
 // sort key of a tile: how long its slower wave ran in the timed launch, in steps of 0.64 us, longest first
@@ -1268,6 +1268,22 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (const char *sd_path = std::getenv("RSREG_DUMP_SEED")) {   // dev: the position every query matched last, and the queries
+        const size_t nq = ctx->n_work;
+        std::vector<int> h(nq);
+        std::vector<float> hq(nq * 4);
+        (void)hipMemcpy(h.data(), ctx->d_seed.ptr, nq * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hq.data(), ctx->d_cur.ptr, nq * 16, hipMemcpyDeviceToHost);
+        if (FILE *f = std::fopen(sd_path, "wb")) {
+            std::fwrite(h.data(), 4, nq, f);
+            std::fwrite(hq.data(), 4, nq * 4, f);
+            const size_t np_ = ctx->grid.n_points;
+            std::vector<float> hp(np_ * 4);
+            (void)hipMemcpy(hp.data(), ctx->d_tgt_sorted.ptr, np_ * 16, hipMemcpyDeviceToHost);
+            std::fwrite(hp.data(), 4, np_ * 4, f);
+            std::fclose(f);
+        }
+    }
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
         if (ctx->grid.dense && ctx->n_work) {
             const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;

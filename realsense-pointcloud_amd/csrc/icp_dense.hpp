@@ -214,7 +214,16 @@ struct DSplit {
 __device__ __forceinline__ void dscan_range(DBest &b, __amdgpu_buffer_rsrc_t pts, uint32_t po, uint32_t pe, f32x2 qxy, float qz,
                                             DSplit sp)
 {
-    for (po += sp.sub * 64u; po < pe; po += 64u << sp.lg) dscan4(b, pts, po, qxy, qz);
+    if (sp.lg != 0) {
+        // The lanes of a split query each derive the range [po, pe) of a row from their OWN best so far, so the ranges
+        // differ: chunks are therefore owned by ABSOLUTE position (64-byte chunk c belongs to lane c mod 2^lg), not by
+        // their place in the range.  A chunk that lies outside its owner's range is never read -- rightly: the owner's
+        // best proves that nothing in it can be nearer.  (Reading from the 64-byte boundary below po only meets more
+        // real points of the row before.)
+        const uint32_t first = po >> 6;
+        po = (first + ((sp.sub - first) & ((1u << sp.lg) - 1u))) << 6;
+    }
+    for (; po < pe; po += 64u << sp.lg) dscan4(b, pts, po, qxy, qz);
 }
 
 // A cell's points are sorted by x (to 2^-16 of a cell).  A walk reads a cell 4 points at a time
@@ -597,7 +606,12 @@ __device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, 
         }
     }
     __shared__ uint32_t s_last;
-    __syncthreads();   // (waits for this workgroup's stores, too)
+    // Every wave's stores must have arrived device-wide BEFORE thread 0 counts this part as done.  The workgroup
+    // barrier alone does not wait for them (one CU, one L1: workgroup scope needs no wait), and most of the stores
+    // come from other waves than the one that bumps the counter.  The stores are write-through (sc1), so "arrived"
+    // is all that is needed: no cache write-back (an agent-scope release fence would add one: 99 -> 160 us per launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t before = __hip_atomic_fetch_add(&sched.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = before + 1u == (1u << lg);

@@ -122,7 +122,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell
     rsreg::DevBuf d_nbr;          // dense mode: uint32 per cell, occupancy of its 27-cell neighbourhood
     rsreg::DevBuf d_pos_of;       // dense mode: uint32 per target record, its position in d_tgt_sorted
-    rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items | wave costs | done counters | sort scratch
+    rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items (4 per tile) | wave costs | done counters | sort scratch
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     size_t n_target_raw = 0;

@@ -91,3 +91,44 @@ def test_schedule_at_bench_size(api, rs, monkeypatch):
     for _ in range(3):   # (the parts of a split tile meet through device-scope atomics: repeat)
         got, _ = _run(api, src, tgt, 2, 12, 0.05, guess)
         assert got == base
+
+
+@pytest.mark.parametrize("f4,f2", [(0.0, 1.0), (1.0, 0.0), (0.3, 0.4)])
+def test_every_tile_split_at_1m(api, rs, monkeypatch, f4, f2):
+    """All 6985 tiles of the 1 M bench pair searched by 2 or 4 lanes per query (crowded cells, rows beyond ring 1
+    whose extents differ from lane to lane): same bits as the unscheduled launch.  (The lanes of a split query
+    each clip an outer row to what their OWN best still allows: chunk ownership has to be by absolute position.)"""
+    tgt, src = rs.synth.render_frame(0, "N1M", "bench"), rs.synth.render_frame(1, "N1M", "bench")
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    monkeypatch.setenv("RSREG_SCHED", "0")
+    base, kind = _run(api, src, tgt, 2, 5, 0.05, guess)
+    if kind != 1:
+        pytest.skip("the schedule belongs to the dense-table search")
+    monkeypatch.setenv("RSREG_SCHED", "1")
+    monkeypatch.setenv("RSREG_SCHED_MIN_TILES", "1")
+    monkeypatch.setenv("RSREG_SCHED_F4", str(f4))
+    monkeypatch.setenv("RSREG_SCHED_F2", str(f2))
+    got, _ = _run(api, src, tgt, 2, 5, 0.05, guess)
+    assert got == base
+
+
+def test_contexts_in_flight_on_one_gpu(api, rs, monkeypatch):
+    """Three alignments at once (one context and one host thread each) share the GPU: the parts of a split tile then
+    run far apart in time, and every context must still get the bits it gets alone."""
+    import threading
+    tgt, src = rs.synth.render_frame(0, "N1M", "bench"), rs.synth.render_frame(1, "N1M", "bench")
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    monkeypatch.delenv("RSREG_SCHED", raising=False)
+    alone, _ = _run(api, src, tgt, 2, 8, 0.05, guess)
+    out = [None] * 3
+
+    def work(k):
+        for _ in range(3):
+            out[k], _ = _run(api, src, tgt, 2, 8, 0.05, guess)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(o == alone for o in out)

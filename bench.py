@@ -268,8 +268,9 @@ def main():
             res = sharded.run_sharded_icp(stepper, allreduce, guess)
     else:
         def step():
-            lib.check(L.rsreg_icp_set_target_device(ctx.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx.h)
+            # source, then target: the reference's order (incremental_icp.hpp:57-58)
             lib.check(L.rsreg_icp_set_source_device(ctx.h, d_src.data_ptr(), n_src, stride, 0), ctx.h)
+            lib.check(L.rsreg_icp_set_target_device(ctx.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx.h)
             lib.check(L.rsreg_icp_align(ctx.h, g.ctypes.data, C.byref(prm), C.byref(res), None, 0), ctx.h)
 
     def sync():

@@ -184,7 +184,10 @@ int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
 int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,
                                 int is_dense, double max_correspondence_distance);
 
-/* icp.setInputSource(cloud) (incremental_icp.hpp:57, icp_edge...hpp:78,108). */
+/* icp.setInputSource(cloud) (incremental_icp.hpp:57, icp_edge...hpp:78,108).  The source is put into the
+ * engine's order on a stream of its own and joined when the alignment begins: called BEFORE rsreg_icp_set_target
+ * (the reference's order) it runs beside the target's index build.  A host buffer is consumed before the call
+ * returns; a device buffer must stay alive and unchanged until rsreg_icp_begin / rsreg_icp_align has returned. */
 int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense);
 int rsreg_icp_set_source_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,
                                 int is_dense);

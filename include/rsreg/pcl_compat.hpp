@@ -252,16 +252,18 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     {
         if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
         rsreg_ctx *c = ctx_->get();
+        // the source first (the reference's order, incremental_icp.hpp:57-58): it is loaded on a stream of its own,
+        // beside the target's index build
+        if (source_dirty_ || ctx_->icp_source_owner != this) {
+            check(rsreg_icp_set_source(c, source_->points.data(), source_->size(), sizeof(PointSource), source_->is_dense), c);
+            source_dirty_ = false;
+            ctx_->icp_source_owner = this;
+        }
         if (target_dirty_ || ctx_->icp_target_owner != this) {
             check(rsreg_icp_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
                                        prm_.max_correspondence_distance), c);
             target_dirty_ = false;
             ctx_->icp_target_owner = this;
-        }
-        if (source_dirty_ || ctx_->icp_source_owner != this) {
-            check(rsreg_icp_set_source(c, source_->points.data(), source_->size(), sizeof(PointSource), source_->is_dense), c);
-            source_dirty_ = false;
-            ctx_->icp_source_owner = this;
         }
         PointCloud<PointSource> tmp;
         detail::copy_aligned(*source_, tmp);
@@ -278,15 +280,15 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     {
         if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
         rsreg_ctx *c = ctx_->get();
-        if (target_dirty_ || ctx_->icp_target_owner != this) {
-            check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
-            target_dirty_ = false;
-            ctx_->icp_target_owner = this;
-        }
         if (source_dirty_ || ctx_->icp_source_owner != this) {
             check(rsreg_icp_set_source_cloud(c, dsource_->handle()), c);
             source_dirty_ = false;
             ctx_->icp_source_owner = this;
+        }
+        if (target_dirty_ || ctx_->icp_target_owner != this) {
+            check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
+            target_dirty_ = false;
+            ctx_->icp_target_owner = this;
         }
         check(rsreg_icp_align_cloud(c, guess.data(), &prm_, &res_, output.handle()), c);
         std::memcpy(final_.m, res_.transform, sizeof(final_.m));

@@ -252,18 +252,8 @@ class IterativeClosestPoint:
         L, h = _l.lib(), self.ctx.h
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
-        if self._tgt_dirty or self.ctx.icp_target_owner is not self:
-            if isinstance(self._tgt, DeviceCloud):
-                _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
-            elif isinstance(self._tgt, tuple):
-                _, p, n, s = self._tgt
-                _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
-            else:
-                keep, p, n, s = _records(self._tgt)
-                dense = int(getattr(self._tgt, "is_dense", False))
-                _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
-            self._tgt_dirty = False
-            self.ctx.icp_target_owner = self
+        # the source first, as the reference does (incremental_icp.hpp:57-58): the library loads it on a stream of its own,
+        # beside the target's index build
         if self._src_dirty or self.ctx.icp_source_owner is not self:
             if isinstance(self._src, DeviceCloud):
                 _l.check(L.rsreg_icp_set_source_cloud(h, self._src.h), h)
@@ -278,6 +268,18 @@ class IterativeClosestPoint:
             self._n_src = n
             self._src_dirty = False
             self.ctx.icp_source_owner = self
+        if self._tgt_dirty or self.ctx.icp_target_owner is not self:
+            if isinstance(self._tgt, DeviceCloud):
+                _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
+            elif isinstance(self._tgt, tuple):
+                _, p, n, s = self._tgt
+                _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
+            else:
+                keep, p, n, s = _records(self._tgt)
+                dense = int(getattr(self._tgt, "is_dense", False))
+                _l.check(L.rsreg_icp_set_target(h, p, n, s, dense, self.params.max_correspondence_distance), h)
+            self._tgt_dirty = False
+            self.ctx.icp_target_owner = self
 
     def align(self, guess=None):
         """icp.align(out[, guess]): returns the aligned cloud (source colours, xyz <- final * xyz)."""

@@ -121,14 +121,11 @@ double cell_cap_from_env()
     return 0.014;   // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
 }
 
-// bounding box + count of the finite points of a device-resident cloud (one host sync)
-int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, float mn[3], float mx[3], uint32_t *nfin)
+// bounding box + count of the finite points of a device-resident cloud (one host sync), on the given stream with
+// the given scratch: d_misc (64 words; result in the first 16), h_misc (pinned, 16 words), partial (1024 x 8 words)
+int device_bbox_on(rsreg_ctx *ctx, hipStream_t st, uint32_t *d_misc, uint32_t *h_misc, uint32_t *partial, const char *d_pts, size_t n,
+                   size_t stride, float mn[3], float mx[3], uint32_t *nfin)
 {
-    hipStream_t st = ctx->stream;
-    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
-    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
-    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();  // pinned scratch, 16 words used here
     const size_t misc_bytes = 16 * sizeof(uint32_t);
     for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
     for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
@@ -136,8 +133,6 @@ int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, floa
     RSREG_HIP(ctx, hipStreamSynchronize(st));  // h_misc is reused as the read-back buffer
     if (n > 0) {
         const uint32_t nb = std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024);
-        RSREG_HIP(ctx, ctx->d_comm.reserve(1024 * 8 * sizeof(uint32_t) + 64 * sizeof(double)));
-        uint32_t *partial = reinterpret_cast<uint32_t *>(ctx->d_comm.as<char>() + 64 * sizeof(double));
         k_bbox<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, partial);
         RSREG_HIP(ctx, hipGetLastError());
         k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, d_misc);
@@ -148,6 +143,15 @@ int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, floa
     *nfin = h_misc[6];
     for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(h_misc[k]); mx[k] = ordered_float(h_misc[3 + k]); }
     return RSREG_OK;
+}
+
+int device_bbox(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, float mn[3], float mx[3], uint32_t *nfin)
+{
+    RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->d_comm.reserve(1024 * 8 * sizeof(uint32_t) + 64 * sizeof(double)));
+    return device_bbox_on(ctx, ctx->stream, ctx->d_misc.as<uint32_t>(), ctx->h_sums.as<uint32_t>(),
+                          reinterpret_cast<uint32_t *>(ctx->d_comm.as<char>() + 64 * sizeof(double)), d_pts, n, stride, mn, mx, nfin);
 }
 
 float prune2_of(double max_dist)
@@ -454,14 +458,35 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     return RSREG_OK;
 }
 
+// The source load runs on its own stream; whoever needs its result (the number of distinct points, the source
+// buffers) joins it first.
+int join_source(rsreg_ctx *ctx)
+{
+    if (!ctx->src_pending) return RSREG_OK;
+    ctx->src_pending = false;
+    RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_src_done));
+    ctx->n_work = ctx->h_smisc.as<uint32_t>()[32];
+    return RSREG_OK;
+}
+
 // Loads the source: orders it spatially (Morton order of a few-mm grid, so the lanes of a wave
 // query neighbouring cells) and merges exact copies of a point into one weighted point (the
 // RealSense (0,0,0) pixels are ~11 % of a frame: they are searched once, not 10^5 times).
 // d_perm: sorted position -> caller's index; d_uniq_of: sorted position -> distinct point.
+// Everything after the bounding box (one host sync) is only queued -- on ctx->stream_src, behind whatever the
+// main stream holds so far -- and joined by join_source: when the caller sets the source before the target (the
+// reference's order, incremental_icp.hpp:57-58) the load runs beside the target's index build.
 int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
 {
     if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
-    hipStream_t st = ctx->stream;
+    int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
+    if (rcj) return rcj;
+    if (!ctx->stream_src) {
+        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    }
+    hipStream_t st = ctx->stream_src;
     RSREG_HIP(ctx, ctx->d_src_all.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
@@ -475,33 +500,38 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->d_smisc.reserve((64 + 1024 * 8) * sizeof(uint32_t)));
+    RSREG_HIP(ctx, ctx->h_smisc.reserve(64 * sizeof(uint32_t)));
     ctx->n_source = n;
     ctx->n_work = 0;
     ctx->src_cloud = nullptr;
     ctx->have_source = false;
     ctx->icp.active = 0;
     if (n) {
+        // the raw cloud may have been produced (uploaded, filtered, transformed) on the main stream just now
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+        uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
+        uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
         float mn[3], mx[3];
         uint32_t nfin = 0;
-        int rc = device_bbox(ctx, d_raw, n, stride, mn, mx, &nfin);
+        int rc = device_bbox_on(ctx, st, d_misc, h_misc, d_misc + 64, d_raw, n, stride, mn, mx, &nfin);
         if (rc) return rc;
         if (nfin == 0) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
         double extent = 0;
         for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
         // fine Morton resolution (a few mm): consecutive points then form compact blobs
         const float cell = (float)std::max(cell_cap_from_env() / 8.0, extent / 60000.0);
-        RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
-        RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
-        RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
-        RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
-        RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
-        auto *keys = ctx->d_keys.as<unsigned long long>();
-        auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
-        auto *vals = ctx->d_vals.as<uint32_t>();
+        RSREG_HIP(ctx, ctx->d_skeys.reserve(n * 8));
+        RSREG_HIP(ctx, ctx->d_skeys_alt.reserve(n * 8));
+        RSREG_HIP(ctx, ctx->d_svals.reserve(n * 4));
+        RSREG_HIP(ctx, ctx->d_sflags.reserve(n * 4));
+        RSREG_HIP(ctx, ctx->d_sscan.reserve(n * 4));
+        auto *keys = ctx->d_skeys.as<unsigned long long>();
+        auto *keys2 = ctx->d_skeys_alt.as<unsigned long long>();
+        auto *vals = ctx->d_svals.as<uint32_t>();
         uint32_t *perm = ctx->d_perm.as<uint32_t>();
-        uint32_t *keep = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
-        uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
-        uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
+        uint32_t *keep = ctx->d_sflags.as<uint32_t>(), *pos = ctx->d_sscan.as<uint32_t>();
         const uint32_t nb = div_up((uint32_t)n, kBlock);
         // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
         int axis_bits = 1;
@@ -512,23 +542,22 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         size_t sort_bytes = 0, scan_bytes = 0;
         RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+        RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr);
         RSREG_HIP(ctx, hipGetLastError());
         k_source_flag<<<nb, kBlock, 0, st>>>(keys2, ctx->d_src_all.as<float4>(), (uint32_t)n, keep);
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
                                                ctx->d_uniq_of.as<uint32_t>(), d_misc + 12);
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc + 12, 4, hipMemcpyDeviceToHost, st));
-        RSREG_HIP(ctx, hipStreamSynchronize(st));
-        const uint32_t nu = h_misc[0];
-        ctx->n_work = nu;
-        k_source_weights<<<div_up(nu, kBlock), kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), ctx->d_first.as<uint32_t>(), nu,
-                                                                ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
+        RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 32, d_misc + 12, 4, hipMemcpyDeviceToHost, st));   // the number of distinct points: read at the join
+        k_source_weights<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), ctx->d_first.as<uint32_t>(), d_misc + 12,
+                                                ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
+        ctx->src_pending = true;
     }
     ctx->have_source = true;
     return RSREG_OK;
@@ -1057,6 +1086,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     if (!ctx) return RSREG_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_src) (void)hipStreamSynchronize(ctx->stream_src);
     rsreg_comm_destroy(ctx);
     if (ctx->recip) {   // the child context of the reciprocal index runs on this context's stream: it goes first
         rsreg_ctx_destroy(ctx->recip);
@@ -1066,14 +1096,21 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
-                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm};
+                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
+    ctx->h_smisc.release();
     ctx->h_stage.release();
     ctx->h_ndt.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_ndt)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->stream_src) {
+        (void)hipStreamDestroy(ctx->stream_src);
+        (void)hipEventDestroy(ctx->ev_src_done);
+        (void)hipEventDestroy(ctx->ev_main);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RSREG_OK;
@@ -1151,7 +1188,9 @@ int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     (void)is_dense;
     if (!ctx || (n && !points) || stride < 12) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = pack_to_stage(ctx, points, n, stride);
+    int rc = join_source(ctx);   // (a load still in flight reads d_src_raw)
+    if (rc) return rc;
+    rc = pack_to_stage(ctx, points, n, stride);
     if (rc) return rc;
     RSREG_HIP(ctx, ctx->d_src_raw.reserve(n * 12 + 16));
     if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_src_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -1172,6 +1211,10 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     if (params->max_correspondence_distance > ctx->gate_built_for)
         return fail(ctx, RSREG_ERR_INVALID_ARG, "max_correspondence_distance exceeds the one the target index was built for");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        int rcj = join_source(ctx);
+        if (rcj) return rcj;
+    }
     IcpState &s = ctx->icp;
     s = IcpState();
     s.prm = *params;
@@ -1396,6 +1439,10 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
         RSREG_HIP(ctx, hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
         RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->grid_info.max_points_per_cell = h;
+    }
+    {
+        int rcj = join_source(ctx);
+        if (rcj) return rcj;
     }
     *info = ctx->grid_info;
     info->n_source_distinct = ctx->have_source ? (uint32_t)ctx->n_work : 0u;

@@ -387,11 +387,12 @@ __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all,
 }
 
 // src[u] = {xyz, weight = number of copies (0: invalid point)}; cur = copy
-__global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all, const uint32_t *first, uint32_t nu, float4 *src,
+// (launched over all n source records: how many of them are distinct is only known on the device yet)
+__global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all, const uint32_t *first, const uint32_t *nu, float4 *src,
                                                            float4 *cur)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nu) return;
+    if (u >= *nu) return;
     const uint32_t j = first[u];
     float4 s = src_all[j];
     s.w = s.w != 0.0f ? (float)(first[u + 1] - j) : 0.0f;

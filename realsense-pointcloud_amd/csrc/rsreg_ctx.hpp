@@ -132,6 +132,13 @@ struct rsreg_ctx {
     const struct rsreg_cloud *src_cloud = nullptr;   // set by rsreg_icp_set_source_cloud: where the aligned cloud's records come from
     size_t n_source = 0;          // source points handed in
     size_t n_work = 0;            // distinct source points the iteration works on (exact copies merged)
+    // the source is loaded on a stream of its own (so that it runs beside the target's index build when the
+    // caller sets the source first, as the reference does) and joined where the alignment begins
+    hipStream_t stream_src = nullptr;
+    hipEvent_t ev_src_done = nullptr, ev_main = nullptr;
+    bool src_pending = false;
+    rsreg::DevBuf d_skeys, d_skeys_alt, d_svals, d_sflags, d_sscan, d_stmp, d_smisc;   // its scratch (the target build has its own)
+    rsreg::PinnedBuf h_smisc;
     rsreg::DevBuf d_src_all;      // float4 {x,y,z,valid} of every source point, spatially sorted
     rsreg::DevBuf d_uniq_of;      // uint32: sorted position -> distinct point id
     rsreg::DevBuf d_first;        // uint32[n_work+1]: first sorted position of each distinct point

@@ -15,14 +15,17 @@ tp, sp = synth.render_frame(0, size, "parity"), synth.render_frame(1, size, "par
 t, s = api.DeviceCloud(tp, ctx), api.DeviceCloud(sp, ctx)
 ref = api.IterativeClosestPoint(ctx)
 ref.params = api.icp_params(reference=True)
-for k in range(25):
-    if k == 5:
-        ctx.synchronize()
-        t0 = time.perf_counter()
+times = []
+for k in range(105):
+    ctx.synchronize()
+    t0 = time.perf_counter()
     ref.setInputSource(s)
     ref.setInputTarget(t)
     ref.align()
-ctx.synchronize()
+    ctx.synchronize()
+    if k >= 5:
+        times.append(time.perf_counter() - t0)
+import numpy as np
 gi = ref.grid_info()
-print("%s reference parameters, device clouds: %.3f ms per pair, %d correspondences, cell %.4f m, %d cells occupied" %
-      (size, (time.perf_counter() - t0) / 20 * 1e3, ref.result.n_correspondences, gi.cell_size, gi.n_cells))
+print("%s reference parameters, device clouds: median %.3f ms per pair (p10 %.3f, p90 %.3f), %d correspondences, cell %.4f m" %
+      (size, np.median(times) * 1e3, np.percentile(times, 10) * 1e3, np.percentile(times, 90) * 1e3, ref.result.n_correspondences, gi.cell_size))

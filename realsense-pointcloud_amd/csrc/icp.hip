@@ -127,10 +127,13 @@ int device_bbox_on(rsreg_ctx *ctx, hipStream_t st, uint32_t *d_misc, uint32_t *h
                    size_t stride, float mn[3], float mx[3], uint32_t *nfin)
 {
     const size_t misc_bytes = 16 * sizeof(uint32_t);
-    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
-    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
-    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, misc_bytes, hipMemcpyHostToDevice, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));  // h_misc is reused as the read-back buffer
+    // words 7..15 (counters of the builds that follow) start at zero; k_bbox_final writes words 0..6 itself
+    RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0, misc_bytes, st));
+    if (n == 0) {   // no kernel runs: the empty box
+        for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(0xffffffffu); mx[k] = ordered_float(0u); }
+        *nfin = 0;
+        return RSREG_OK;
+    }
     if (n > 0) {
         const uint32_t nb = std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024);
         k_bbox<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, partial);

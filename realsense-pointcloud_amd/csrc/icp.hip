@@ -226,8 +226,6 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_nbr.reserve((total + 2) * 4));
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_pos_of.reserve((n + 1) * 4));
-    k_dense_fill_sentinels<<<div_up(nfin + 4, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), nfin + 4);
-    RSREG_HIP(ctx, hipGetLastError());
     const DenseDev g = dense_dev(ctx, max_dist);
     auto *keys = ctx->d_keys.as<unsigned long long>();
     auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
@@ -238,7 +236,6 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
     uint32_t *table = ctx->d_dense.as<uint32_t>();
     RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4, st));
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 8, 0, 8 * 4, st));
     k_dense_keys<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
     int id_bits = 1;

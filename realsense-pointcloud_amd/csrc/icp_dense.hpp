@@ -87,13 +87,6 @@ __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long 
     cstart[i] = cs;
 }
 
-// far-away sentinels behind the last sorted point: a 4-wide candidate read may run past it
-__global__ __launch_bounds__(kBlock) void k_dense_fill_sentinels(float4 *sorted, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sorted[i] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
-}
-
 // the sorted point array, and for every occupied cell (in sorted order) its table slot and the
 // position of its first point; pos / cid = exclusive scans of keep / cstart.
 // stats[0] = occupied cells, stats[2] = kept points
@@ -120,6 +113,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         stats[0] = nc;
         stats[2] = nu;
         cellpos[nc] = nu;   // sentinel
+        // far-away points behind the last sorted point: a 4-wide candidate read may run past it
+        for (uint32_t k = 0; k < 4; ++k) sorted[nu + k] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
     }
 }
 

@@ -231,8 +231,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
-    uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n;
-    uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n;
+    auto *flags = ctx->d_flags.as<unsigned long long>(), *scan = ctx->d_scan.as<unsigned long long>();   // keep | cstart << 32 and its scan
     uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
     uint32_t *table = ctx->d_dense.as<uint32_t>();
     RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4, st));
@@ -243,16 +242,15 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     const unsigned end_bit = (unsigned)std::min(64, 16 + id_bits);
     size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
     RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     const uint32_t nbf = div_up(nfin, kBlock);
-    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart);
+    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, flags);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, pos, cid, ctx->d_tgt_sorted.as<float4>(),
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
+    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, flags, scan, ctx->d_tgt_sorted.as<float4>(),
                                             ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);

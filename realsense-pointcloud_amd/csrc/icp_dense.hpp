@@ -66,10 +66,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t s
     vals[i] = i;
 }
 
-// keep[i]: not a value-equal duplicate of its predecessor in the same (cell, hash) run;
-// cstart[i]: first point of a cell (always kept)
+// flags[i] = keep | cstart << 32.  keep: not a value-equal duplicate of its predecessor in the same (cell, x bucket)
+// run; cstart: first point of a cell (always kept).  One 64-bit exclusive scan of the flags gives both running
+// counts at once: pos (low word) and cid (high word).
 __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long *keys, const uint32_t *vals, const char *pts,
-                                                       size_t stride, uint32_t nfin, uint32_t *keep, uint32_t *cstart)
+                                                       size_t stride, uint32_t nfin, unsigned long long *flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
@@ -83,33 +84,33 @@ __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long 
             if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) kp = 0;
         }
     }
-    keep[i] = kp;
-    cstart[i] = cs;
+    flags[i] = (unsigned long long)kp | (unsigned long long)cs << 32;
 }
 
 // the sorted point array, and for every occupied cell (in sorted order) its table slot and the
-// position of its first point; pos / cid = exclusive scans of keep / cstart.
+// position of its first point; scan[i] = exclusive scan of flags: pos | cid << 32.
 // stats[0] = occupied cells, stats[2] = kept points
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long long *keys, const uint32_t *vals, const char *pts,
-                                                          size_t stride, uint32_t nfin, const uint32_t *keep,
-                                                          const uint32_t *cstart, const uint32_t *pos, const uint32_t *cid,
-                                                          float4 *sorted, uint32_t *pos_of, uint32_t *cellslot,
-                                                          uint32_t *cellpos, uint32_t *stats)
+                                                          size_t stride, uint32_t nfin, const unsigned long long *flags,
+                                                          const unsigned long long *scan, float4 *sorted, uint32_t *pos_of,
+                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
-    if (keep[i]) {
+    const unsigned long long f = flags[i], sc = scan[i];
+    const uint32_t keep = (uint32_t)f, cstart = (uint32_t)(f >> 32), pos = (uint32_t)sc, cid = (uint32_t)(sc >> 32);
+    if (keep) {
         const uint32_t v = vals[i];
         const float *p = rec_xyz(pts, stride, v);
-        sorted[pos[i]] = tgt_rec(p[0], p[1], p[2], v);
-        pos_of[v] = pos[i];
+        sorted[pos] = tgt_rec(p[0], p[1], p[2], v);
+        pos_of[v] = pos;
     }
-    if (cstart[i]) {
-        cellslot[cid[i]] = (uint32_t)(keys[i] >> 16);
-        cellpos[cid[i]] = pos[i];
+    if (cstart) {
+        cellslot[cid] = (uint32_t)(keys[i] >> 16);
+        cellpos[cid] = pos;
     }
     if (i == nfin - 1) {
-        const uint32_t nu = pos[i] + keep[i], nc = cid[i] + cstart[i];
+        const uint32_t nu = pos + keep, nc = cid + cstart;
         stats[0] = nc;
         stats[2] = nu;
         cellpos[nc] = nu;   // sentinel

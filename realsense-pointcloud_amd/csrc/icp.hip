@@ -875,7 +875,11 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
         if (ctx->grid.dense) {
             unsigned long long *wt = wave_times_ptr(ctx, n);
             static const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
-            auto kern = wt ? (light ? k_icp_fused_dense<2> : k_icp_fused_dense<1>) : k_icp_fused_dense<0>;
+            // (the search beyond ring 1 comes in two forms; each instantiation carries only the one its grid uses)
+            const bool blocks = ctx->grid.max_ring <= 4 && !std::getenv("RSREG_FAR_ROWS");
+            auto kern = wt ? (light ? (blocks ? k_icp_fused_dense<2, 1> : k_icp_fused_dense<2, 2>)
+                                    : (blocks ? k_icp_fused_dense<1, 1> : k_icp_fused_dense<1, 2>))
+                           : (blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>);
             const SchedCfg cfg = sched_cfg();
             const uint32_t n_tiles = reduce_blocks(n);
             const bool sched_ok = cfg.on && (!wt || light) && n_tiles >= cfg.min_tiles && n_tiles < (1u << 24);

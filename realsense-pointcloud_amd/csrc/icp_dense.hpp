@@ -478,6 +478,105 @@ __device__ __forceinline__ void dense_far(const DenseDev &g, const DRes &rs, con
     }
 }
 
+// The same search for grids whose gate reaches at most 4 cells (max_ring <= 4: every bounded gate), driven by the
+// neighbourhood words instead of the table: the 81 rows around the query are 9 blocks of 3 x 3 rows, and the three
+// words at columns cx-3, cx, cx+3 of a block's middle row say which of the block's 9 x 9 cells hold points.
+// Empty rows (most rows of a query that has to look this far) cost a few bit operations instead of two dependent
+// table loads each, and an occupied row is read only over the span of its occupied cells.
+template <bool kDiag = false>
+__device__ __forceinline__ void dense_far_row_occ(const DenseDev &g, const DRes &rs, const DQuery &q, int y, int z, bool central,
+                                                  uint32_t rowbits, float inv_cell2, f32x2 qxy, DBest &b, float &limit2, DSplit sp,
+                                                  DDiag *dg)
+{
+    const float ay = axis_gap(q.uy, y, y, g.margin), az = axis_gap(q.uz, z, z, g.margin);
+    const float rem = limit2 * inv_cell2 - (ay * ay + az * az);   // budget left for the x gap, squared cells
+    if (rem < 0.0f) return;
+    // cells cx-kl .. cx+kr are the ones whose x gap fits the budget; rowbits: bit k = cell cx - 4 + k
+    const float sr = sqrtf(rem) + g.margin + 1e-4f, fx = q.ux - (float)q.cx;
+    const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), 4.0f), kr = (int)fminf(fmaxf(sr + fx, 0.0f), 4.0f);
+    uint32_t m = rowbits & ((2u << (4 + kr)) - (1u << (4 - kl)));
+    if (central) m &= ~0x38u;   // cells cx-1 .. cx+1 of the nine central rows were searched in rings 0-1
+    if (!m) return;
+    if (kDiag) ++dg->far_rows;
+    const int row = (int)dense_cell_id(g, q.cx - 4, y, z);
+    const float yz2 = (ay * ay + az * az) * (g.cell * g.cell), x_slack = g.x_slack;
+    if (!central) {
+        const int xa = __ffs((int)m) - 1, xb = 31 - __clz((int)m);   // first and last occupied cell in reach
+        const uint32_t s = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xa) * 4u, 0, 0);
+        const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + xb + 1) * 4u, 0, 0);
+        if (kDiag) dg->far_scans += (e - s + 3) / 4;
+        dscan_range(b, rs.pts, s * 16u, e * 16u, qxy, q.qz, sp);
+    } else {
+        // the part left of the searched middle (bits 0..2) from its right end, the part right of it (bits 6..8) from its left end;
+        // an empty part reads the same table entry twice
+        const uint32_t ml = m & 7u, mr = m >> 6;
+        const int la = ml ? __ffs((int)ml) - 1 : 0, lb = ml ? 32 - __clz((int)ml) : 0;
+        const int ra = mr ? 6 + __ffs((int)mr) - 1 : 6, rb = mr ? 6 + 32 - __clz((int)mr) : 6;
+        const uint32_t s0 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + la) * 4u, 0, 0);
+        const uint32_t e0 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + lb) * 4u, 0, 0);
+        const uint32_t s1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + ra) * 4u, 0, 0);
+        const uint32_t e1 = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (uint32_t)(row + rb) * 4u, 0, 0);
+        if (kDiag) dg->far_scans += (e0 - s0 + 3) / 4 + (e1 - s1 + 3) / 4;
+        DWalk w;
+        dwalk_open(w, u32x2{s0, e0}, true, yz2, sp);
+        while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
+        dwalk_open(w, u32x2{s1, e1}, false, yz2, sp);
+        while (w.left > 0) dwalk_step(w, b, rs.pts, qxy, q.qz, x_slack, limit2);
+    }
+    limit2 = fminf(limit2, b.d);
+}
+
+template <bool kDiag = false>
+__device__ __forceinline__ void dense_far_blocks(const DenseDev &g, const DRes &rs, const DQuery &q, DBest &b, float &limit2,
+                                                 DSplit sp, DDiag *dg = nullptr)
+{
+    const f32x2 qxy = {q.qx, q.qy};
+    const float cell2 = g.cell * g.cell, inv_cell2 = 1.0f / cell2;
+    // blocks by distance: the middle one (the nine central rows), its four edge neighbours, the four corners;
+    // (by + 1) and (bz + 1) of block k, two bits each
+    constexpr uint32_t kBy = 1u | 0u << 2 | 2u << 4 | 1u << 6 | 1u << 8 | 0u << 10 | 2u << 12 | 0u << 14 | 2u << 16;
+    constexpr uint32_t kBz = 1u | 1u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+        const int by = (int)((kBy >> (2 * k)) & 3u) - 1, bz = (int)((kBz >> (2 * k)) & 3u) - 1;
+        const int yc = q.cy + 3 * by, zc = q.cz + 3 * bz;   // the block's middle row (a border row still has a valid word)
+        if (yc < -1 || yc > g.ny || zc < -1 || zc > g.nz) continue;
+        // nothing in the block's rows yc-1 .. yc+1, zc-1 .. zc+1 can be closer than this
+        const float aby = k ? axis_gap(q.uy, yc - 1, yc + 1, g.margin) : 0.0f, abz = k ? axis_gap(q.uz, zc - 1, zc + 1, g.margin) : 0.0f;
+        const float rem_b = limit2 * inv_cell2 - (aby * aby + abz * abz);
+        if (rem_b < 0.0f) continue;
+        const int base = (int)dense_cell_id(g, q.cx, yc, zc);
+        // (a column outside the padded table reads as "nothing there": the descriptor's bounds check returns 0)
+        uint32_t w0 = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, q.cx >= 2 ? (uint32_t)(base - 3) * 4u : 0xfffffff0u, 0, 0);
+        uint32_t w1 = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
+        uint32_t w2 = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, q.cx + 3 <= g.nx ? (uint32_t)(base + 3) * 4u : 0xfffffff0u, 0, 0);
+        {
+            // the columns ANY row of the block can reach with the budget left (a superset of each row's own extent, from the
+            // block's smallest possible (y, z) gap): occupied cells outside it are dropped from all nine rows at once, so
+            // only rows that hold points where they can matter come up below
+            const float sr = sqrtf(rem_b) + g.margin + 1e-4f, fx = q.ux - (float)q.cx;
+            const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), 4.0f), kr = (int)fminf(fmaxf(sr + fx, 0.0f), 4.0f);
+            uint32_t e = (2u << (4 + kr)) - (1u << (4 - kl));
+            if (k == 0) e &= ~0x38u;   // the middle three columns of the nine central rows were searched in rings 0-1
+            w0 &= ((e & 1u) ? 0x1249249u : 0u) | ((e & 2u) ? 0x2492492u : 0u) | ((e & 4u) ? 0x4924924u : 0u);
+            w1 &= ((e & 8u) ? 0x1249249u : 0u) | ((e & 16u) ? 0x2492492u : 0u) | ((e & 32u) ? 0x4924924u : 0u);
+            w2 &= ((e & 64u) ? 0x1249249u : 0u) | ((e & 128u) ? 0x2492492u : 0u) | ((e & 256u) ? 0x4924924u : 0u);
+        }
+        // bit 3 m of t: row m = lz * 3 + ly of the block holds points somewhere in columns cx-4 .. cx+4
+        const uint32_t any = w0 | w1 | w2;
+        uint32_t t = (any | any >> 1 | any >> 2) & 0x1249249u;
+        while (t) {
+            const int m3 = __ffs((int)t) - 1;   // = lz * 9 + ly * 3: the shift of the row's three bits in each word
+            t &= t - 1;
+            const int lz = (m3 >= 9) + (m3 >= 18), ly = ((m3 - 9 * lz) >= 3) + ((m3 - 9 * lz) >= 6);
+            const int dy = 3 * by + ly - 1, dz = 3 * bz + lz - 1;
+            if (max(abs(dy), abs(dz)) > g.max_ring) continue;
+            const uint32_t rowbits = ((w0 >> m3) & 7u) | ((w1 >> m3) & 7u) << 3 | ((w2 >> m3) & 7u) << 6;
+            dense_far_row_occ<kDiag>(g, rs, q, q.cy + dy, q.cz + dz, k == 0, rowbits, inv_cell2, qxy, b, limit2, sp, dg);
+        }
+    }
+}
+
 __device__ __forceinline__ Best dense_result(const DenseDev &g, const DBest &b)
 {
     Best out{~0ull, -1, FLT_MAX};
@@ -490,7 +589,9 @@ __device__ __forceinline__ Best dense_result(const DenseDev &g, const DBest &b)
 }
 
 // Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
-template <bool kDiag = false>
+// kFar: which search beyond ring 1 is compiled in -- 0: both, chosen by the grid (max_ring <= 4: blocks); 1: blocks only
+// (the caller knows max_ring <= 4); 2: rows only
+template <bool kDiag = false, int kFar = 0>
 __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos, DDiag *dg = nullptr,
                                                DSplit sp = DSplit{0u, 0u})
 {
@@ -502,7 +603,10 @@ __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, floa
     dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, sp, dg);
     if (kDiag) dg->t_near = wall_clock64();
     const bool far = dense_needs_far(g, limit2);
-    if (far) dense_far<kDiag>(g, rs, q, b, limit2, sp, dg);
+    if (far) {
+        if (kFar == 1 || (kFar == 0 && g.max_ring <= 4)) dense_far_blocks<kDiag>(g, rs, q, b, limit2, sp, dg);
+        else dense_far<kDiag>(g, rs, q, b, limit2, sp, dg);
+    }
     if (kDiag) dg->t_far = wall_clock64();
     // the lanes of a split query hold the bests of disjoint parts of the candidate set: the smallest
     // (distance, index) key among them is the query's (every lane of the group ends up with it)
@@ -571,6 +675,7 @@ __device__ __forceinline__ float4 coherent_load(const float4 *p)
 
 // One part of a split tile: 128 >> lg queries, 2^lg lanes each.  Returns true in the workgroup that finishes
 // the tile last (it then adds the tile's sums up from what all parts have left in sched.pos / sched.d2 / cur).
+template <int kFar>
 __device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, const Mat34 &T, int apply_t, const DenseDev &g, double gate2,
                                                        int *seed, const TileSched &sched, uint32_t tile, uint32_t part, uint32_t lg)
 {
@@ -586,7 +691,7 @@ __device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, 
                 q = make_float4(t.x, t.y, t.z, q.w);
             }
             const int seed_in = seed ? seed[i] : -1;
-            const Best b = nn_query_dense<false>(g, q.x, q.y, q.z, seed_in, nullptr, sp);
+            const Best b = nn_query_dense<false, kFar>(g, q.x, q.y, q.z, seed_in, nullptr, sp);
             if (sp.sub == 0) {
                 if (apply_t) coherent_store(&cur[i], q);
                 if (seed && b.pos != seed_in) seed[i] = b.pos;
@@ -632,7 +737,7 @@ __device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsi
 // gate, accumulate (same contract and summation order as k_icp_fused).  kDiag: the diagnostic
 // instantiation (RSREG_WAVE_TIMES) also writes clock stamps and step counts per wave (1), or only the start and
 // end stamp and the hardware slot of each wave, at the product kernel's own occupancy (2: RSREG_WAVE_TIMES_LIGHT=1).
-template <int kDiag>
+template <int kDiag, int kFar>
 __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev,
@@ -653,7 +758,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
     float d2 = 0.0f;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lg != 0) {
-        if (!fused_dense_split_part(cur, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
+        if (!fused_dense_split_part<kFar>(cur, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
             if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg, item);
             return;
         }
@@ -673,7 +778,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
                 cur[i] = q;
             }
             const int seed_in = seed ? seed[i] : -1;
-            const Best b = nn_query_dense<kFull>(g, q.x, q.y, q.z, seed_in, &dg);
+            const Best b = nn_query_dense<kFull, kFar>(g, q.x, q.y, q.z, seed_in, &dg);
             if (seed && b.pos != seed_in) seed[i] = b.pos;   // (most matches do not change once the clouds have settled)
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;

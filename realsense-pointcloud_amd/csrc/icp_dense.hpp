@@ -491,12 +491,9 @@ __device__ __forceinline__ void dense_far_row_occ(const DenseDev &g, const DRes 
     const float ay = axis_gap(q.uy, y, y, g.margin), az = axis_gap(q.uz, z, z, g.margin);
     const float rem = limit2 * inv_cell2 - (ay * ay + az * az);   // budget left for the x gap, squared cells
     if (rem < 0.0f) return;
-    // cells cx-kl .. cx+kr are the ones whose x gap fits the budget; rowbits: bit k = cell cx - 4 + k
-    const float sr = sqrtf(rem) + g.margin + 1e-4f, fx = q.ux - (float)q.cx;
-    const int kl = (int)fminf(fmaxf(sr + 1.0f - fx, 0.0f), 4.0f), kr = (int)fminf(fmaxf(sr + fx, 0.0f), 4.0f);
-    uint32_t m = rowbits & ((2u << (4 + kr)) - (1u << (4 - kl)));
-    if (central) m &= ~0x38u;   // cells cx-1 .. cx+1 of the nine central rows were searched in rings 0-1
-    if (!m) return;
+    // rowbits: bit k = cell cx - 4 + k, already cut to the columns the BLOCK's budget reaches (a superset of this row's own
+    // extent: a few more candidates read, no square root per row) and without the searched middle of the central rows
+    const uint32_t m = rowbits;
     if (kDiag) ++dg->far_rows;
     const int row = (int)dense_cell_id(g, q.cx - 4, y, z);
     const float yz2 = (ay * ay + az * az) * (g.cell * g.cell), x_slack = g.x_slack;

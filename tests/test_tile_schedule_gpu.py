@@ -132,3 +132,37 @@ def test_contexts_in_flight_on_one_gpu(api, rs, monkeypatch):
     for t in threads:
         t.join()
     assert all(o == alone for o in out)
+
+
+def test_random_scenes_split_equals_unsplit(api, rs, monkeypatch):
+    """Random scenes (clusters, planes, lattices full of exact ties, lines; duplicates, invalid records, queries far
+    outside; gates from a fraction of a cell to unbounded): staged kernels, the unscheduled fused kernel and the fused
+    kernel with every tile searched by 2 / by 2 and 4 lanes per query give the same bits."""
+    from test_nn_fuzz_gpu import scene
+    rng = np.random.default_rng(77)
+    kinds = ["uniform", "plane", "clusters", "lattice", "line"]
+    gates = [0.004, 0.013, 0.05, 0.2, 1e30]
+    for it in range(15):
+        kind = kinds[it % len(kinds)]
+        nt, ns = int(rng.integers(2000, 60000)), int(rng.integers(2000, 40000))
+        tgt = scene(rng, kind, nt).astype(np.float32)
+        src = (scene(rng, kind, ns) + rng.uniform(-0.02, 0.02, 3)).astype(np.float32)
+        if it % 3 == 0:
+            tgt[rng.integers(0, nt, nt // 10)] = 0.0
+            src[rng.integers(0, ns, ns // 10)] = 0.0
+            src[rng.integers(0, ns, ns // 50)] = np.inf
+        if it % 4 == 1:
+            src[rng.integers(0, ns, ns // 8)] += rng.uniform(-1, 1, 3).astype(np.float32)
+        gate = gates[int(rng.integers(0, len(gates)))]
+        tc, sc = rs.PointCloud.from_xyz(tgt), rs.PointCloud.from_xyz(src)
+        out = []
+        for pipeline, env in ((2, {"RSREG_SCHED": "0"}), (0, {"RSREG_SCHED": "0"}),
+                              (2, {"RSREG_SCHED_MIN_TILES": "1", "RSREG_SCHED_F2": "0.5", "RSREG_SCHED_F4": "0.5"}),
+                              (2, {"RSREG_SCHED_MIN_TILES": "1", "RSREG_SCHED_F2": "1.0", "RSREG_SCHED_F4": "0.0"})):
+            for k in ("RSREG_SCHED", "RSREG_SCHED_MIN_TILES", "RSREG_SCHED_F2", "RSREG_SCHED_F4"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, _ = _run(api, sc, tc, pipeline, 4, gate)
+            out.append(got)
+        assert out[0] == out[1] == out[2] == out[3], (it, kind, nt, ns, gate)

@@ -61,12 +61,27 @@ __global__ __launch_bounds__(256) void k_ndt_bbox(const char *pts, size_t stride
         }
         cnt += __shfl_down(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[k], f2o(mn[k]));
-            atomicMax(&bbox[3 + k], f2o(mx[k]));
+    // one set of atomics per workgroup, not per wave: they all hit the same seven words
+    __shared__ float smn[4][3], smx[4][3];
+    __shared__ uint32_t scnt[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) { smn[wave][k] = mn[k]; smx[wave][k] = mx[k]; }
+        scnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], smn[w][k]); mx[k] = fmaxf(mx[k], smx[w][k]); }
+            cnt += scnt[w];
         }
-        atomicAdd(&bbox[6], cnt);
+        if (cnt) {
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&bbox[k], f2o(mn[k]));
+                atomicMax(&bbox[3 + k], f2o(mx[k]));
+            }
+            atomicAdd(&bbox[6], cnt);
+        }
     }
 }
 
@@ -410,13 +425,12 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     const size_t pstride = stride;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_ndt.as<uint32_t>();
-    for (int k = 0; k < 3; ++k) { h_misc[k] = 0xffffffffu; h_misc[3 + k] = 0u; }
-    for (int k = 6; k < 16; ++k) h_misc[k] = 0u;
-    RSREG_HIP(ctx, hipMemcpyAsync(d_misc, h_misc, 64, hipMemcpyHostToDevice, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    // minima start at all ones, maxima and the count at zero (ordered-float encoding): two memsets, no upload + sync
+    RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0xff, 12, st));
+    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, 52, st));
     h_misc[6] = 0;
     if (n) {
-        k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 1024), 256, 0, st>>>(d_pts, pstride, (uint32_t)n, d_misc);
+        k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 256), 256, 0, st>>>(d_pts, pstride, (uint32_t)n, d_misc);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
         RSREG_HIP(ctx, hipStreamSynchronize(st));

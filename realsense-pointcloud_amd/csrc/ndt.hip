@@ -197,7 +197,9 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
     }
     k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
                                                            store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
-                                                           ctx->d_ndt_partials.as<double>(), ctx->d_ndt_out.as<double>(),
+                                                           ctx->d_ndt_partials.as<double>(),
+                                                           // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue)
+                                                           ctx->comm ? ctx->d_ndt_out.as<double>() : ctx->h_ndt.as<double>(),
                                                            reinterpret_cast<unsigned int *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc));   // (the final reduce rides along)
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
@@ -206,7 +208,7 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
         if (rc) return rc;
     }
     double *h = ctx->h_ndt.as<double>();
-    RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_ndt_out.ptr, kNdtAcc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->comm) RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_ndt_out.ptr, kNdtAcc * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling) {
         float ms = 0;

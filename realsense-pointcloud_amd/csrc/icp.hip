@@ -741,6 +741,10 @@ int launch_search(rsreg_ctx *ctx)
 
 extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int count);  // comm.cpp
 
+// where k_final_reduce leaves the 17 sums the host is about to read: without a communicator straight in the pinned
+// host buffer (no copy to queue behind the kernel), otherwise in HBM (the all-reduce works there)
+double *host_sums_target(rsreg_ctx *ctx) { return ctx->comm ? ctx->d_sums.as<double>() : ctx->h_sums.as<double>(); }
+
 int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
     if (global && ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
@@ -748,7 +752,7 @@ int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
         if (rc) return rc;
     }
     double *h = ctx->h_sums.as<double>();
-    RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_sums.ptr, RSREG_NUM_SUMS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->comm) RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_sums.ptr, RSREG_NUM_SUMS * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(sums, h, RSREG_NUM_SUMS * 8);
     return RSREG_OK;
@@ -768,7 +772,7 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
                                                                     ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
                                                                     ctx->d_partials.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
-        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
+        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), host_sums_target(ctx));
         RSREG_HIP(ctx, hipGetLastError());
     }
     return fetch_sums(ctx, sums, global);
@@ -933,7 +937,8 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
         RSREG_HIP(ctx, hipGetLastError());
         return RSREG_OK;
     }
-    k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>());
+    k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n),
+                                                               device_loop ? ctx->d_sums.as<double>() : host_sums_target(ctx));
     RSREG_HIP(ctx, hipGetLastError());
     if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass
         if (ctx->comm) {

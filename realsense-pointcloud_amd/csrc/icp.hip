@@ -138,10 +138,9 @@ int device_bbox_on(rsreg_ctx *ctx, hipStream_t st, uint32_t *d_misc, uint32_t *h
         const uint32_t nb = std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024);
         k_bbox<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, partial);
         RSREG_HIP(ctx, hipGetLastError());
-        k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, d_misc);
+        k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, h_misc);   // straight into the pinned host buffer: no copy queued
         RSREG_HIP(ctx, hipGetLastError());
     }
-    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
     *nfin = h_misc[6];
     for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(h_misc[k]); mx[k] = ordered_float(h_misc[3 + k]); }
@@ -251,7 +250,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
     k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, flags, scan, ctx->d_tgt_sorted.as<float4>(),
-                                            ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8);
+                                            ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
     RSREG_HIP(ctx, hipGetLastError());
@@ -262,8 +261,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, ctx->d_nbr.as<uint32_t>());
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
-    RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
+    RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in the pinned buffer)
     gp.n_cells = h_misc[8];
     gp.n_points = h_misc[10];
     gp.n_bricks = 0;
@@ -548,9 +546,8 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
-                                               ctx->d_uniq_of.as<uint32_t>(), d_misc + 12);
+                                               ctx->d_uniq_of.as<uint32_t>(), d_misc + 12, h_misc + 32);   // the number of distinct points: read at the join
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 32, d_misc + 12, 4, hipMemcpyDeviceToHost, st));   // the number of distinct points: read at the join
         k_source_weights<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), ctx->d_first.as<uint32_t>(), d_misc + 12,
                                                 ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());

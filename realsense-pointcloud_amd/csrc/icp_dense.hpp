@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long 
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long long *keys, const uint32_t *vals, const char *pts,
                                                           size_t stride, uint32_t nfin, const unsigned long long *flags,
                                                           const unsigned long long *scan, float4 *sorted, uint32_t *pos_of,
-                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats)
+                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats, uint32_t *host_stats)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
@@ -113,6 +113,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         const uint32_t nu = pos + keep, nc = cid + cstart;
         stats[0] = nc;
         stats[2] = nu;
+        host_stats[0] = nc;   // (pinned host memory: what the host reads when the build has drained, no copy queued)
+        host_stats[2] = nu;
         cellpos[nc] = nu;   // sentinel
         // far-away points behind the last sorted point: a 4-wide candidate read may run past it
         for (uint32_t k = 0; k < 4; ++k) sorted[nu + k] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_source_flag(const unsigned long long
 // pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id
 __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all, uint32_t n, const uint32_t *keep,
                                                           const uint32_t *pos, uint32_t *first, uint32_t *uniq_of,
-                                                          uint32_t *count)
+                                                          uint32_t *count, uint32_t *host_count)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all,
     if (keep[j]) first[u] = j;
     if (j == n - 1) {
         count[0] = u + 1;
+        host_count[0] = u + 1;   // (pinned host memory: read at the join, no copy queued)
         first[u + 1] = n;
     }
 }

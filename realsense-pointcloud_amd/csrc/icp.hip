@@ -126,9 +126,6 @@ double cell_cap_from_env()
 int device_bbox_on(rsreg_ctx *ctx, hipStream_t st, uint32_t *d_misc, uint32_t *h_misc, uint32_t *partial, const char *d_pts, size_t n,
                    size_t stride, float mn[3], float mx[3], uint32_t *nfin)
 {
-    const size_t misc_bytes = 16 * sizeof(uint32_t);
-    // words 7..15 (counters of the builds that follow) start at zero; k_bbox_final writes words 0..6 itself
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0, misc_bytes, st));
     if (n == 0) {   // no kernel runs: the empty box
         for (int k = 0; k < 3; ++k) { mn[k] = ordered_float(0xffffffffu); mx[k] = ordered_float(0u); }
         *nfin = 0;
@@ -138,7 +135,7 @@ int device_bbox_on(rsreg_ctx *ctx, hipStream_t st, uint32_t *d_misc, uint32_t *h
         const uint32_t nb = std::min<uint32_t>(div_up((uint32_t)n, kBlock), 1024);
         k_bbox<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, partial);
         RSREG_HIP(ctx, hipGetLastError());
-        k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, h_misc);   // straight into the pinned host buffer: no copy queued
+        k_bbox_final<<<1, kBlock, 0, st>>>(partial, nb, h_misc, d_misc);   // the box straight into the pinned host buffer (no copy queued); clears the counters
         RSREG_HIP(ctx, hipGetLastError());
     }
     RSREG_HIP(ctx, hipStreamSynchronize(st));
@@ -1233,11 +1230,10 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     ctx->ev_reduce.clear();
     ctx->ev_transform.clear();
     const uint32_t n = (uint32_t)ctx->n_work;
-    if (n) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_seed.ptr, 0xff, (size_t)n * 4, ctx->stream));  // no seeds yet
     if (n) {
         const int apply = s.final_t.is_identity() ? 0 : 1;
         k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t),
-                                                                        apply, ctx->d_cur.as<float4>());
+                                                                        apply, ctx->d_cur.as<float4>(), ctx->d_seed.as<int>());   // (and: no seeds yet)
         RSREG_HIP(ctx, hipGetLastError());
     }
     return RSREG_OK;

@@ -176,8 +176,10 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const char *pts, size_t stride,
 }
 
 // one block: combine the per-block partials of k_bbox into bbox[0..6]
-__global__ __launch_bounds__(kBlock) void k_bbox_final(const uint32_t *partial, uint32_t nblocks, uint32_t *bbox)
+// (and clears the 16 device-side counter words the builds that follow use)
+__global__ __launch_bounds__(kBlock) void k_bbox_final(const uint32_t *partial, uint32_t nblocks, uint32_t *bbox, uint32_t *counters)
 {
+    if (threadIdx.x < 16) counters[threadIdx.x] = 0u;
     uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0, 0, 0}, cnt = 0;
     for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
         const uint32_t *p = partial + (size_t)b * 8;
@@ -401,11 +403,13 @@ __global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all
     cur[u] = s;
 }
 
+// cur = guess * src (or src); also: no seeds yet
 __global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, uint32_t n, Mat34 guess, int apply_guess,
-                                                           float4 *cur)
+                                                           float4 *cur, int *seed)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    seed[i] = -1;
     float4 s = src[i];
     if (s.w != 0.0f && apply_guess) {
         const float3 t = xform(guess, s.x, s.y, s.z);

@@ -178,7 +178,7 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.pts = ctx->d_tgt_sorted.as<float4>();
     g.n_pts = p.n_points;
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
-    g.nbr = ctx->d_nbr.as<uint32_t>();
+    g.nbr = ctx->d_dense.as<uint32_t>() + g.table_bytes / 4;   // the occupancy words lie right behind the table (one memset clears both)
     g.pos_of = ctx->d_pos_of.as<uint32_t>();
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
@@ -218,8 +218,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_cellpos.reserve(((size_t)nfin + 2) * 4));
     RSREG_HIP(ctx, ctx->d_brick.reserve(((size_t)nfin + 2) * 4));
-    RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4));
-    RSREG_HIP(ctx, ctx->d_nbr.reserve((total + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4 * 2));   // cell starts, then the neighbourhood occupancy words
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_pos_of.reserve((n + 1) * 4));
     const DenseDev g = dense_dev(ctx, max_dist);
@@ -230,7 +229,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     auto *flags = ctx->d_flags.as<unsigned long long>(), *scan = ctx->d_scan.as<unsigned long long>();   // keep | cstart << 32 and its scan
     uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
     uint32_t *table = ctx->d_dense.as<uint32_t>();
-    RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4, st));
+    RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));   // (the table and the occupancy words behind it)
     k_dense_keys<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
     int id_bits = 1;
@@ -254,8 +253,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     // counts -> first sorted point of every cell (in place), entry [total] = number of points
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
-    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_nbr.ptr, 0, (total + 2) * 4, st));
-    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, ctx->d_nbr.as<uint32_t>());
+    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, table + (total + 2));
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
     RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in the pinned buffer)
@@ -1094,7 +1092,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ctx->recip = nullptr;
     }
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_nbr, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,

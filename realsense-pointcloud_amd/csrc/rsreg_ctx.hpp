@@ -119,8 +119,7 @@ struct rsreg_ctx {
     rsreg::DevBuf d_tgt_sorted;   // float4 {x,y,z,bits(orig index)}, cell-sorted, de-duplicated
     rsreg::DevBuf d_table;        // BrickEntry[table_mask+1]
     rsreg::DevBuf d_cellpos;      // uint32[n_cells+1]: first sorted point of each occupied cell
-    rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell
-    rsreg::DevBuf d_nbr;          // dense mode: uint32 per cell, occupancy of its 27-cell neighbourhood
+    rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell, followed by one uint32 per cell: occupancy of its 27-cell neighbourhood
     rsreg::DevBuf d_pos_of;       // dense mode: uint32 per target record, its position in d_tgt_sorted
     rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items (4 per tile) | wave costs | done counters | sort scratch
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;

@@ -535,9 +535,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
         RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
-        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr);
-        RSREG_HIP(ctx, hipGetLastError());
-        k_source_flag<<<nb, kBlock, 0, st>>>(keys2, ctx->d_src_all.as<float4>(), (uint32_t)n, keep);
+        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),

@@ -345,8 +345,11 @@ __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t 
 }
 
 // src[j] = {xyz of original point perm[j], valid}; cur = copy
+// keys + keep (both or neither): also flags the sorted point j that is not an exact copy of its predecessor (same Morton
+// key, same xyz; invalid points are never merged: they carry weight 0 anyway), from the predecessor's own record
 __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_t stride, uint32_t n, const uint32_t *perm,
-                                                          float4 *src, float4 *cur)
+                                                          float4 *src, float4 *cur, const unsigned long long *keys = nullptr,
+                                                          uint32_t *keep = nullptr)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -355,21 +358,14 @@ __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_
     const float4 s = make_float4(x, y, z, finite3(x, y, z) ? 1.0f : 0.0f);
     src[j] = s;
     if (cur) cur[j] = s;
-}
-
-// keep[j]: sorted source point j is not an exact copy of its predecessor (same Morton key, same
-// xyz).  Invalid points are never merged (they carry weight 0 anyway).
-__global__ __launch_bounds__(kBlock) void k_source_flag(const unsigned long long *keys, const float4 *src_all, uint32_t n,
-                                                        uint32_t *keep)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    uint32_t kp = 1;
-    if (j > 0 && keys[j] == keys[j - 1]) {
-        const float4 a = src_all[j], b = src_all[j - 1];
-        if (a.w != 0.0f && b.w != 0.0f && a.x == b.x && a.y == b.y && a.z == b.z) kp = 0;
+    if (keep) {
+        uint32_t kp = 1;
+        if (j > 0 && keys[j] == keys[j - 1]) {
+            const float *b = rec_xyz(raw, stride, perm ? perm[j - 1] : j - 1);
+            if (s.w != 0.0f && finite3(b[0], b[1], b[2]) && x == b[0] && y == b[1] && z == b[2]) kp = 0;
+        }
+        keep[j] = kp;
     }
-    keep[j] = kp;
 }
 
 // pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id

@@ -197,10 +197,11 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
     }
     k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
                                                            store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
-                                                           ctx->d_ndt_partials.as<double>(),
-                                                           // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue)
-                                                           ctx->comm ? ctx->d_ndt_out.as<double>() : ctx->h_ndt.as<double>(),
-                                                           reinterpret_cast<unsigned int *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc));   // (the final reduce rides along)
+                                                           ctx->d_ndt_partials.as<double>());
+    RSREG_HIP(ctx, hipGetLastError());
+    // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue behind the kernel)
+    k_ndt_final_reduce<<<1, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks,
+                                                         ctx->comm ? ctx->d_ndt_out.as<double>() : ctx->h_ndt.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
     if (ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
@@ -348,8 +349,7 @@ int load_ndt_source_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
 {
     RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8 + 64));
-    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_ndt_partials.as<char>() + (size_t)kPassBlocks * kNdtAcc * 8, 0, 64, ctx->stream));   // the pass kernel's ticket
+    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
     if (n) {
@@ -367,8 +367,7 @@ int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
-    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8 + 64));
-    RSREG_HIP(ctx, hipMemsetAsync(ctx->d_ndt_partials.as<char>() + (size_t)kPassBlocks * kNdtAcc * 8, 0, 64, ctx->stream));   // the pass kernel's ticket
+    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
     if (n) {

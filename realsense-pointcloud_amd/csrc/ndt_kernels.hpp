@@ -129,10 +129,8 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) { retu
 // voxels whose centroid is within the resolution (f32 L2_Simple, strict <), accumulate
 // score / gradient / Hessian in f64.  Voxel table chunks are staged through LDS.
 // partials[block][28]: 0 score, 1..6 gradient, 7..27 Hessian upper triangle (row-major i<=j)
-// The workgroup that finishes last adds the per-workgroup partials up (per sum: the 64 lanes of a wave stride over the workgroups, then a
-// shuffle tree -- the same operands in the same order whichever workgroup it is) and leaves the 28 sums in `out`; `ticket` goes back to 0.
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp,
-                                                        float *trans_out, double *partials, double *out, unsigned int *ticket)
+                                                        float *trans_out, double *partials)
 {
     __shared__ NdtVoxel sv[kNdtVoxChunk];
     __shared__ double sh[kNdtBlock / 64][kNdtAcc];
@@ -233,24 +231,16 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint3
     if (threadIdx.x < kNdtAcc) {
         double s = sh[0][threadIdx.x];
         for (int w = 1; w < kNdtBlock / 64; ++w) s += sh[w][threadIdx.x];
-        // device-wide visible at once (write-through), so that the last workgroup can read it inside this launch
-        __hip_atomic_store(&partials[(size_t)blockIdx.x * kNdtAcc + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        partials[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
     }
-    if (!ticket) return;
-    __shared__ unsigned int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have arrived before this workgroup is counted
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int before = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = before + 1u == gridDim.x;
-        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *partials, uint32_t nblocks, double *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = wave; k < kNdtAcc; k += kNdtBlock / 64) {
         double v = 0.0;
-        for (uint32_t b = lane; b < gridDim.x; b += 64)
-            v += __hip_atomic_load(&partials[(size_t)b * kNdtAcc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t b = lane; b < nblocks; b += 64) v += partials[(size_t)b * kNdtAcc + k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if (lane == 0) out[k] = v;
     }

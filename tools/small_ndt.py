@@ -31,4 +31,4 @@ for k in range(reps + 5):
     if k >= 5:
         times.append(time.perf_counter() - t)
 r = ndt.result
-print("NDT align, %d -> %d points: median %.3f ms; iterations %d, passes %d" % (len(sb), len(ta), np.median(times) * 1e3, r.iterations, getattr(r, "n_passes", -1)))
+print("NDT align, %d -> %d points: median %.3f ms; iterations %d, passes %d, voxels %d" % (len(sb), len(ta), np.median(times) * 1e3, r.iterations, r.n_derivative_passes, r.n_voxels))

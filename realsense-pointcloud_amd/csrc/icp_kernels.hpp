@@ -693,45 +693,6 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// one step of the recursive-halving reduction (tile_reduce_store): the lane holds the sums
-// [base, base + cnt) in v[0..N); it keeps the lower or the upper half according to its bit
-// `mask` and adds its partner's copy of that half
-// gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd 16-lane rows) of one register with the
-// lower half (the even rows) of another: exactly the "keep one half of the sums, hand the other half to the partner"
-// of a halving step across lane bit 5 / bit 4.  After the swap a = {own lower-half sum in the lanes that keep it | the
-// partner's upper-half sum} and b the other two, so a + b is the step's result in every lane -- the same two operands
-// as `mine + partner's`, without the selects and the cross-lane shuffle.
-template <int kMask>
-__device__ __forceinline__ void swap_lane_halves(double &a, double &b)
-{
-    const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
-    const uint32_t al = (uint32_t)ua, ah = (uint32_t)(ua >> 32), bl = (uint32_t)ub, bh = (uint32_t)(ub >> 32);
-    const auto r0 = kMask == 32 ? __builtin_amdgcn_permlane32_swap(al, bl, false, false) : __builtin_amdgcn_permlane16_swap(al, bl, false, false);
-    const auto r1 = kMask == 32 ? __builtin_amdgcn_permlane32_swap(ah, bh, false, false) : __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
-    a = __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
-    b = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
-}
-
-template <int N>
-__device__ __forceinline__ void halve_sums(const double (&v)[N], double (&out)[(N + 1) / 2], int lane, int mask, int &base, int &cnt)
-{
-    constexpr int H = (N + 1) / 2;
-    const bool up = (lane & mask) != 0;
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-        double lo = v[j], hi = (H + j < N) ? v[H + j] : 0.0;
-        if (mask == 32 || mask == 16) {   // (compile-time after inlining: tile_reduce_store passes literals)
-            if (mask == 32) swap_lane_halves<32>(lo, hi); else swap_lane_halves<16>(lo, hi);
-            out[j] = lo + hi;   // = mine + the partner's (an IEEE sum does not depend on the order of its two operands)
-            continue;
-        }
-        const double mine = up ? hi : lo, send = up ? lo : hi;
-        out[j] = mine + __shfl_xor(send, mask);
-    }
-    base = up ? base + H : base;
-    cnt = up ? max(cnt - H, 0) : min(cnt, H);
-}
-
 // accumulate one accepted pair (p = source, q = target) into the 17 sums; w = how many
 // identical source points this one stands for (exact duplicates are searched once)
 __device__ __forceinline__ void accum_pair(double *a, float px, float py, float pz, float qx, float qy, float qz, float d2,

@@ -4,6 +4,7 @@
 // Device: voxel binning, per-voxel moments, the per-point derivative pass (ndt_kernels.hpp).
 // Host:   covariance regularisation + inversion per voxel (tens to hundreds of 3x3s), the
 //         Newton step (6x6 SVD solve) and the More-Thuente line search.
+#include <atomic>
 #include <cstring>
 #include <string.h>
 
@@ -21,7 +22,7 @@ extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int c
 
 namespace {
 
-constexpr int kPassBlocks = 256;  // fixed: the summation order does not depend on the GPU
+constexpr int kPassBlocks = 1024;  // fixed: the summation order does not depend on the GPU (4 workgroups per CU of an MI355X)
 constexpr int kMinPointsPerVoxel = 6;
 constexpr double kMinCovarEigMult = 0.01;
 
@@ -162,6 +163,19 @@ void angle_terms(const double *p, NdtPassParams &pp)
     set(pp.hang[14], -sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0);
 }
 
+constexpr int kNdtFlagSlot = 32;  // h_ndt: 28 sums, then the pass number the final reduce stamps
+
+// partial sums of a pass + the counter the final reduce counts its workgroups on (zero between passes)
+hipError_t reserve_partials(rsreg_ctx *ctx)
+{
+    const size_t tickets = 8;
+    const size_t bytes = (size_t)kPassBlocks * kNdtAcc * 8 + tickets;
+    if (ctx->d_ndt_partials.cap >= bytes) return hipSuccess;
+    hipError_t e = ctx->d_ndt_partials.reserve(bytes);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(static_cast<char *>(ctx->d_ndt_partials.ptr) + bytes - tickets, 0, tickets, ctx->stream);
+}
+
 struct NdtRun {
     rsreg_ctx *ctx;
     rsreg_ndt_params prm;
@@ -195,22 +209,36 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
         e1 = ctx->ev_ndt[1];
         (void)hipEventRecord(e0, ctx->stream);
     }
+    double *h = ctx->h_ndt.as<double>();
+    const bool watch = !ctx->comm && !ctx->profiling && !getenv("RSREG_NDT_NO_WATCH");
+    volatile uint64_t *flag = reinterpret_cast<volatile uint64_t *>(h + kNdtFlagSlot);
+    const uint64_t seq = ++ctx->ndt_seq;
+    *flag = 0;
     k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
                                                            store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
                                                            ctx->d_ndt_partials.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
     // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue behind the kernel)
-    k_ndt_final_reduce<<<1, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks,
-                                                         ctx->comm ? ctx->d_ndt_out.as<double>() : ctx->h_ndt.as<double>());
+    k_ndt_final_reduce<<<kNdtAcc, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks,
+                                                         ctx->comm ? ctx->d_ndt_out.as<double>() : h,
+                                                         reinterpret_cast<uint32_t *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc),
+                                                         watch ? const_cast<uint64_t *>(flag) : nullptr, seq);
     RSREG_HIP(ctx, hipGetLastError());
     if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
     if (ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
         int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_ndt_out.as<double>(), kNdtAcc);
         if (rc) return rc;
     }
-    double *h = ctx->h_ndt.as<double>();
     if (ctx->comm) RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_ndt_out.ptr, kNdtAcc * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (watch) {
+        // the pass number lands in pinned memory right behind the sums; a stream query now and then notices a fault
+        for (uint32_t spins = 1; *flag != seq; ++spins)
+            if ((spins & 0xFFFFu) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*flag != seq) RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) r.ms_derivatives += ms;
@@ -349,7 +377,7 @@ int load_ndt_source_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
 {
     RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
+    RSREG_HIP(ctx, reserve_partials(ctx));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
     if (n) {
@@ -367,7 +395,7 @@ int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_ndt_trans.reserve(n * 12 + 16));
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
-    RSREG_HIP(ctx, ctx->d_ndt_partials.reserve((size_t)kPassBlocks * kNdtAcc * 8));
+    RSREG_HIP(ctx, reserve_partials(ctx));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
     if (n) {

@@ -14,13 +14,14 @@
 #include <cfloat>
 #include <cstdint>
 
+#include "records.hpp"
 #include "rsreg_ctx.hpp"
 
 namespace rsreg {
 
 constexpr int kNdtBlock = 256;
 constexpr int kNdtAcc = 28;        // score + 6 gradient + 21 upper-triangle Hessian entries
-constexpr int kNdtVoxChunk = 256;  // voxels staged through LDS per pass over the table
+constexpr int kNdtVoxChunk = 64;   // voxels staged through LDS per pass over the table (8 KB: many workgroups per CU)
 constexpr int kNdtStatBlocks = 1;  // (per voxel) one block reduces one voxel's points
 
 struct NdtVoxel {        // 128 B, device voxel table entry
@@ -125,21 +126,108 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_voxel_stats(const uint32_t *v
 
 __device__ __forceinline__ double dot3d(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
+// f32 transform of a source record by the pose, PCL's operation order
+__device__ __forceinline__ void ndt_transform(const NdtPassParams &pp, const float4 &s4, float &tx, float &ty, float &tz)
+{
+    tx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[0], s4.x), __fmul_rn(pp.M[1], s4.y)), __fmul_rn(pp.M[2], s4.z)), pp.M[3]);
+    ty = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[4], s4.x), __fmul_rn(pp.M[5], s4.y)), __fmul_rn(pp.M[6], s4.z)), pp.M[7]);
+    tz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[8], s4.x), __fmul_rn(pp.M[9], s4.y)), __fmul_rn(pp.M[10], s4.z)), pp.M[11]);
+}
+
+// score / gradient / Hessian contribution of one (point, voxel) pair whose centroid passed the radius test
+__device__ __forceinline__ void ndt_pair(const NdtPassParams &pp, const float4 &s4, float tx, float ty, float tz,
+                                         const NdtVoxel &vx, double *acc)
+{
+    const double x[3] = {s4.x, s4.y, s4.z};
+    // point gradient columns 3..5 (columns 0..2 are the identity)
+    const double g13 = dot3d(x, pp.jang[0]), g23 = dot3d(x, pp.jang[1]);
+    const double g04 = dot3d(x, pp.jang[2]), g14 = dot3d(x, pp.jang[3]), g24 = dot3d(x, pp.jang[4]);
+    const double g05 = dot3d(x, pp.jang[5]), g15 = dot3d(x, pp.jang[6]), g25 = dot3d(x, pp.jang[7]);
+    const double J[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, g13, g23}, {g04, g14, g24}, {g05, g15, g25}};
+    const double xm[3] = {(double)tx - vx.mean[0], (double)ty - vx.mean[1], (double)tz - vx.mean[2]};
+    const double *ci = vx.icov;
+    const double cx[3] = {ci[0] * xm[0] + ci[1] * xm[1] + ci[2] * xm[2],
+                          ci[3] * xm[0] + ci[4] * xm[1] + ci[5] * xm[2],
+                          ci[6] * xm[0] + ci[7] * xm[1] + ci[8] * xm[2]};
+    double e = exp(-pp.d2 * dot3d(xm, cx) / 2);
+    const double score_inc = -pp.d1 * e;
+    e = pp.d2 * e;
+    if (e > 1 || e < 0 || e != e) return;
+    if (pp.mode != 2) acc[0] += score_inc;
+    e *= pp.d1;
+    double cg[6][3], xcg[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cg[a][r] = ci[r * 3] * J[a][0] + ci[r * 3 + 1] * J[a][1] + ci[r * 3 + 2] * J[a][2];
+        xcg[a] = dot3d(xm, cg[a]);
+        if (pp.mode != 2) acc[1 + a] += xcg[a] * e;
+    }
+    if (pp.mode == 1) return;
+    double ha[3], hb[3], hc[3], hd[3], he[3], hf[3];
+    ha[0] = 0; ha[1] = dot3d(x, pp.hang[0]); ha[2] = dot3d(x, pp.hang[1]);
+    hb[0] = 0; hb[1] = dot3d(x, pp.hang[2]); hb[2] = dot3d(x, pp.hang[3]);
+    hc[0] = 0; hc[1] = dot3d(x, pp.hang[4]); hc[2] = dot3d(x, pp.hang[5]);
+    hd[0] = dot3d(x, pp.hang[6]); hd[1] = dot3d(x, pp.hang[7]); hd[2] = dot3d(x, pp.hang[8]);
+    he[0] = dot3d(x, pp.hang[9]); he[1] = dot3d(x, pp.hang[10]); he[2] = dot3d(x, pp.hang[11]);
+    hf[0] = dot3d(x, pp.hang[12]); hf[1] = dot3d(x, pp.hang[13]); hf[2] = dot3d(x, pp.hang[14]);
+    int h = 7;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            // second derivative of the transformed point w.r.t. (p_a, p_b)
+            double xh = 0.0;
+            if (a >= 3) {
+                const double *hv = (a == 3) ? (b == 3 ? ha : (b == 4 ? hb : hc))
+                                 : (a == 4) ? (b == 4 ? hd : he)
+                                            : hf;
+                // x'^T Sigma^-1 h  (PCL: x_trans.dot(c_inv * block)); Sigma^-1 symmetric
+                const double ch[3] = {ci[0] * hv[0] + ci[1] * hv[1] + ci[2] * hv[2],
+                                      ci[3] * hv[0] + ci[4] * hv[1] + ci[5] * hv[2],
+                                      ci[6] * hv[0] + ci[7] * hv[1] + ci[8] * hv[2]};
+                xh = dot3d(xm, ch);
+            }
+            const double jc = J[b][0] * cg[a][0] + J[b][1] * cg[a][1] + J[b][2] * cg[a][2];
+            acc[h++] += e * (-pp.d2 * xcg[a] * xcg[b] + xh + jc);
+        }
+    }
+}
+
 // One derivative pass: transform each source point by the pose (f32, PCL op order), find the
 // voxels whose centroid is within the resolution (f32 L2_Simple, strict <), accumulate
 // score / gradient / Hessian in f64.  Voxel table chunks are staged through LDS.
 // partials[block][28]: 0 score, 1..6 gradient, 7..27 Hessian upper triangle (row-major i<=j)
+//
+// Work items are (point, voxel) pairs, point-major; each wave takes a contiguous quarter of its workgroup's items.  About
+// a third of the pairs pass the radius test, and a wave pays for the f64 derivative block whenever any of its lanes has
+// one: a wave first packs the passing pairs into a list in LDS (ballot + prefix count, item order kept) and runs the
+// block on 64 listed pairs at a time, every lane busy.  With one point per lane a pass took one point's walk over all
+// its voxels (7-14 us of dependent f64 work whether the cloud had 2 k or 36 k points); with pairs over four times as many
+// workgroups a lane holds one or two.  Which lane adds which pair depends on n, the pose and the table only, and the
+// sums are reduced in the fixed tree below.
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp,
                                                         float *trans_out, double *partials)
 {
     __shared__ NdtVoxel sv[kNdtVoxChunk];
     __shared__ double sh[kNdtBlock / 64][kNdtAcc];
+    __shared__ uint32_t pend[kNdtBlock / 64][128];
     double acc[kNdtAcc];
     for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
 
     const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
-    const uint32_t lo = blockIdx.x * per_block;
+    const uint32_t lo = min(n, blockIdx.x * per_block);
     const uint32_t hi = min(n, lo + per_block);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *list = pend[wave];
+
+    auto run = [&](uint32_t it, int cn, int c0) {
+        const uint32_t pi = it / (uint32_t)cn;
+        const float4 s4 = src[lo + pi];
+        float tx, ty, tz;
+        ndt_transform(pp, s4, tx, ty, tz);
+        ndt_pair(pp, s4, tx, ty, tz, sv[it - pi * (uint32_t)cn], acc);
+    };
 
     for (int c0 = 0; c0 < pp.n_vox; c0 += kNdtVoxChunk) {
         const int cn = min(kNdtVoxChunk, pp.n_vox - c0);
@@ -150,82 +238,58 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint3
             for (int k = threadIdx.x; k < cn * 16; k += blockDim.x) s[k] = g[k];
         }
         __syncthreads();
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            const float4 s4 = src[i];
-            if (s4.w == 0.0f) continue;
-            const float tx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[0], s4.x), __fmul_rn(pp.M[1], s4.y)), __fmul_rn(pp.M[2], s4.z)), pp.M[3]);
-            const float ty = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[4], s4.x), __fmul_rn(pp.M[5], s4.y)), __fmul_rn(pp.M[6], s4.z)), pp.M[7]);
-            const float tz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pp.M[8], s4.x), __fmul_rn(pp.M[9], s4.y)), __fmul_rn(pp.M[10], s4.z)), pp.M[11]);
-            if (trans_out && c0 == 0) { trans_out[3 * i] = tx; trans_out[3 * i + 1] = ty; trans_out[3 * i + 2] = tz; }
-            const double x[3] = {s4.x, s4.y, s4.z};
-            // point gradient columns 3..5 (columns 0..2 are the identity)
-            const double g13 = dot3d(x, pp.jang[0]), g23 = dot3d(x, pp.jang[1]);
-            const double g04 = dot3d(x, pp.jang[2]), g14 = dot3d(x, pp.jang[3]), g24 = dot3d(x, pp.jang[4]);
-            const double g05 = dot3d(x, pp.jang[5]), g15 = dot3d(x, pp.jang[6]), g25 = dot3d(x, pp.jang[7]);
-            const double J[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, g13, g23}, {g04, g14, g24}, {g05, g15, g25}};
-            double ha[3], hb[3], hc[3], hd[3], he[3], hf[3];
-            if (pp.mode != 1) {
-                ha[0] = 0; ha[1] = dot3d(x, pp.hang[0]); ha[2] = dot3d(x, pp.hang[1]);
-                hb[0] = 0; hb[1] = dot3d(x, pp.hang[2]); hb[2] = dot3d(x, pp.hang[3]);
-                hc[0] = 0; hc[1] = dot3d(x, pp.hang[4]); hc[2] = dot3d(x, pp.hang[5]);
-                hd[0] = dot3d(x, pp.hang[6]); hd[1] = dot3d(x, pp.hang[7]); hd[2] = dot3d(x, pp.hang[8]);
-                he[0] = dot3d(x, pp.hang[9]); he[1] = dot3d(x, pp.hang[10]); he[2] = dot3d(x, pp.hang[11]);
-                hf[0] = dot3d(x, pp.hang[12]); hf[1] = dot3d(x, pp.hang[13]); hf[2] = dot3d(x, pp.hang[14]);
-            }
-            for (int v = 0; v < cn; ++v) {
+        const uint32_t items = (hi - lo) * (uint32_t)cn;
+        const uint32_t per_wave = (items + kNdtBlock / 64 - 1) / (kNdtBlock / 64);
+        const uint32_t w_lo = min(items, (uint32_t)wave * per_wave), w_hi = min(items, w_lo + per_wave);
+        uint32_t held = 0;   // listed pairs not yet run (wave-uniform)
+        for (uint32_t it0 = w_lo; it0 < w_hi; it0 += 64) {
+            const uint32_t it = it0 + lane;
+            bool pass = false;
+            if (it < w_hi) {
+                const uint32_t pi = it / (uint32_t)cn;
+                const int v = (int)(it - pi * (uint32_t)cn);
+                const uint32_t i = lo + pi;
+                const float4 s4 = src[i];
+                float tx, ty, tz;
+                ndt_transform(pp, s4, tx, ty, tz);
+                if (trans_out && c0 == 0 && v == 0) { trans_out[3 * i] = tx; trans_out[3 * i + 1] = ty; trans_out[3 * i + 2] = tz; }
                 const NdtVoxel &vx = sv[v];
                 const float dx = __fsub_rn(tx, vx.centroid[0]), dy = __fsub_rn(ty, vx.centroid[1]), dz = __fsub_rn(tz, vx.centroid[2]);
                 const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                if (!(dd < pp.r2)) continue;
-                const double xm[3] = {(double)tx - vx.mean[0], (double)ty - vx.mean[1], (double)tz - vx.mean[2]};
-                const double *ci = vx.icov;
-                const double cx[3] = {ci[0] * xm[0] + ci[1] * xm[1] + ci[2] * xm[2],
-                                      ci[3] * xm[0] + ci[4] * xm[1] + ci[5] * xm[2],
-                                      ci[6] * xm[0] + ci[7] * xm[1] + ci[8] * xm[2]};
-                double e = exp(-pp.d2 * dot3d(xm, cx) / 2);
-                const double score_inc = -pp.d1 * e;
-                e = pp.d2 * e;
-                if (e > 1 || e < 0 || e != e) continue;
-                if (pp.mode != 2) acc[0] += score_inc;
-                e *= pp.d1;
-                double cg[6][3], xcg[6];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) cg[a][r] = ci[r * 3] * J[a][0] + ci[r * 3 + 1] * J[a][1] + ci[r * 3 + 2] * J[a][2];
-                    xcg[a] = dot3d(xm, cg[a]);
-                    if (pp.mode != 2) acc[1 + a] += xcg[a] * e;
-                }
-                if (pp.mode == 1) continue;
-                int h = 7;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                    for (int b = a; b < 6; ++b) {
-                        // second derivative of the transformed point w.r.t. (p_a, p_b)
-                        double xh = 0.0;
-                        if (a >= 3) {
-                            const double *hv = (a == 3) ? (b == 3 ? ha : (b == 4 ? hb : hc))
-                                             : (a == 4) ? (b == 4 ? hd : he)
-                                                        : hf;
-                            // x'^T Sigma^-1 h  (PCL: x_trans.dot(c_inv * block)); Sigma^-1 symmetric
-                            const double ch[3] = {ci[0] * hv[0] + ci[1] * hv[1] + ci[2] * hv[2],
-                                                  ci[3] * hv[0] + ci[4] * hv[1] + ci[5] * hv[2],
-                                                  ci[6] * hv[0] + ci[7] * hv[1] + ci[8] * hv[2]};
-                            xh = dot3d(xm, ch);
-                        }
-                        const double jc = J[b][0] * cg[a][0] + J[b][1] * cg[a][1] + J[b][2] * cg[a][2];
-                        acc[h++] += e * (-pp.d2 * xcg[a] * xcg[b] + xh + jc);
-                    }
-                }
+                pass = s4.w != 0.0f && dd < pp.r2;
+            }
+            const uint64_t m = __ballot(pass);
+            if (pass) list[held + __popcll(m & ((1ull << lane) - 1ull))] = it;
+            held += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (held >= 64) {
+                run(list[lane], cn, c0);
+                const uint32_t moved = list[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                list[lane] = moved;
+                held -= 64;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
+        if ((uint32_t)lane < held) run(list[lane], cn, c0);
+        __builtin_amdgcn_wave_barrier();
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < kNdtAcc; ++k) {
-        double s = acc[k];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if (lane == 0) sh[wave][k] = s;
+    // 28 sums over the 64 lanes by recursive halving (records.hpp: halve_sums): at each of the six steps a lane keeps half
+    // of the sums it still holds and hands the other half to its partner, 14 + 7 + 4 + 2 + 1 + 1 = 29 doubles moved
+    // instead of 28 x 6 = 168 for 28 separate shuffle trees -- which were most of what a pass took (24 us whether the
+    // cloud had 2 k or 36 k points).  The tree is fixed: the result depends on n and the voxel table only.
+    {
+        int base = 0, cnt = kNdtAcc;
+        double v14[14], v7[7], v4[4], v2[2], v1[1], v0[1];
+        rsreg::halve_sums<kNdtAcc>(acc, v14, lane, 32, base, cnt);
+        rsreg::halve_sums<14>(v14, v7, lane, 16, base, cnt);
+        rsreg::halve_sums<7>(v7, v4, lane, 8, base, cnt);
+        rsreg::halve_sums<4>(v4, v2, lane, 4, base, cnt);
+        rsreg::halve_sums<2>(v2, v1, lane, 2, base, cnt);
+        rsreg::halve_sums<1>(v1, v0, lane, 1, base, cnt);
+        if (cnt >= 1) sh[wave][base] = v0[0];   // exactly one lane ends up owning each of the 28 sums
     }
     __syncthreads();
     if (threadIdx.x < kNdtAcc) {
@@ -235,14 +299,33 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint3
     }
 }
 
-__global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *partials, uint32_t nblocks, double *out)
+// One workgroup per sum: fixed order (each thread its share of the partials in ascending order, shuffle tree, waves in
+// order).  With a flag (one GPU, sums written straight to pinned host memory) the workgroup that finishes last stamps the
+// pass number behind the sums, and the host watches for it instead of going through a stream synchronisation.
+// (Finishing the sums inside k_ndt_pass -- last workgroup, or last of each 32 and then the last group -- made a pass
+// longer, not shorter: every hand-over between workgroups is a trip to memory and back, profiles/r02_experiments.)
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *partials, uint32_t nblocks, double *out,
+                                                                uint32_t *ticket, uint64_t *flag, uint64_t seq)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < kNdtAcc; k += kNdtBlock / 64) {
-        double v = 0.0;
-        for (uint32_t b = lane; b < nblocks; b += 64) v += partials[(size_t)b * kNdtAcc + k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) out[k] = v;
+    __shared__ double shw[kNdtBlock / 64];
+    const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kNdtBlock) v += partials[(size_t)b * kNdtAcc + k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) shw[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = shw[0];
+        for (int w = 1; w < kNdtBlock / 64; ++w) t += shw[w];
+        out[k] = t;
+        if (flag) {
+            __threadfence_system();
+            if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+                *ticket = 0;
+                __threadfence_system();
+                __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 

@@ -166,6 +166,7 @@ struct rsreg_ctx {
     bool have_ndt_target = false;
     double ndt_resolution = 0;
     int ndt_n_voxels = 0;
+    uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;
     rsreg::DevBuf d_ndt_seg;      // first sorted point of every occupied leaf (NDT's own: d_cellpos belongs to the live ICP hash index)

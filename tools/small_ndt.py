@@ -18,6 +18,11 @@ vox = api.ApproximateVoxelGrid(api.default_context())
 vox.setLeafSize(0.01, 0.01, 0.01)
 vox.setInputCloud(api.DeviceCloud(ea)); ta = vox.filter()
 vox.setInputCloud(api.DeviceCloud(eb)); sb = vox.filter()
+sub = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if sub > 1:
+    h = sb.download()
+    pts = np.ascontiguousarray(h.points[::sub])
+    sb = api.DeviceCloud(rsreg_amd.PointCloud(pts, width=len(pts), height=1, is_dense=h.is_dense))
 ndt = schemes.HipBackend().ndt()
 guess = schemes.rot_y(-np.deg2rad(0.15))
 times = []

@@ -144,7 +144,8 @@ template <int N> RSREG_HD inline void jacobi_svd(const double *A, SvdResult<N> &
 
 // jacobi_svd<3> written so that every array index is a compile-time constant (the loops over
 // p, q, k unroll; orderings go through pick3): on the device all of it then lives in registers.
-// Same operations in the same order as the generic template above.
+// Same operations in the same order as the generic template above, except that a column of U is scaled by the
+// reciprocal of its norm (one division per column instead of three).
 RSREG_HD inline double pick3(double a0, double a1, double a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
 
 // `v0` (optional): an orthogonal matrix to start from, e.g. the V of a nearby matrix (the
@@ -221,8 +222,9 @@ RSREG_HD inline void jacobi_svd3(const double *A, SvdResult<3> &out, const doubl
 #pragma unroll
         for (int i = 0; i < N; ++i) out.V[i * N + k] = pick3(V[i * N], V[i * N + 1], V[i * N + 2], j);
         if (nj > 0 && nj > 1e-13 * smax) {
+            const double inv = 1.0 / nj;
 #pragma unroll
-            for (int i = 0; i < N; ++i) out.U[i * N + k] = pick3(W[i * N], W[i * N + 1], W[i * N + 2], j) / nj;
+            for (int i = 0; i < N; ++i) out.U[i * N + k] = pick3(W[i * N], W[i * N + 1], W[i * N + 2], j) * inv;
             rank = k + 1;
         } else {
 #pragma unroll
@@ -299,9 +301,12 @@ RSREG_HD inline bool umeyama_from_sums(const double *sums, Mat4f &T, double *v_w
     const double n = sums[0];
     if (!(n >= 1.0)) return false;
     double mu_p[3], mu_q[3], sigma[9];
-    for (int i = 0; i < 3; ++i) { mu_p[i] = sums[1 + i] / n; mu_q[i] = sums[4 + i] / n; }
+    // one division, fifteen products: on the device this runs on a single lane between two search kernels, where an
+    // f64 division is a chain of a dozen dependent instructions (host and device share this source: same bits)
+    const double inv_n = 1.0 / n;
+    for (int i = 0; i < 3; ++i) { mu_p[i] = sums[1 + i] * inv_n; mu_q[i] = sums[4 + i] * inv_n; }
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = sums[7 + i * 3 + j] / n - mu_q[i] * mu_p[j];
+        for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = sums[7 + i * 3 + j] * inv_n - mu_q[i] * mu_p[j];
     SvdResult<3> r;
     jacobi_svd3(sigma, r, v_warm);
     if (v_warm) {

@@ -762,14 +762,31 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const i
     tile_reduce_store(a, partials, gridDim.x);
 }
 
+// A thread's share of `count` partials (every kBlock-th, ascending), added in that order.  The loads go out sixteen at a
+// time before the first is used: one after the other, each waiting for the last (what the plain loop compiles to),
+// thirty trips to memory in a row were 10 of the 14 us between two search kernels.
+__device__ __forceinline__ double strided_sum(const double *src, uint32_t count)
+{
+    constexpr int kInFlight = 16;
+    double v = 0.0;
+    for (uint32_t b = threadIdx.x; b < count; b += kBlock * kInFlight) {
+        double x[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) x[j] = b + j * kBlock < count ? src[b + j * kBlock] : 0.0;
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j)
+            if (b + j * kBlock < count) v += x[j];
+    }
+    return v;
+}
+
 // 17 blocks of 256 threads: block k adds sum k over all slabs, fixed order
 __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials, uint32_t nblocks, double *sums)
 {
     __shared__ double shf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *src = partials + (size_t)blockIdx.x * nblocks;
-    double v = 0.0;
-    for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) v += src[b];
+    double v = strided_sum(src, nblocks);
     v = wave_sum(v);
     if (lane == 0) shf[wave] = v;
     __syncthreads();
@@ -856,18 +873,18 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
     __shared__ double shf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *src = partials + (size_t)blockIdx.x * nblocks;
-    double v = 0.0;
-    for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) v += src[b];
+    double v = strided_sum(src, nblocks);
     v = wave_sum(v);
     if (lane == 0) shf[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = shf[0];
         for (int w = 1; w < kBlock / 64; ++w) t += shf[w];
+        // written through (agent-scope store), acknowledged, then counted: no fence, which would write back and
+        // invalidate this XCD's L2
         __hip_atomic_store(&sums[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
             double all[RSREG_NUM_SUMS];
             for (int k = 0; k < RSREG_NUM_SUMS; ++k) all[k] = __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *ticket = 0;

@@ -310,7 +310,14 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *pa
     __shared__ double shw[kNdtBlock / 64];
     const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double v = 0.0;
-    for (uint32_t b = threadIdx.x; b < nblocks; b += kNdtBlock) v += partials[(size_t)b * kNdtAcc + k];
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kNdtBlock * 4) {   // four loads in flight, added in order
+        double x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = b + j * kNdtBlock < nblocks ? partials[(size_t)(b + j * kNdtBlock) * kNdtAcc + k] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (b + j * kNdtBlock < nblocks) v += x[j];
+    }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) shw[wave] = v;
     __syncthreads();

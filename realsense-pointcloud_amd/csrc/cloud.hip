@@ -48,6 +48,56 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
     if (set_w && stride >= 16) dst[3] = __float_as_uint(1.0f);
 }
 
+// A dropped cloud's buffer goes to the context's pool and the next cloud takes it from there (rsreg_ctx.hpp, CloudPool):
+// the frame loops create and drop half a dozen clouds per frame, and every hipFree is a device-wide synchronisation
+// (0.16 ms).  Every kernel and copy that touches a cloud runs on ctx->stream, so a buffer handed on is written only
+// after the work queued on its previous owner; the one other reader is a source load on ctx->stream_src, which the main
+// stream is made to wait for before a buffer changes hands.
+void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
+{
+    if (!b.ptr) return;
+    CloudPool &pool = ctx->cloud_pool;
+    if (b.cap <= pool.limit && pool.held + b.cap <= pool.limit) {
+        if (ctx->src_pending) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_src_done, 0);
+        pool.slots.push_back({b.ptr, b.cap});
+        pool.held += b.cap;
+        b.ptr = nullptr;
+        b.cap = 0;
+        return;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    b.release();
+}
+
+// like DevBuf::reserve (the contents are not kept), through the pool: the smallest kept buffer that is large enough
+// and not more than twice too large
+hipError_t cloud_reserve(rsreg_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return hipSuccess;
+    cloud_drop(ctx, b);
+    CloudPool &pool = ctx->cloud_pool;
+    size_t best = pool.slots.size();
+    for (size_t i = 0; i < pool.slots.size(); ++i)
+        if (pool.slots[i].cap >= bytes && pool.slots[i].cap <= 2 * bytes + (1u << 20) &&
+            (best == pool.slots.size() || pool.slots[i].cap < pool.slots[best].cap))
+            best = i;
+    if (best != pool.slots.size()) {
+        b.ptr = pool.slots[best].ptr;
+        b.cap = pool.slots[best].cap;
+        pool.held -= b.cap;
+        pool.slots[best] = pool.slots.back();
+        pool.slots.pop_back();
+        return hipSuccess;
+    }
+    hipError_t e = b.reserve(bytes);
+    if (e != hipSuccess && !pool.slots.empty()) {   // out of memory with buffers kept aside: give them back and try once more
+        (void)hipGetLastError();
+        rsreg::cloud_pool_clear(ctx);
+        e = b.reserve(bytes);
+    }
+    return e;
+}
+
 int check_pair(const rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b)
 {
     if (!ctx || !a || !b || a->ctx != ctx || b->ctx != ctx) return RSREG_ERR_INVALID_ARG;
@@ -55,6 +105,18 @@ int check_pair(const rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b)
 }
 
 }  // namespace
+
+namespace rsreg {
+void cloud_pool_clear(rsreg_ctx *ctx)
+{
+    CloudPool &pool = ctx->cloud_pool;
+    if (pool.slots.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (const CloudPool::Slot &sl : pool.slots) (void)hipFree(sl.ptr);
+    pool.slots.clear();
+    pool.held = 0;
+}
+}  // namespace rsreg
 
 extern "C" {
 
@@ -72,8 +134,7 @@ int rsreg_cloud_destroy(rsreg_cloud *c)
 {
     if (!c) return RSREG_OK;
     (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    c->buf.release();
+    cloud_drop(c->ctx, c->buf);
     delete c;
     return RSREG_OK;
 }
@@ -83,7 +144,7 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
     if (!c || (n && !points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
     rsreg_ctx *ctx = c->ctx;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    RSREG_HIP(ctx, c->buf.reserve(n * stride + 16));
+    RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) {
         // through pinned staging, copied by a few threads (a pageable hipMemcpy of tens of MB is several times slower)
         RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
@@ -135,7 +196,7 @@ const void *rsreg_cloud_device_ptr(const rsreg_cloud *c) { return c ? c->buf.ptr
 int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
 {
     rsreg_ctx *ctx = c->ctx;
-    RSREG_HIP(ctx, c->buf.reserve(n * stride + 16));
+    RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, buf->ptr, n * stride, hipMemcpyDeviceToDevice, ctx->stream));
     c->n = n; c->stride = stride; c->width = width; c->height = height; c->is_dense = is_dense;
     return RSREG_OK;
@@ -147,7 +208,7 @@ int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
     if (rc) return rc;
     if (in == out) return RSREG_OK;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    RSREG_HIP(ctx, out->buf.reserve(in->n * in->stride + 16));
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, in->n * in->stride + 16));
     if (in->n) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, in->buf.ptr, in->n * in->stride, hipMemcpyDeviceToDevice, ctx->stream));
     out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
     return RSREG_OK;
@@ -165,7 +226,7 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
     const size_t stride = in->stride;
     rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr);
     if (rc) return rc;
-    RSREG_HIP(ctx, out->buf.reserve((size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
     if (nr) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream));
     out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
     return RSREG_OK;
@@ -177,7 +238,7 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
     int rc = check_pair(ctx, in, out);
     if (rc || !transform) return rc ? rc : RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    if (in != out) RSREG_HIP(ctx, out->buf.reserve(in->n * in->stride + 16));
+    if (in != out) RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, in->n * in->stride + 16));
     Mat4f T;
     std::memcpy(T.m, transform, 64);
     if (in->n) {
@@ -203,11 +264,10 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
         if (nb) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.as<char>() + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         DevBuf fresh;
-        RSREG_HIP(ctx, fresh.reserve(total * stride + (out == a ? total * stride / 2 : 0) + 16));   // a growing model: room for the next frames
+        RSREG_HIP(ctx, cloud_reserve(ctx, fresh, total * stride + (out == a ? total * stride / 2 : 0) + 16));   // a growing model: room for the next frames
         if (na) RSREG_HIP(ctx, hipMemcpyAsync(fresh.ptr, a->buf.ptr, na * stride, hipMemcpyDeviceToDevice, ctx->stream));
         if (nb) RSREG_HIP(ctx, hipMemcpyAsync(static_cast<char *>(fresh.ptr) + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
-        RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a or b may be `out`, whose old buffer goes away now
-        out->buf.release();
+        cloud_drop(ctx, out->buf);   // (a or b may be `out`: its old buffer is reused only by work queued after these copies)
         out->buf = fresh;
     }
     out->n = total; out->stride = stride; out->width = (uint32_t)total; out->height = 1; out->is_dense = dense;
@@ -239,7 +299,7 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
     int rc = rsreg_icp_align(ctx, guess, params, result, nullptr, 0);
     if (rc || !aligned_out) return rc;
     const rsreg_cloud *src = ctx->src_cloud;
-    if (aligned_out != src) RSREG_HIP(ctx, aligned_out->buf.reserve(src->n * src->stride + 16));
+    if (aligned_out != src) RSREG_HIP(ctx, cloud_reserve(ctx, aligned_out->buf, src->n * src->stride + 16));
     Mat4f T;
     std::memcpy(T.m, result->transform, 64);
     if (src->n) {
@@ -267,7 +327,7 @@ int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float
                           rsreg_ndt_result *result, rsreg_cloud *aligned_out)
 {
     if (!ctx || !source || source->ctx != ctx || !params || (aligned_out && aligned_out->ctx != ctx)) return RSREG_ERR_INVALID_ARG;
-    if (aligned_out && aligned_out != source) RSREG_HIP(ctx, aligned_out->buf.reserve(source->n * source->stride + 16));
+    if (aligned_out && aligned_out != source) RSREG_HIP(ctx, cloud_reserve(ctx, aligned_out->buf, source->n * source->stride + 16));
     int rc = rsreg_ndt_align_device(ctx, source->n ? source->buf.ptr : nullptr, source->n, source->stride, source->is_dense, guess, params,
                                     result, aligned_out ? aligned_out->buf.ptr : nullptr);
     if (rc || !aligned_out) return rc;

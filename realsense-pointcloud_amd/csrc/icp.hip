@@ -1103,6 +1103,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_ndt)
         if (e) (void)hipEventDestroy(e);
+    cloud_pool_clear(ctx);
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

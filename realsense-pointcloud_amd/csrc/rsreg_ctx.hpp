@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <string>
@@ -38,6 +39,21 @@ struct DevBuf {
         cap = 0;
     }
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+// Buffers of dropped device clouds, kept for the clouds to come (cloud.hip).  `limit`: bytes kept at most
+// (RSREG_CLOUD_POOL_MB, default 4096; 0 = every drop is a hipFree).
+struct CloudPool {
+    struct Slot {
+        void *ptr;
+        size_t cap;
+    };
+    std::vector<Slot> slots;
+    size_t held = 0;
+    size_t limit = [] {
+        const char *e = std::getenv("RSREG_CLOUD_POOL_MB");
+        return (size_t)(e ? std::max(0ll, std::atoll(e)) : 4096ll) << 20;
+    }();
 };
 
 struct PinnedBuf {
@@ -166,6 +182,7 @@ struct rsreg_ctx {
     bool have_ndt_target = false;
     double ndt_resolution = 0;
     int ndt_n_voxels = 0;
+    rsreg::CloudPool cloud_pool;
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;
@@ -188,6 +205,8 @@ struct rsreg_ctx {
 };
 
 namespace rsreg {
+
+void cloud_pool_clear(rsreg_ctx *ctx);   // cloud.hip: frees the buffers kept in ctx->cloud_pool
 
 inline int fail(rsreg_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {

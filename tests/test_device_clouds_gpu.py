@@ -107,3 +107,42 @@ def test_schemes_device_loop_equals_host_loop(api, rs, kind):
     _same_records(c0a, c0b)                 # what the scheme did to the caller's frame 0 is the same too
     if kind == "incremental":
         assert ma is c0a and mb is c0b      # the reference returns (and grows) the caller's frame 0
+
+
+def test_cloud_buffers_are_recycled_without_changing_results(api, rs, frames, monkeypatch):
+    """Dropped clouds hand their buffers to the context's pool (no hipFree per drop).  A frame loop that creates and
+    drops clouds of many sizes gives the same records with the pool (default), with a pool too small to keep anything,
+    and with the pool switched off."""
+    a, b = frames[0], frames[2]
+    T = rs.synth.small_transform(2.0, (0.01, 0.02, -0.01)).astype(np.float32)
+
+    def loop(ctx):
+        out = []
+        model = api.DeviceCloud(a, ctx)
+        v = api.ApproximateVoxelGrid(ctx)
+        v.setLeafSize(0.02, 0.02, 0.02)
+        for k in range(6):
+            f = api.DeviceCloud(b if k & 1 else a, ctx)
+            v.setInputCloud(f)
+            small = v.filter()                                  # a new, smaller cloud every round
+            moved = api.transformPointCloud(f, T, ctx)
+            moved = api.transformPointCloud(moved, T, ctx)      # the first `moved` is dropped: its buffer comes back below
+            model = small + model                               # the old model is dropped, a larger one takes over
+            model = model + moved
+            out.append(small.download())
+            del f, small, moved
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, max_correspondence_distance=0.05)
+        icp.setInputSource(api.DeviceCloud(b, ctx))             # (buffers that have been through the pool)
+        icp.setInputTarget(api.DeviceCloud(a, ctx))
+        icp.align()
+        out.append(model.download())
+        return out, icp.getFinalTransformation().tobytes()
+
+    ref, t_ref = loop(api.Context(0))
+    for mb in ("0", "1"):
+        monkeypatch.setenv("RSREG_CLOUD_POOL_MB", mb)
+        got, t = loop(api.Context(0))
+        assert t == t_ref
+        for x, y in zip(ref, got):
+            _same_records(x, y)

@@ -7,7 +7,10 @@
 // With cloud handles each of those steps takes and leaves its clouds in HBM: a frame is uploaded
 // once, the merged cloud is downloaded once, nothing else crosses PCIe (and no 32 -> 12 byte packing
 // on the host: the kernels read the 32-byte records as they are, through their stride).
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "records.hpp"
 
@@ -98,6 +101,26 @@ hipError_t cloud_reserve(rsreg_ctx *ctx, DevBuf &b, size_t bytes)
     return e;
 }
 
+// A download comes over PCIe in pieces, and a piece is copied out of the pinned staging buffer while the next ones are
+// still in flight (the merged cloud of 16 frames, 157 MB: 5.1 -> 4.0 ms).  f(p) handles piece p; pieces are dealt
+// round-robin to a few threads.
+constexpr size_t kPieceMin = (size_t)1 << 20, kPieceMax = (size_t)8 << 20;
+inline size_t piece_bytes(size_t bytes) { return std::min(kPieceMax, std::max(kPieceMin, bytes / 32)); }
+
+template <typename F> void parallel_pieces(size_t n_pieces, F f)
+{
+    static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::min<size_t>(hw, n_pieces);
+    std::vector<std::thread> th;
+    th.reserve(nt ? nt - 1 : 0);
+    for (unsigned t = 1; t < nt; ++t)
+        th.emplace_back([=] {
+            for (size_t p = t; p < n_pieces; p += nt) f(p);
+        });
+    for (size_t p = 0; p < n_pieces; p += std::max(1u, nt)) f(p);
+    for (auto &t : th) t.join();
+}
+
 int check_pair(const rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b)
 {
     if (!ctx || !a || !b || a->ctx != ctx || b->ctx != ctx) return RSREG_ERR_INVALID_ARG;
@@ -146,7 +169,8 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) {
-        // through pinned staging, copied by a few threads (a pageable hipMemcpy of tens of MB is several times slower)
+        // through pinned staging, copied by a few threads (a pageable hipMemcpy of tens of MB is several times slower).
+        // (Staging and PCIe copy in overlapping pieces gained nothing: 0.34 ms for a 9.8 MB frame is the link's rate.)
         RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
         char *stage = ctx->h_stage.as<char>();
         const char *src = static_cast<const char *>(points);
@@ -168,14 +192,32 @@ int rsreg_cloud_download(const rsreg_cloud *c, void *out, size_t capacity)
     rsreg_ctx *ctx = c->ctx;
     if (!c->n) return RSREG_OK;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = c->n * c->stride;
+    const size_t bytes = c->n * c->stride, piece = piece_bytes(bytes), n_pieces = (bytes + piece - 1) / piece;
     RSREG_HIP(ctx, ctx->h_stage.reserve(bytes));
-    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, c->buf.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const char *stage = ctx->h_stage.as<char>();
+    while (ctx->ev_copy.size() < n_pieces) {
+        hipEvent_t e = nullptr;
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_copy.push_back(e);
+    }
+    char *stage = ctx->h_stage.as<char>();
+    const char *src = c->buf.as<char>();
+    for (size_t p = 0; p < n_pieces; ++p) {   // all pieces queued; an event behind each
+        const size_t off = p * piece, len = std::min(piece, bytes - off);
+        RSREG_HIP(ctx, hipMemcpyAsync(stage + off, src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_copy[p], ctx->stream));
+    }
     char *dst = static_cast<char *>(out);
-    const size_t stride = c->stride;
-    host_parallel_for(c->n, [=](size_t lo, size_t hi) { std::memcpy(dst + lo * stride, stage + lo * stride, (hi - lo) * stride); });
+    std::atomic<int> err{(int)hipSuccess};
+    const int device = ctx->device;
+    hipEvent_t *ev = ctx->ev_copy.data();
+    parallel_pieces(n_pieces, [&, stage, dst, bytes, piece, device, ev](size_t p) {   // a piece is copied out while the next ones arrive
+        const size_t off = p * piece, len = std::min(piece, bytes - off);
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipEventSynchronize(ev[p]);
+        if (e != hipSuccess) { err.store((int)e); return; }
+        std::memcpy(dst + off, stage + off, len);
+    });
+    RSREG_HIP(ctx, (hipError_t)err.load());
     return RSREG_OK;
 }
 

@@ -1104,6 +1104,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     for (hipEvent_t e : ctx->ev_ndt)
         if (e) (void)hipEventDestroy(e);
     cloud_pool_clear(ctx);
+    for (hipEvent_t e : ctx->ev_copy) (void)hipEventDestroy(e);
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

@@ -183,6 +183,7 @@ struct rsreg_ctx {
     double ndt_resolution = 0;
     int ndt_n_voxels = 0;
     rsreg::CloudPool cloud_pool;
+    std::vector<hipEvent_t> ev_copy;   // one per piece of a cloud download in flight (cloud.hip)
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;

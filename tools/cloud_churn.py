@@ -40,3 +40,5 @@ print("upload 307k frame: %.3f ms, drop %.3f ms" % tuple(t(lambda: api.DeviceClo
 print("copy 307k cloud:   %.3f ms, drop %.3f ms" % tuple(t(lambda: small.copy())))
 print("copy 4.9M cloud:   %.3f ms, drop %.3f ms" % tuple(t(lambda: big.copy())))
 print("4.9M + 307k:       %.3f ms, drop %.3f ms" % tuple(t(lambda: big + small)))
+print("download 4.9M:     %.3f ms, drop %.3f ms" % tuple(t(lambda: big.download(), reps=8)))
+print("download 307k:     %.3f ms, drop %.3f ms" % tuple(t(lambda: small.download())))

@@ -97,6 +97,34 @@ def test_align_matches_oracle(api, orc, rs, edge_like, guess_kind):
         assert np.linalg.norm(n.getFinalTransformation() - gt) < np.linalg.norm(np.eye(4) - gt)
 
 
+@pytest.mark.parametrize("resolution", [0.3, 0.12])
+def test_many_voxels_several_table_chunks(api, orc, rs, edge_like, resolution):
+    """The derivative pass stages the voxel table through LDS 64 voxels at a time and deals (point, voxel) pairs to the
+    lanes chunk by chunk: a fine grid (hundreds to thousands of voxels, ragged last chunk) against the oracle, for the
+    three kinds of pass (score + gradient + Hessian in derivatives(), all of them inside align())."""
+    tgt, src = edge_like
+    n = _ndt(api, src, tgt, resolution=resolution)
+    o = orc.NdtOracle()
+    o.set_centroid_mode(1)
+    o.set_target(tgt.points, resolution)
+    po = orc.NdtParams.reference()
+    po.resolution = resolution
+    pose = np.array([0.01, -0.02, 0.015, 0.004, -0.006, 0.003])
+    score, grad, hess = n.derivatives(pose)
+    so, go, ho = o.derivatives(src.points, pose, po)
+    m, c = n.voxels()
+    assert len(c) > 2 * 64 and len(c) % 64 != 0, len(c)
+    assert abs(score - so) < 1e-10 * abs(so)
+    np.testing.assert_allclose(grad, go, rtol=1e-9, atol=1e-9 * np.abs(go).max())
+    np.testing.assert_allclose(hess, ho, rtol=1e-9, atol=1e-9 * np.abs(ho).max())
+    guess = rs.synth.small_transform(0.5, (0.0, 0.0, 0.0)).astype(np.float32)
+    n.align(guess)
+    ro = o.align(src.points, guess, po)
+    r = n.result
+    assert (r.converged, r.iterations, r.n_voxels, r.n_derivative_passes) == (ro.converged, ro.iterations, ro.n_voxels, ro.n_derivative_passes)
+    assert np.linalg.norm(n.getFinalTransformation() - ro.T) < 1e-5
+
+
 def test_ndt_then_icp_pair_like_the_reference_scheme(api, orc, rs, edge_like):
     """configs[2] shape: NDT on the subset gives the guess, ICP refines (ndt_edge...hpp:71-99)."""
     tgt, src = edge_like

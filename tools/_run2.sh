@@ -1,4 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2t
-python -m pytest tests/test_ndt_gpu.py -m gpu -x -q > gpurun_out/r2t/t.log 2>&1 || { tail -40 gpurun_out/r2t/t.log; exit 1; }
-tail -3 gpurun_out/r2t/t.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" || exit 1
+python bench.py > gpurun_out/r2t/bench_n1.json || exit 1
+cut -c1-300 gpurun_out/r2t/bench_n1.json

@@ -17,15 +17,21 @@
 // missing GPU makes the calls throw rsreg::Error (there is no CPU fallback).
 #pragma once
 
+#include <sys/mman.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <new>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../rsreg.h"
@@ -60,11 +66,67 @@ struct alignas(16) PointXYZRGB {
 };
 static_assert(sizeof(PointXYZRGB) == 32, "PointXYZRGB must stay byte-compatible with pcl::PointXYZRGB");
 
+// ---- storage of a cloud's points.  pcl::PointCloud keeps a std::vector with Eigen's aligned allocator; this one is
+// aligned too and can hand out records WITHOUT constructing them one by one, for the callers that overwrite every
+// record right away (a download of the merged cloud of 16 frames spent 25 ms of a 60 ms scheme constructing 4.9 M
+// points on one thread before the copy touched them).
+namespace detail {
+inline bool &skip_point_init()
+{
+    static thread_local bool skip = false;
+    return skip;
+}
+template <class T> struct point_allocator {
+    using value_type = T;
+    point_allocator() = default;
+    template <class U> point_allocator(const point_allocator<U> &) {}
+    // Large clouds sit on 2 MB pages where the kernel hands them out on request (what numpy does for its arrays): the
+    // first touch of a 157 MB merged cloud is 75 page faults instead of 38 000 (20 ms of a 54 ms scheme).
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T), huge = (size_t)2 << 20;
+        const bool large = bytes >= 2 * huge;
+        void *p = nullptr;
+        if (posix_memalign(&p, large ? huge : (alignof(T) > sizeof(void *) ? alignof(T) : sizeof(void *)), bytes ? bytes : 1) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+        if (large) (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) { std::free(p); }
+    template <class U> void construct(U *p)
+    {
+        if (!skip_point_init()) ::new (static_cast<void *>(p)) U();
+    }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const point_allocator<U> &) const { return true; }
+    template <class U> bool operator!=(const point_allocator<U> &) const { return false; }
+};
+}  // namespace detail
+
+template <typename PointT> using PointVector = std::vector<PointT, detail::point_allocator<PointT>>;
+
+// n records the caller is about to overwrite, all of them (their contents are unspecified until then)
+template <typename PointT> inline PointVector<PointT> uninitialized_points(size_t n)
+{
+    static_assert(std::is_trivially_copyable<PointT>::value && std::is_trivially_destructible<PointT>::value,
+                  "records that may stay unconstructed must be plain data");
+    struct Guard {
+        bool before = detail::skip_point_init();
+        Guard() { detail::skip_point_init() = true; }
+        ~Guard() { detail::skip_point_init() = before; }
+    } guard;
+    return PointVector<PointT>(n);
+}
+
 // ---- pcl::PointCloud<PointT>
 template <typename PointT> struct PointCloud {
     using Ptr = std::shared_ptr<PointCloud<PointT>>;
     using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
-    std::vector<PointT> points;
+    PointVector<PointT> points;
     uint32_t width = 0, height = 0;
     bool is_dense = true;
 
@@ -175,7 +237,7 @@ template <typename PointT> class DeviceCloud {
         int dense = 0;
         check(rsreg_cloud_info(h_, &n, &stride, &w, &h, &dense), ctx_->get());
         if (n && stride != sizeof(PointT)) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: record size of the device cloud differs");
-        std::vector<PointT> pts(n);
+        PointVector<PointT> pts = uninitialized_points<PointT>(n);
         check(rsreg_cloud_download(h_, pts.data(), n), ctx_->get());
         host.points = std::move(pts);
         host.width = w;
@@ -395,7 +457,7 @@ template <typename PointT> class ApproximateVoxelGrid {
     void filter(PointCloud<PointT> &output)  // output may be *input (the reference filters in place)
     {
         if (!input_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputCloud not called");
-        std::vector<PointT> out(input_->size());
+        PointVector<PointT> out = uninitialized_points<PointT>(input_->size());
         size_t n_out = 0;
         if (ctx_)
             check(rsreg_approx_voxel_grid_gpu(ctx_->get(), input_->points.data(), input_->size(), sizeof(PointT), leaf_, out.data(),
@@ -424,7 +486,7 @@ template <typename PointT>
 void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, const Matrix4f &T,
                          const std::shared_ptr<Context> &ctx = Context::Default())
 {
-    std::vector<PointT> pts(in.size());
+    PointVector<PointT> pts = uninitialized_points<PointT>(in.size());
     check(rsreg_transform_cloud(ctx->get(), in.points.data(), pts.data(), in.size(), sizeof(PointT), in.is_dense, T.data()),
           ctx->get());
     const uint32_t w = in.width, h = in.height;
@@ -446,7 +508,7 @@ inline std::shared_ptr<PointCloud<PointXYZRGB>> extract_edge_features(const std:
 {
     auto out = std::make_shared<PointCloud<PointXYZRGB>>();
     if ((size_t)cloud->width * cloud->height != cloud->size()) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: edge extraction needs an organized cloud");
-    std::vector<PointXYZRGB> pts(cloud->size());
+    PointVector<PointXYZRGB> pts = uninitialized_points<PointXYZRGB>(cloud->size());
     size_t n = 0;
     check(rsreg_extract_edge_features(ctx->get(), cloud->points.data(), cloud->width, cloud->height, sizeof(PointXYZRGB), pts.data(), nullptr, &n),
           ctx->get());

@@ -2,6 +2,7 @@
 // that the Python GPU tests can compare it with the ctypes path and the CPU checker.
 //   scheme_runner <incremental|icp_edge|ndt_edge|icp_pair|ndt_pair> <out_prefix> <a.pcd> <b.pcd> [...]
 // Writes <out_prefix>.pcd (merged / aligned cloud) and <out_prefix>.txt (4x4 transforms, row-major).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -31,6 +32,32 @@ int main(int argc, char **argv)
                 return 3;
             }
             clouds.push_back(c);
+        }
+        // RSREG_SCHEME_TIME=<reps>: the scheme is run <reps> times on fresh copies of the frames first and the wall time of
+        // every run goes to stderr (frames on the host in, merged cloud on the host out; the first run also pays for
+        // the context and the first allocations)
+        const int timed_reps = std::getenv("RSREG_SCHEME_TIME") ? std::atoi(std::getenv("RSREG_SCHEME_TIME")) : 0;
+        for (int rep = 0; rep < timed_reps; ++rep) {
+            std::vector<rgb_point_cloud_pointer> fresh;
+            for (auto &c : clouds) fresh.push_back(std::make_shared<rgb_point_cloud>(*c));
+            const bool host_loop_t = std::getenv("RSREG_SCHEME_HOST_LOOP") && std::getenv("RSREG_SCHEME_HOST_LOOP")[0] == '1';
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t merged = 0;
+            if (mode == "incremental") {
+                IncrementalICP s;
+                s.device_resident = !host_loop_t;
+                merged = s.registration(fresh)->size();
+            } else if (mode == "icp_edge") {
+                ICPEdgeBasedRegistration s(-0.0261799f);
+                s.device_resident = !host_loop_t;
+                merged = s.registration(fresh)->size();
+            } else if (mode == "ndt_edge") {
+                NDTEdgeBasedRegistration s(-0.0261799f);
+                s.device_resident = !host_loop_t;
+                merged = s.registration(fresh)->size();
+            }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "%s run %d: %.2f ms, %zu frames, merged %zu points\n", mode.c_str(), rep, ms, clouds.size(), merged);
         }
         FILE *f = std::fopen((prefix + ".txt").c_str(), "w");
         rgb_point_cloud_pointer out;

@@ -288,6 +288,12 @@ int rsreg_cloud_create(rsreg_ctx *ctx, rsreg_cloud **out);
 int rsreg_cloud_destroy(rsreg_cloud *cloud);
 int rsreg_cloud_upload(rsreg_cloud *cloud, const void *points, size_t n, size_t stride, uint32_t width,
                        uint32_t height, int is_dense);
+/* The same, returning as soon as the records are staged: the PCIe copy runs on a copy stream of the context beside the
+ * work of the main stream (a frame loop uploads frame k + 1 while frame k is being aligned: incremental_icp.hpp:51-66
+ * hands over all frames up front).  Every call that reads or rewrites the cloud waits for the copy first; `points` may
+ * be reused when the call returns. */
+int rsreg_cloud_upload_async(rsreg_cloud *cloud, const void *points, size_t n, size_t stride, uint32_t width,
+                             uint32_t height, int is_dense);
 int rsreg_cloud_download(const rsreg_cloud *cloud, void *out, size_t capacity_records);
 int rsreg_cloud_info(const rsreg_cloud *cloud, size_t *n, size_t *stride, uint32_t *width, uint32_t *height,
                      int *is_dense);

@@ -230,6 +230,12 @@ template <typename PointT> class DeviceCloud {
     {
         check(rsreg_cloud_upload(h_, host.points.data(), host.size(), sizeof(PointT), host.width, host.height, host.is_dense), ctx_->get());
     }
+    // upload() that returns once the records are staged: the PCIe copy runs beside the main stream's work, and whoever
+    // touches this cloud next waits for it (rsreg_cloud_upload_async).  `host` may change as soon as this returns.
+    void upload_async(const PointCloud<PointT> &host)
+    {
+        check(rsreg_cloud_upload_async(h_, host.points.data(), host.size(), sizeof(PointT), host.width, host.height, host.is_dense), ctx_->get());
+    }
     void download(PointCloud<PointT> &host) const
     {
         size_t n = 0, stride = 0;

@@ -95,9 +95,11 @@ class IncrementalICP : public RegistrationScheme {
         ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
-        rgb_device_cloud model(*clouds[0]), reduced, aligned, frame, moved;
+        rgb_device_cloud model(*clouds[0]), reduced, aligned, frames[2], moved;
+        if (clouds.size() > 1) frames[1].upload_async(*clouds[1]);
         for (size_t k = 1; k < clouds.size(); ++k) {
-            frame.upload(*clouds[k]);
+            rgb_device_cloud &frame = frames[k & 1];
+            if (k + 1 < clouds.size()) frames[(k + 1) & 1].upload_async(*clouds[k + 1]);   // on the link while frame k is aligned
             voxel.filter(frame, reduced);
             icp.setInputSource(reduced);
             icp.setInputTarget(model);
@@ -179,16 +181,18 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         ApproximateVoxelGrid<rgb_point> voxel;
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
-        rgb_device_cloud target, merged(pairs ? *(*pairs)[0].second : *(*frames)[0]), features, reduced, coarse_out, refined, full, moved;
+        rgb_device_cloud target, merged(pairs ? *(*pairs)[0].second : *(*frames)[0]), features, reduced, coarse_out, refined, fulls[2], moved;
         if (pairs) target.upload(*(*pairs)[0].first);
         else extract_edge_features(merged, target);
+        if (!pairs && n_frames > 1) fulls[1].upload_async(*(*frames)[1]);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
         float acc_rads = 0.f;
         frame_transforms.clear();
         for (size_t k = 1; k < n_frames; ++k) {
+            rgb_device_cloud &full = fulls[k & 1];
             if (pairs) features.upload(*(*pairs)[k].first);
             else {
-                full.upload(*(*frames)[k]);
+                if (k + 1 < n_frames) fulls[(k + 1) & 1].upload_async(*(*frames)[k + 1]);   // on the link while frame k is aligned
                 extract_edge_features(full, features);
             }
             voxel.filter(features, reduced);

@@ -133,6 +133,14 @@ class DeviceCloud:
                                              int(cloud.is_dense)), self.ctx.h)
         return self
 
+    def upload_async(self, cloud):
+        """upload() that returns once the records are staged: the PCIe copy runs beside the main stream's work and
+        whatever touches this cloud next waits for it (rsreg_cloud_upload_async)."""
+        pts = np.ascontiguousarray(cloud.points)
+        _l.check(_l.lib().rsreg_cloud_upload_async(self.h, pts.ctypes.data, len(pts), pts.dtype.itemsize, cloud.width, cloud.height,
+                                                   int(cloud.is_dense)), self.ctx.h)
+        return self
+
     def info(self):
         n, s = C.c_size_t(0), C.c_size_t(0)
         w, h, d = C.c_uint32(0), C.c_uint32(0), C.c_int(0)

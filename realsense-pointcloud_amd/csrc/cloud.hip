@@ -22,6 +22,9 @@ struct rsreg_cloud {
     size_t n = 0, stride = 32;
     uint32_t width = 0, height = 1;
     int is_dense = 0;
+    // rsreg_cloud_upload_async: the copy that fills this cloud may still be on the link
+    hipEvent_t ev_filled = nullptr;
+    mutable bool filling = false;
 };
 
 namespace rsreg {
@@ -56,6 +59,16 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
 // (0.16 ms).  Every kernel and copy that touches a cloud runs on ctx->stream, so a buffer handed on is written only
 // after the work queued on its previous owner; the one other reader is a source load on ctx->stream_src, which the main
 // stream is made to wait for before a buffer changes hands.
+// Whoever reads or rewrites a cloud first waits (on the host) for an upload of it that is still in flight: by then a
+// frame prefetched one step of the frame loop earlier has long arrived, and a host wait is right whatever stream the
+// reader works on.
+hipError_t settle(const rsreg_cloud *c)
+{
+    if (!c || !c->filling) return hipSuccess;
+    c->filling = false;
+    return hipEventSynchronize(c->ev_filled);
+}
+
 void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
 {
     if (!b.ptr) return;
@@ -157,6 +170,8 @@ int rsreg_cloud_destroy(rsreg_cloud *c)
 {
     if (!c) return RSREG_OK;
     (void)hipSetDevice(c->ctx->device);
+    (void)settle(c);
+    if (c->ev_filled) (void)hipEventDestroy(c->ev_filled);
     cloud_drop(c->ctx, c->buf);
     delete c;
     return RSREG_OK;
@@ -167,6 +182,7 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
     if (!c || (n && !points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
     rsreg_ctx *ctx = c->ctx;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(c));
     RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) {
         // through pinned staging, copied by a few threads (a pageable hipMemcpy of tens of MB is several times slower).
@@ -186,10 +202,56 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
     return RSREG_OK;
 }
 
+// rsreg_cloud_upload that returns as soon as the records are in a pinned staging buffer of their own: the PCIe copy
+// runs on the context's copy stream beside whatever the main stream is doing (the frame loops upload frame k + 1 while
+// frame k is being aligned).  Every entry point that reads or rewrites the cloud waits for the copy first (settle).
+int rsreg_cloud_upload_async(rsreg_cloud *c, const void *points, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
+{
+    if (!c || (n && !points) || stride < 12 || (stride & 3)) return RSREG_ERR_INVALID_ARG;
+    rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(c));
+    RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
+    if (n) {
+        if (!ctx->stream_copy) {
+            RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+            RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy_gate, hipEventDisableTiming));
+            for (hipEvent_t &e : ctx->ev_up) RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (!c->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&c->ev_filled, hipEventDisableTiming));
+        const int slot = ctx->up_next;
+        ctx->up_next ^= 1;
+        if (ctx->up_busy[slot]) {   // the copy that last used this staging buffer
+            RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_up[slot]));
+            ctx->up_busy[slot] = false;
+        }
+        RSREG_HIP(ctx, ctx->h_up[slot].reserve(n * stride));
+        char *stage = ctx->h_up[slot].as<char>();
+        const char *src = static_cast<const char *>(points);
+        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+        // the buffer may come from the pool: work queued on its previous owner (main stream) goes first
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_copy_gate, ctx->stream));
+        RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_copy_gate, 0));
+        if (ctx->src_pending) RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_src_done, 0));
+        RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, stage, n * stride, hipMemcpyHostToDevice, ctx->stream_copy));
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_up[slot], ctx->stream_copy));
+        RSREG_HIP(ctx, hipEventRecord(c->ev_filled, ctx->stream_copy));
+        ctx->up_busy[slot] = true;
+        c->filling = true;
+    }
+    c->n = n;
+    c->stride = stride;
+    c->width = width;
+    c->height = height;
+    c->is_dense = is_dense;
+    return RSREG_OK;
+}
+
 int rsreg_cloud_download(const rsreg_cloud *c, void *out, size_t capacity)
 {
     if (!c || (c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
     rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, settle(c));
     if (!c->n) return RSREG_OK;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = c->n * c->stride, piece = piece_bytes(bytes), n_pieces = (bytes + piece - 1) / piece;
@@ -232,12 +294,17 @@ int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *
     return RSREG_OK;
 }
 
-const void *rsreg_cloud_device_ptr(const rsreg_cloud *c) { return c ? c->buf.ptr : nullptr; }
+const void *rsreg_cloud_device_ptr(const rsreg_cloud *c)
+{
+    if (!c || settle(c) != hipSuccess) return nullptr;   // (the pointer may be used on any stream: an upload in flight is waited for)
+    return c->buf.ptr;
+}
 
 // (internal, edges.hip) the cloud takes a copy of the first n records of `buf`
 int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
 {
     rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, settle(c));
     RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, buf->ptr, n * stride, hipMemcpyDeviceToDevice, ctx->stream));
     c->n = n; c->stride = stride; c->width = width; c->height = height; c->is_dense = is_dense;
@@ -248,6 +315,8 @@ int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
 {
     int rc = check_pair(ctx, in, out);
     if (rc) return rc;
+    RSREG_HIP(ctx, settle(in));
+    RSREG_HIP(ctx, settle(out));
     if (in == out) return RSREG_OK;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, in->n * in->stride + 16));
@@ -264,6 +333,8 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
     if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
     if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(in));
+    RSREG_HIP(ctx, settle(out));
     uint32_t nr = 0;
     const size_t stride = in->stride;
     rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr);
@@ -280,6 +351,8 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
     int rc = check_pair(ctx, in, out);
     if (rc || !transform) return rc ? rc : RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(in));
+    RSREG_HIP(ctx, settle(out));
     if (in != out) RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, in->n * in->stride + 16));
     Mat4f T;
     std::memcpy(T.m, transform, 64);
@@ -300,6 +373,9 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     if (rc || !out || out->ctx != ctx) return rc ? rc : RSREG_ERR_INVALID_ARG;
     if (a->n && b->n && a->stride != b->stride) return fail(ctx, RSREG_ERR_INVALID_ARG, "record strides differ");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(a));
+    RSREG_HIP(ctx, settle(b));
+    RSREG_HIP(ctx, settle(out));
     const size_t stride = a->n ? a->stride : b->stride, na = a->n, nb = b->n, total = na + nb;
     const int dense = a->is_dense && b->is_dense;
     if (out == a && out->buf.cap >= total * stride + 16) {
@@ -320,12 +396,14 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
 int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_correspondence_distance)
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, settle(c));
     return rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
 }
 
 int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, settle(c));
     int rc = rsreg_icp_set_source_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense);
     if (rc) return rc;
     ctx->src_cloud = c;
@@ -338,6 +416,7 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
 {
     if (!ctx || !params || !result) return RSREG_ERR_INVALID_ARG;
     if (aligned_out && (aligned_out->ctx != ctx || !ctx->src_cloud)) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_set_source_cloud not called");
+    RSREG_HIP(ctx, settle(aligned_out));
     int rc = rsreg_icp_align(ctx, guess, params, result, nullptr, 0);
     if (rc || !aligned_out) return rc;
     const rsreg_cloud *src = ctx->src_cloud;
@@ -362,6 +441,7 @@ int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
 int rsreg_ndt_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double resolution)
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, settle(c));
     return rsreg_ndt_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, resolution);
 }
 
@@ -369,6 +449,8 @@ int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float
                           rsreg_ndt_result *result, rsreg_cloud *aligned_out)
 {
     if (!ctx || !source || source->ctx != ctx || !params || (aligned_out && aligned_out->ctx != ctx)) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, settle(source));
+    RSREG_HIP(ctx, settle(aligned_out));
     if (aligned_out && aligned_out != source) RSREG_HIP(ctx, cloud_reserve(ctx, aligned_out->buf, source->n * source->stride + 16));
     int rc = rsreg_ndt_align_device(ctx, source->n ? source->buf.ptr : nullptr, source->n, source->stride, source->is_dense, guess, params,
                                     result, aligned_out ? aligned_out->buf.ptr : nullptr);

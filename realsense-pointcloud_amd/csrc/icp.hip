@@ -1105,6 +1105,13 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     cloud_pool_clear(ctx);
     for (hipEvent_t e : ctx->ev_copy) (void)hipEventDestroy(e);
+    if (ctx->stream_copy) {
+        (void)hipStreamSynchronize(ctx->stream_copy);
+        (void)hipStreamDestroy(ctx->stream_copy);
+        (void)hipEventDestroy(ctx->ev_copy_gate);
+        for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
+    }
+    for (rsreg::PinnedBuf &b : ctx->h_up) b.release();
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

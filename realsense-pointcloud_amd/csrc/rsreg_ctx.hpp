@@ -184,6 +184,13 @@ struct rsreg_ctx {
     int ndt_n_voxels = 0;
     rsreg::CloudPool cloud_pool;
     std::vector<hipEvent_t> ev_copy;   // one per piece of a cloud download in flight (cloud.hip)
+    // rsreg_cloud_upload_async: a copy stream, two pinned staging buffers used in turn, the event behind the last copy
+    // out of each, and the event that lets the copy stream start only after what the main stream holds
+    hipStream_t stream_copy = nullptr;
+    hipEvent_t ev_copy_gate = nullptr, ev_up[2] = {nullptr, nullptr};
+    rsreg::PinnedBuf h_up[2];
+    bool up_busy[2] = {false, false};
+    int up_next = 0;
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;

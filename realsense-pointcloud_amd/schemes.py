@@ -79,6 +79,9 @@ class HipBackend:
     def upload(self, cloud):
         return cloud
 
+    def prefetch(self, cloud):
+        return cloud
+
     def download(self, cloud):
         return cloud
 
@@ -95,6 +98,12 @@ class HipDeviceBackend(HipBackend):
         if isinstance(cloud, self.api.DeviceCloud):   # (already there: the two-phase driver uploads a frame once)
             return cloud
         return self.api.DeviceCloud(cloud, self.ctx or self.api.default_context())
+
+    def prefetch(self, cloud):
+        """upload() whose PCIe copy runs beside the GPU's work on the frame before (one frame ahead in the frame loops)"""
+        if isinstance(cloud, self.api.DeviceCloud):
+            return cloud
+        return self.api.DeviceCloud(ctx=self.ctx or self.api.default_context()).upload_async(cloud)
 
     def download(self, cloud):
         return cloud.download()
@@ -126,9 +135,40 @@ class TwoPhaseRegistrationScheme(RegistrationScheme):
     def registration(self, clouds):
         # a frame goes to the GPU once: its features are extracted there and both stay there for the frame loop
         # (a plugged-in feature_fn is a host function: it gets, and returns, host clouds)
-        frames = clouds if self.feature_fn else [self.backend.upload(c) for c in clouds]
-        pairs = [(self.extract_features(f), f) for f in frames]
-        return self.global_registration(pairs)
+        if self.feature_fn:
+            return self.global_registration([(self.extract_features(f), f) for f in clouds])
+        return self.global_registration(_FramePairs(self, clouds))
+
+
+class _FramePairs:
+    """The (features, frame) pairs of types.hpp:30-43, made when the frame loop gets to them: frame k + 1 is on the
+    PCIe link while frame k is being aligned, and its features are extracted when it is first asked for."""
+
+    def __init__(self, scheme, clouds):
+        self.scheme, self.clouds = scheme, clouds
+        self.frames = {}
+        self.pairs = {}
+
+    def __len__(self):
+        return len(self.clouds)
+
+    def _frame(self, k):
+        if k not in self.frames:
+            self.frames[k] = self.scheme.backend.prefetch(self.clouds[k])
+        return self.frames[k]
+
+    def __getitem__(self, k):
+        if k < 0:
+            k += len(self.clouds)
+        if k not in self.pairs:
+            f = self._frame(k)
+            if k + 1 < len(self.clouds):
+                self._frame(k + 1)
+            self.pairs[k] = (self.scheme.extract_features(f), f)
+        return self.pairs[k]
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
 
 
 class IncrementalICP(RegistrationScheme):
@@ -136,19 +176,20 @@ class IncrementalICP(RegistrationScheme):
         b = self.backend
         voxel = b.voxel()                 # leaf never set -> PCL's 1 m default
         icp = b.icp()
-        frames = [b.upload(c) for c in clouds]
-        model = frames[0]                 # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
+        model = b.upload(clouds[0])       # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
+        ahead = b.prefetch(clouds[1]) if len(clouds) > 1 else None
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
         for k in range(1, len(clouds)):
-            voxel.setInputCloud(frames[k])
+            frame, ahead = ahead, (b.prefetch(clouds[k + 1]) if k + 1 < len(clouds) else None)   # frame k + 1 on the link meanwhile
+            voxel.setInputCloud(frame)
             reduced = voxel.filter()
             icp.setInputSource(reduced)
             icp.setInputTarget(model)
             icp.align()
             if not icp.hasConverged():
                 continue
-            moved = b.transform(frames[k], icp.getFinalTransformation())
+            moved = b.transform(frame, icp.getFinalTransformation())
             model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
             self.transforms.append(icp.getFinalTransformation())
             self.merged_frames.append(k)

@@ -86,6 +86,9 @@ class OracleBackend:
     def upload(self, cloud):
         return cloud
 
+    def prefetch(self, cloud):
+        return cloud
+
     def download(self, cloud):
         return cloud
 

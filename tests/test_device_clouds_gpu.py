@@ -146,3 +146,48 @@ def test_cloud_buffers_are_recycled_without_changing_results(api, rs, frames, mo
         assert t == t_ref
         for x, y in zip(ref, got):
             _same_records(x, y)
+
+
+def test_upload_async_is_waited_for_by_every_consumer(api, rs, frames):
+    """rsreg_cloud_upload_async returns with the PCIe copy still in flight; whatever touches the cloud next must see
+    the uploaded records: download, copy, filter, transform, concatenation (either side), device pointer, an alignment
+    (source and target), re-upload into the same handle, and a drop right after the call."""
+    a, b = frames[0], frames[2]
+    ctx = api.Context(0)
+    T = rs.synth.small_transform(2.0, (0.01, 0.02, -0.01)).astype(np.float32)
+
+    def fresh(c):
+        return api.DeviceCloud(ctx=ctx).upload_async(c)
+
+    _same_records(fresh(a).download(), a)
+    _same_records(fresh(b).copy().download(), b)
+    _same_records(api.transformPointCloud(fresh(a), T, ctx).download(), api.transformPointCloud(a, T, ctx))
+    _same_records((fresh(a) + fresh(b)).download(), a + b)
+    grown = fresh(a)
+    grown.append(fresh(b))
+    _same_records(grown.download(), a + b)
+    v1, v2 = api.ApproximateVoxelGrid(ctx), api.ApproximateVoxelGrid(ctx)
+    for v in (v1, v2):
+        v.setLeafSize(0.02, 0.02, 0.02)
+    v1.setInputCloud(fresh(b))
+    v2.setInputCloud(b)
+    _same_records(v1.filter().download(), v2.filter())
+    c = fresh(a)
+    assert c.device_ptr
+    assert c.info()[0] == len(a)
+    again = fresh(a).upload_async(b)          # a second upload into a handle whose first is still in flight
+    _same_records(again.download(), b)
+    for _ in range(4):                         # more uploads in flight than staging buffers; some dropped at once
+        fresh(a)
+        keep = fresh(b)
+    _same_records(keep.download(), b)
+    res = []
+    for src, tgt in ((fresh(b), fresh(a)), (api.DeviceCloud(b, ctx), api.DeviceCloud(a, ctx))):
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, max_correspondence_distance=0.05)
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        out = icp.align()
+        res.append((icp.getFinalTransformation().tobytes(), out.download()))
+    assert res[0][0] == res[1][0]
+    _same_records(res[0][1], res[1][1])

@@ -309,6 +309,11 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
  * cloud): the source records with xyz <- final * xyz and data[3] = 1 */
 int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud, double max_correspondence_distance);
 int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud);
+/* 1 when the ICP target index of `ctx` was built by rsreg_icp_set_target_cloud from this cloud, whose records have not
+ * been rewritten since, for this gate; 0 otherwise.  The ICP edge scheme sets the same grown feature cloud as the target
+ * of its coarse and of its refining ICP, one after the other (icp_edge_based_registration.hpp:94-95,108-109): a caller
+ * that asks first may skip the second build (pcl_compat.hpp: setReuseTargetIndex). */
+int rsreg_icp_target_is_cloud(const rsreg_ctx *ctx, const rsreg_cloud *cloud, double max_correspondence_distance);
 int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params,
                           rsreg_icp_result *result, rsreg_cloud *aligned_out);
 /* ndt.setInputTarget / align on handles, and on raw device pointers */

@@ -343,6 +343,10 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     // stay alive and unchanged until align has returned); output may be the source cloud itself
     void setInputSource(const DeviceCloud<PointSource> &cloud) { dsource_ = &cloud; source_.reset(); source_dirty_ = true; }
     void setInputTarget(const DeviceCloud<PointTarget> &cloud) { dtarget_ = &cloud; target_.reset(); target_dirty_ = true; }
+    // engine extra: with a device cloud as the target, keep the context's index when it was built from that very cloud
+    // (unchanged since) by another ICP object of the same context, instead of building it again.  Off by default: PCL
+    // rebuilds its kd-tree at every setInputTarget.
+    void setReuseTargetIndex(bool on) { reuse_target_index_ = on; }
     void align(DeviceCloud<PointSource> &output) { align(output, Matrix4f::Identity()); }
     void align(DeviceCloud<PointSource> &output, const Matrix4f &guess)
     {
@@ -354,7 +358,8 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
             ctx_->icp_source_owner = this;
         }
         if (target_dirty_ || ctx_->icp_target_owner != this) {
-            check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
+            if (!(reuse_target_index_ && rsreg_icp_target_is_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance)))
+                check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
             target_dirty_ = false;
             ctx_->icp_target_owner = this;
         }
@@ -375,7 +380,7 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     TargetPtr target_;
     const DeviceCloud<PointSource> *dsource_ = nullptr;
     const DeviceCloud<PointTarget> *dtarget_ = nullptr;
-    bool source_dirty_ = true, target_dirty_ = true;
+    bool source_dirty_ = true, target_dirty_ = true, reuse_target_index_ = false;
 };
 
 // ---- pcl::NormalDistributionsTransform

@@ -178,6 +178,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         if (use_imu) assert(n_frames == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
+        icp.setReuseTargetIndex(true);   // the coarse ICP of the ICP scheme has just built the index of the same target
         ApproximateVoxelGrid<rgb_point> voxel;
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();

@@ -200,6 +200,7 @@ class IterativeClosestPoint:
     def __init__(self, ctx=None):
         self.ctx = ctx or default_context()
         self.params = icp_params()
+        self.reuse_target_index = False   # engine extra, see _sync_inputs; PCL rebuilds its kd-tree at every setInputTarget
         self._src = self._tgt = None
         self._tgt_dirty = True
         self._src_dirty = True
@@ -278,7 +279,9 @@ class IterativeClosestPoint:
             self.ctx.icp_source_owner = self
         if self._tgt_dirty or self.ctx.icp_target_owner is not self:
             if isinstance(self._tgt, DeviceCloud):
-                _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
+                # (reuse_target_index: another ICP object of this context has just built the index of this very cloud)
+                if not (self.reuse_target_index and L.rsreg_icp_target_is_cloud(h, self._tgt.h, self.params.max_correspondence_distance)):
+                    _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
             elif isinstance(self._tgt, tuple):
                 _, p, n, s = self._tgt
                 _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)

@@ -25,6 +25,9 @@ struct rsreg_cloud {
     // rsreg_cloud_upload_async: the copy that fills this cloud may still be on the link
     hipEvent_t ev_filled = nullptr;
     mutable bool filling = false;
+    // which cloud this is and how often its records have been rewritten: an index built from (id, version) is still
+    // good while both are unchanged (rsreg_icp_set_target_cloud)
+    uint64_t id = 0, version = 0;
 };
 
 namespace rsreg {
@@ -161,7 +164,9 @@ int rsreg_cloud_create(rsreg_ctx *ctx, rsreg_cloud **out)
     if (!ctx || !out) return RSREG_ERR_INVALID_ARG;
     rsreg_cloud *c = new (std::nothrow) rsreg_cloud();
     if (!c) return RSREG_ERR_ALLOC;
+    static std::atomic<uint64_t> next_id{1};
     c->ctx = ctx;
+    c->id = next_id.fetch_add(1);
     *out = c;
     return RSREG_OK;
 }
@@ -194,6 +199,7 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
         RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, stage, n * stride, hipMemcpyHostToDevice, ctx->stream));
         RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
     }
+    c->version++;
     c->n = n;
     c->stride = stride;
     c->width = width;
@@ -239,6 +245,7 @@ int rsreg_cloud_upload_async(rsreg_cloud *c, const void *points, size_t n, size_
         ctx->up_busy[slot] = true;
         c->filling = true;
     }
+    c->version++;
     c->n = n;
     c->stride = stride;
     c->width = width;
@@ -307,6 +314,7 @@ int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uin
     RSREG_HIP(ctx, settle(c));
     RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, buf->ptr, n * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    c->version++;
     c->n = n; c->stride = stride; c->width = width; c->height = height; c->is_dense = is_dense;
     return RSREG_OK;
 }
@@ -321,6 +329,7 @@ int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, in->n * in->stride + 16));
     if (in->n) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, in->buf.ptr, in->n * in->stride, hipMemcpyDeviceToDevice, ctx->stream));
+    out->version++;
     out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
     return RSREG_OK;
 }
@@ -341,6 +350,7 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
     if (rc) return rc;
     RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
     if (nr) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    out->version++;
     out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
     return RSREG_OK;
 }
@@ -361,6 +371,7 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
                                                                                         in->stride, to_mat34(T), 0);
         RSREG_HIP(ctx, hipGetLastError());
     }
+    out->version++;
     out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
     return RSREG_OK;
 }
@@ -388,6 +399,7 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
         cloud_drop(ctx, out->buf);   // (a or b may be `out`: its old buffer is reused only by work queued after these copies)
         out->buf = fresh;
     }
+    out->version++;
     out->n = total; out->stride = stride; out->width = (uint32_t)total; out->height = 1; out->is_dense = dense;
     return RSREG_OK;
 }
@@ -397,7 +409,20 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
-    return rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
+    int rc = rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
+    if (rc) return rc;
+    ctx->tgt_cloud_id = c->id;
+    ctx->tgt_cloud_version = c->version;
+    return RSREG_OK;
+}
+
+// 1 when the context's ICP target index was built from this cloud, as it is now, for this gate: the ICP edge scheme
+// hands the same grown feature cloud to its coarse and to its refining ICP, one after the other
+// (icp_edge_based_registration.hpp:94-95,108-109), and the second of them may keep the index instead of building it again
+int rsreg_icp_target_is_cloud(const rsreg_ctx *ctx, const rsreg_cloud *c, double max_correspondence_distance)
+{
+    return ctx && c && c->ctx == ctx && ctx->have_target && ctx->tgt_cloud_id == c->id && ctx->tgt_cloud_version == c->version &&
+           ctx->gate_built_for == max_correspondence_distance;
 }
 
 int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
@@ -428,6 +453,7 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
                                                                                          (uint32_t)src->n, src->stride, to_mat34(T), 1);
         RSREG_HIP(ctx, hipGetLastError());
     }
+    aligned_out->version++;
     aligned_out->n = src->n; aligned_out->stride = src->stride; aligned_out->width = src->width; aligned_out->height = src->height;
     aligned_out->is_dense = src->is_dense;
     return RSREG_OK;
@@ -455,6 +481,7 @@ int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float
     int rc = rsreg_ndt_align_device(ctx, source->n ? source->buf.ptr : nullptr, source->n, source->stride, source->is_dense, guess, params,
                                     result, aligned_out ? aligned_out->buf.ptr : nullptr);
     if (rc || !aligned_out) return rc;
+    aligned_out->version++;
     aligned_out->n = source->n; aligned_out->stride = source->stride; aligned_out->width = source->width;
     aligned_out->height = source->height; aligned_out->is_dense = source->is_dense;
     return RSREG_OK;

@@ -281,6 +281,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
 {
     hipStream_t st = ctx->stream;
     ctx->have_target = false;
+    ctx->tgt_cloud_id = 0;
     ctx->n_target_raw = n;
     std::memset(&ctx->grid_info, 0, sizeof(ctx->grid_info));
     std::memset(&ctx->grid, 0, sizeof(ctx->grid));

@@ -182,6 +182,7 @@ struct rsreg_ctx {
     bool have_ndt_target = false;
     double ndt_resolution = 0;
     int ndt_n_voxels = 0;
+    uint64_t tgt_cloud_id = 0, tgt_cloud_version = 0;   // the device cloud the ICP target index was built from (0: none)
     rsreg::CloudPool cloud_pool;
     std::vector<hipEvent_t> ev_copy;   // one per piece of a cloud download in flight (cloud.hip)
     // rsreg_cloud_upload_async: a copy stream, two pinned staging buffers used in turn, the event behind the last copy

@@ -29,7 +29,7 @@ EXPORTS = [
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
     "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_upload_async", "rsreg_cloud_download", "rsreg_cloud_info",
     "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_transform", "rsreg_cloud_concat",
-    "rsreg_icp_set_target_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
+    "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
     "rsreg_extract_edge_features", "rsreg_cloud_edge_features",
     "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
@@ -182,6 +182,7 @@ def lib():
     L.rsreg_cloud_transform.argtypes = [vp, vp, vp, vp]
     L.rsreg_cloud_concat.argtypes = [vp, vp, vp, vp]
     L.rsreg_icp_set_target_cloud.argtypes = [vp, vp, dbl]
+    L.rsreg_icp_target_is_cloud.argtypes = [vp, vp, dbl]
     L.rsreg_icp_set_source_cloud.argtypes = [vp, vp]
     L.rsreg_icp_align_cloud.argtypes = [vp, vp, C.POINTER(IcpParams), C.POINTER(IcpResult), vp]
     L.rsreg_ndt_set_target_cloud.argtypes = [vp, vp, dbl]

@@ -214,6 +214,8 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         if self.use_imu:
             assert len(pairs) == len(self.thetas)
         icp = b.icp()
+        if hasattr(icp, "reuse_target_index"):
+            icp.reuse_target_index = True    # the coarse ICP of the ICP scheme has just built the index of the same target
         voxel = b.voxel((0.01, 0.01, 0.01))
         coarse = self._coarse()
         merged = b.upload(pairs[0][1])

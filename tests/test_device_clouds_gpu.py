@@ -191,3 +191,47 @@ def test_upload_async_is_waited_for_by_every_consumer(api, rs, frames):
         res.append((icp.getFinalTransformation().tobytes(), out.download()))
     assert res[0][0] == res[1][0]
     _same_records(res[0][1], res[1][1])
+
+
+def test_target_index_of_an_unchanged_cloud_can_be_kept(api, rs, frames):
+    """rsreg_icp_target_is_cloud: 1 only for the very cloud the index was built from, unchanged, at the same gate.  A
+    second ICP object that opts in (reuse_target_index) skips the build and gets the same bits; without the opt-in, or
+    once the cloud has been rewritten in place, the index is built again."""
+    from rsreg_amd import lib
+    L = lib.lib()
+    ctx = api.Context(0)
+    tgt, src = api.DeviceCloud(frames[0], ctx), api.DeviceCloud(frames[2], ctx)
+    other = api.DeviceCloud(frames[0], ctx)
+    prm = dict(max_iterations=4, criteria_mode=1, max_correspondence_distance=0.05)
+
+    def run(reuse):
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(**prm)
+        icp.reuse_target_index = reuse
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        icp.align()
+        return icp.getFinalTransformation().tobytes(), icp.grid_info()
+
+    t0, g0 = run(False)
+    assert L.rsreg_icp_target_is_cloud(ctx.h, tgt.h, 0.05) == 1
+    assert L.rsreg_icp_target_is_cloud(ctx.h, tgt.h, 0.01) == 0          # another gate: another index
+    assert L.rsreg_icp_target_is_cloud(ctx.h, other.h, 0.05) == 0        # same records, another cloud
+    t1, g1 = run(True)
+    assert t1 == t0 and g1.n_cells == g0.n_cells
+    tgt.append(other)                                                    # rewritten in place: same handle, new contents
+    assert L.rsreg_icp_target_is_cloud(ctx.h, tgt.h, 0.05) == 0
+    t2, g2 = run(True)
+    assert g2.n_unique_points >= g0.n_unique_points
+    fresh = api.IterativeClosestPoint(ctx)
+    fresh.params = api.icp_params(**prm)
+    fresh.setInputSource(src)
+    fresh.setInputTarget(api.DeviceCloud(frames[0] + frames[0], ctx))
+    fresh.align()
+    assert fresh.getFinalTransformation().tobytes() == t2
+    host = api.IterativeClosestPoint(ctx)                                # a target set another way forgets the cloud
+    host.params = api.icp_params(**prm)
+    host.setInputSource(frames[2])
+    host.setInputTarget(frames[0])
+    host.align()
+    assert L.rsreg_icp_target_is_cloud(ctx.h, tgt.h, 0.05) == 0

@@ -355,7 +355,8 @@ typedef struct rsreg_grid_info {
     uint32_t n_cells;           /* occupied cells                                           */
     uint32_t max_points_per_cell;
     double ms_build;            /* device time of the last build (profiling on)             */
-    uint32_t index_kind;        /* 1 = dense cell-start table, 0 = brick hash (huge extents) */
+    uint32_t index_kind;        /* 1 = dense cell-start table, 0 = brick hash (huge extents), 2 = none: a device-cloud
+                                 * target set for at most 64 source points is searched whole (IncrementalICP) */
     uint32_t n_source_distinct; /* distinct source points the iterations work on (0: no source) */
     uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
 } rsreg_grid_info;

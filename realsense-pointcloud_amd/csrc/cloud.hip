@@ -30,6 +30,10 @@ struct rsreg_cloud {
     uint64_t id = 0, version = 0;
 };
 
+extern "C" int rsreg_icp_set_target_scan_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, double max_correspondence_distance);   // icp.hip
+constexpr size_t kScanSourceLimit = 64;       // (= kScanMaxSource of icp_kernels.hpp) source points at most, and ...
+constexpr size_t kScanTargetFloor = 32768;    // ... target points at least, for the search without an index
+
 namespace rsreg {
 int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out);   // voxel.hip
 }
@@ -409,7 +413,13 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
-    int rc = rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
+    // IncrementalICP aligns the ten or twenty points a 1 m voxel filter leaves of a frame against the whole merged model
+    // (incremental_icp.hpp:54-59): for so few queries the index is not worth building (icp.hip: scan_target).  The
+    // source is set before the target in the reference; if it is not, or changes, rsreg_icp_begin builds the index.
+    const bool few_queries = ctx->have_source && ctx->n_source > 0 && ctx->n_source <= kScanSourceLimit && c->n >= kScanTargetFloor &&
+                             !std::getenv("RSREG_NO_SCAN");
+    int rc = few_queries ? rsreg_icp_set_target_scan_(ctx, c->buf.ptr, c->n, c->stride, max_correspondence_distance)
+                         : rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
     if (rc) return rc;
     ctx->tgt_cloud_id = c->id;
     ctx->tgt_cloud_version = c->version;

@@ -450,6 +450,34 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     return RSREG_OK;
 }
 
+// No index at all (icp_kernels.hpp: k_scan_nn): the target is only put into (x, y, index, z) records in the caller's
+// order.  Chosen by rsreg_icp_set_target_cloud when the source that is already loaded has a handful of points;
+// rsreg_icp_begin builds the real index after all if the alignment turns out to need it (`d_pts` must stay valid
+// until then: the contract of cloud handles).
+int scan_target(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist)
+{
+    ctx->have_target = false;
+    ctx->tgt_cloud_id = 0;
+    ctx->n_target_raw = n;
+    std::memset(&ctx->grid_info, 0, sizeof(ctx->grid_info));
+    std::memset(&ctx->grid, 0, sizeof(ctx->grid));
+    ctx->gate_built_for = max_dist;
+    if (n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "target too large");
+    RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve((n + 8) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_scan_keys.reserve(kScanMaxSource * 8));
+    k_scan_pack<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_pts, stride, (uint32_t)n, ctx->d_tgt_sorted.as<float4>());
+    RSREG_HIP(ctx, hipGetLastError());
+    ctx->grid.dense = 2;
+    ctx->grid.n_points = (uint32_t)n;
+    ctx->scan_raw = d_pts;
+    ctx->scan_stride = stride;
+    ctx->grid_info.index_kind = 2;
+    ctx->grid_info.n_unique_points = n;
+    ctx->grid_info.index_bytes = (uint64_t)n * sizeof(float4);
+    ctx->have_target = true;
+    return RSREG_OK;
+}
+
 // The source load runs on its own stream; whoever needs its result (the number of distinct points, the source
 // buffers) joins it first.
 int join_source(rsreg_ctx *ctx)
@@ -707,7 +735,19 @@ int launch_search(rsreg_ctx *ctx)
     if (n) {
         ScopedEvents ev(ctx, &ctx->ev_nn);
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
-        if (ctx->grid.dense)
+        if (ctx->grid.dense == 2) {
+            // the largest float that passes PCL's `if (distance > max_dist_sqr) continue` (compared in double)
+            float gate_f = gate2 >= (double)FLT_MAX ? FLT_MAX : (float)gate2;
+            if ((double)gate_f > gate2) gate_f = std::nextafterf(gate_f, 0.0f);
+            unsigned long long *keys = ctx->d_scan_keys.as<unsigned long long>();
+            const uint32_t nt = ctx->grid.n_points;
+            RSREG_HIP(ctx, hipMemsetAsync(keys, 0xff, (size_t)n * 8, ctx->stream));
+            if (nt)
+                k_scan_nn<<<std::min(div_up(nt, kBlock), 2048u), kBlock, 0, ctx->stream>>>(ctx->d_tgt_sorted.as<float4>(), nt, ctx->d_cur.as<float4>(),
+                                                                                          n, gate_f, keys);
+            k_scan_finish<<<1, kScanMaxSource, 0, ctx->stream>>>(keys, ctx->d_cur.as<float4>(), n, ctx->d_corr_pos.as<int>(),
+                                                                ctx->d_corr_d2.as<float>());
+        } else if (ctx->grid.dense)
             k_nn_search_dense<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n,
                                                                              dense_dev(ctx, s.prm.max_correspondence_distance), gate2,
                                                                              ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
@@ -1095,7 +1135,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
-                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc};
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
     ctx->h_smisc.release();
@@ -1169,6 +1209,13 @@ int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     return build_grid(ctx, static_cast<const char *>(d_points), n, stride, max_correspondence_distance);
 }
 
+// (internal, cloud.hip) a target for the handful of source points already loaded: no index, see scan_target
+int rsreg_icp_set_target_scan_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, double max_correspondence_distance)
+{
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    return scan_target(ctx, static_cast<const char *>(d_points), n, stride, max_correspondence_distance);
+}
+
 int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense,
                          double max_correspondence_distance)
 {
@@ -1221,6 +1268,11 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     {
         int rcj = join_source(ctx);
         if (rcj) return rcj;
+    }
+    if (ctx->grid.dense == 2 && (ctx->n_work > kScanMaxSource || filters_on(*params))) {
+        // the target was set for a handful of queries (scan_target); this alignment needs the index after all
+        int rcb = build_grid(ctx, ctx->scan_raw, ctx->n_target_raw, ctx->scan_stride, ctx->gate_built_for);
+        if (rcb) return rcb;
     }
     IcpState &s = ctx->icp;
     s = IcpState();
@@ -1334,7 +1386,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         }
     }
     if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
-        if (ctx->grid.dense && ctx->n_work) {
+        if (ctx->grid.dense == 1 && ctx->n_work) {
             const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
             const size_t nw = light ? (size_t)(ctx->icp.sched_ready ? ctx->icp.sched_items : reduce_blocks(ctx->n_work)) * kTileWaves
                                     : (ctx->n_work + 63) / 64;
@@ -1408,8 +1460,9 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     int done = 0;
     double sums[RSREG_NUM_SUMS];
     const bool filtered = filters_on(*params);   // the optional correspondence filters run between the staged kernels
-    const bool fused = !filtered && (params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP);
-    if (!filtered && params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
+    const bool scan = ctx->grid.dense == 2;   // no index: the staged kernels (search over the whole target, sums)
+    const bool fused = !filtered && !scan && (params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP);
+    if (!filtered && !scan && params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
         !(!ctx->grid.dense && use_tile_kernel())) {
         rc = run_device_loop(ctx);
         if (rc) return rc;
@@ -1435,7 +1488,7 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
     static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
-    if (want_max && ctx->grid.dense && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
+    if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
         const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);
         uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;
         uint32_t h = 0;

@@ -893,6 +893,63 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
     }
 }
 
+// ------------------------------------------------------------------------ no index: a handful of queries
+// IncrementalICP aligns what a 1 m voxel filter leaves of a frame -- ten or twenty points -- against everything merged so
+// far (incremental_icp.hpp:54-59; the leaf is never set, PCL's default applies).  Building an index over millions of
+// target points for twenty queries costs fifty times the search: with at most kScanMaxSource distinct source points every
+// target point is scored against every query instead.  Same float32 distance in the same operation order, same gate
+// test, lowest index among equals (the minimum of (distance, index) keys does not depend on the order they arrive in).
+constexpr uint32_t kScanMaxSource = 64;
+
+// (x, y, index, z) records in the caller's order: position == index.  A non-finite point is infinitely far from
+// every query.
+__global__ __launch_bounds__(kBlock) void k_scan_pack(const char *pts, size_t stride, uint32_t n, float4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = rec_xyz(pts, stride, i);
+    const float x = p[0], y = p[1], z = p[2];
+    out[i] = finite3(x, y, z) ? tgt_rec(x, y, z, i) : tgt_rec(__uint_as_float(0x7f800000u), 0.0f, 0.0f, i);
+}
+
+// keys[s] = min over the target of (d2 bits << 32 | index), d2 <= gate_f (the largest float not above the gate)
+__global__ __launch_bounds__(kBlock) void k_scan_nn(const float4 *tgt, uint32_t nt, const float4 *cur, uint32_t ns, float gate_f,
+                                                    unsigned long long *keys)
+{
+    __shared__ float4 s_q[kScanMaxSource];
+    __shared__ unsigned long long s_best[kScanMaxSource];
+    if (threadIdx.x < ns) {
+        s_q[threadIdx.x] = cur[threadIdx.x];
+        s_best[threadIdx.x] = ~0ull;
+    }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += gridDim.x * blockDim.x) {
+        const float4 t = tgt[i];
+        for (uint32_t s = 0; s < ns; ++s) {
+            const float4 q = s_q[s];
+            if (q.w == 0.0f) continue;
+            const float dx = __fsub_rn(q.x, t.x), dy = __fsub_rn(q.y, t.y), dz = __fsub_rn(q.z, tgt_z(t));
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            // the workgroup's best so far bounds what is worth an atomic (a stale bound only costs one)
+            const uint32_t bound = (uint32_t)(__hip_atomic_load(&s_best[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+            if (d <= gate_f && __float_as_uint(d) <= bound)
+                atomicMin(&s_best[s], ((unsigned long long)__float_as_uint(d) << 32) | tgt_idx(t));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ns && s_best[threadIdx.x] != ~0ull) atomicMin(&keys[threadIdx.x], s_best[threadIdx.x]);
+}
+
+__global__ void k_scan_finish(const unsigned long long *keys, const float4 *cur, uint32_t ns, int *corr_pos, float *corr_d2)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    const unsigned long long k = keys[s];
+    const bool hit = k != ~0ull && cur[s].w != 0.0f;
+    corr_pos[s] = hit ? (int)(uint32_t)k : -1;
+    corr_d2[s] = hit ? __uint_as_float((uint32_t)(k >> 32)) : 0.0f;
+}
+
 // corr (sorted source order, position in the sorted target) -> caller's order and indices
 __global__ __launch_bounds__(kBlock) void k_export_corr(const int *corr_pos, const float *corr_d2, const float4 *tgt,
                                                         const uint32_t *perm, const uint32_t *uniq_of, uint32_t n,

@@ -90,7 +90,7 @@ struct GridParams {
     uint32_t n_cells;      // occupied cells
     uint32_t n_bricks;     // occupied 4x4x4-cell bricks
     int max_ring;          // rings (cells) needed to cover the correspondence gate
-    int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos)
+    int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos), 2: no index (scan_target)
 };
 
 struct BrickEntry {          // 32 B, one hash-table slot
@@ -182,6 +182,9 @@ struct rsreg_ctx {
     bool have_ndt_target = false;
     double ndt_resolution = 0;
     int ndt_n_voxels = 0;
+    rsreg::DevBuf d_scan_keys;           // no-index search (scan_target): one (distance, index) key per source point
+    const char *scan_raw = nullptr;      // ... and the records the index is built from if an alignment needs it after all
+    size_t scan_stride = 0;
     uint64_t tgt_cloud_id = 0, tgt_cloud_version = 0;   // the device cloud the ICP target index was built from (0: none)
     rsreg::CloudPool cloud_pool;
     std::vector<hipEvent_t> ev_copy;   // one per piece of a cloud download in flight (cloud.hip)

@@ -235,3 +235,66 @@ def test_target_index_of_an_unchanged_cloud_can_be_kept(api, rs, frames):
     host.setInputTarget(frames[0])
     host.align()
     assert L.rsreg_icp_target_is_cloud(ctx.h, tgt.h, 0.05) == 0
+
+
+@pytest.mark.parametrize("gate", [0.01, 0.05, 0.5, None])
+def test_handful_of_queries_without_an_index(api, rs, frames, gate, monkeypatch):
+    """With at most 64 source points (what IncrementalICP's 1 m voxel filter leaves of a frame) a device-cloud target is
+    not indexed: every target point is scored against every query.  Matches (index and squared distance, bit for bit),
+    iteration counts and transforms must be those of the indexed search; ties go to the lowest index; non-finite points
+    on either side take no part; an alignment that turns out to need the index (more source points) gets it."""
+    rng = np.random.default_rng(5)
+    tgt = frames[0].copy()
+    tgt.points[["x", "y", "z"]][100:110] = tgt.points[["x", "y", "z"]][50:60]        # value-equal copies: the lower index wins
+    tgt.points["y"][7] = np.inf
+    pick = rng.choice(len(frames[2]), 23, replace=False)
+    few = rs.PointCloud(np.ascontiguousarray(frames[2].points[pick]))
+    few.points[["x", "y", "z"]][3] = tgt.points[["x", "y", "z"]][55]                 # a query sitting on a duplicated target point
+    few.points[["x", "y", "z"]][4] = few.points[["x", "y", "z"]][5]                  # two copies of one query
+    few.points["z"][9] = np.nan
+    kw = dict(max_iterations=6, criteria_mode=1)
+    if gate is not None:
+        kw["max_correspondence_distance"] = gate
+
+    def run(no_scan, src):
+        if no_scan:
+            monkeypatch.setenv("RSREG_NO_SCAN", "1")
+        else:
+            monkeypatch.delenv("RSREG_NO_SCAN", raising=False)
+        ctx = api.Context(0)
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(**kw)
+        icp.setInputSource(api.DeviceCloud(src, ctx))
+        icp.setInputTarget(api.DeviceCloud(tgt, ctx))
+        icp.begin()
+        idx, d2 = icp.search()
+        kind = icp.grid_info().index_kind
+        out = icp.align()
+        return kind, idx, d2, icp.getFinalTransformation().tobytes(), icp.result.iterations, icp.result.n_correspondences, out.download()
+
+    a, b = run(False, few), run(True, few)
+    assert a[0] == 2 and b[0] == 1
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert a[3:6] == b[3:6]
+    _same_records(a[6], b[6])
+    assert (a[1] >= 0).sum() >= (3 if gate == 0.01 else 10) and a[1][9] == -1
+    if gate is None or gate >= 0.05:
+        assert a[1][3] == 50 + 5                                                     # not its copy at 105
+    many = rs.PointCloud(np.ascontiguousarray(frames[2].points[:5000]))
+    c, d = run(False, many), run(True, many)
+    assert c[0] == 1 and c[3:6] == d[3:6]
+    # the target set for a handful of queries, then a larger source without setting the target again
+    monkeypatch.delenv("RSREG_NO_SCAN", raising=False)
+    ctx = api.Context(0)
+    icp = api.IterativeClosestPoint(ctx)
+    icp.params = api.icp_params(**kw)
+    icp.setInputSource(api.DeviceCloud(few, ctx))
+    keep = api.DeviceCloud(tgt, ctx)
+    icp.setInputTarget(keep)
+    icp.align()
+    assert icp.grid_info().index_kind == 2 and icp.getFinalTransformation().tobytes() == b[3]
+    icp.setInputSource(api.DeviceCloud(many, ctx))
+    icp.align()
+    assert icp.grid_info().index_kind == 1
+    assert (icp.getFinalTransformation().tobytes(), icp.result.iterations, icp.result.n_correspondences) == d[3:6]

@@ -61,11 +61,6 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
     if (set_w && stride >= 16) dst[3] = __float_as_uint(1.0f);
 }
 
-// A dropped cloud's buffer goes to the context's pool and the next cloud takes it from there (rsreg_ctx.hpp, CloudPool):
-// the frame loops create and drop half a dozen clouds per frame, and every hipFree is a device-wide synchronisation
-// (0.16 ms).  Every kernel and copy that touches a cloud runs on ctx->stream, so a buffer handed on is written only
-// after the work queued on its previous owner; the one other reader is a source load on ctx->stream_src, which the main
-// stream is made to wait for before a buffer changes hands.
 // Whoever reads or rewrites a cloud first waits (on the host) for an upload of it that is still in flight: by then a
 // frame prefetched one step of the frame loop earlier has long arrived, and a host wait is right whatever stream the
 // reader works on.
@@ -76,6 +71,11 @@ hipError_t settle(const rsreg_cloud *c)
     return hipEventSynchronize(c->ev_filled);
 }
 
+// A dropped cloud's buffer goes to the context's pool and the next cloud takes it from there (rsreg_ctx.hpp, CloudPool):
+// the frame loops create and drop half a dozen clouds per frame, and every hipFree is a device-wide synchronisation
+// (0.16 ms).  Every kernel and copy that touches a cloud runs on ctx->stream, so a buffer handed on is written only
+// after the work queued on its previous owner; the one other reader is a source load on ctx->stream_src, which the main
+// stream is made to wait for before a buffer changes hands.
 void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
 {
     if (!b.ptr) return;

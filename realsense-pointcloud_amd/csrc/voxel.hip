@@ -143,42 +143,111 @@ __global__ __launch_bounds__(kVBlock) void k_vox_runs(const char *recs, size_t s
     vox_store_run(acc, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);
 }
 
-// One wave per long run (a 1 m leaf puts 10^4..10^5 points in a run): 64 lanes fetch 64 points
-// at a time into LDS (component-major), lanes 0..6 each add one of the seven components in input
-// order, four LDS values per read; the next 64 points are in flight meanwhile.  A short last
-// chunk is padded with +0.0f, which leaves a float sum unchanged.
+// The seven terms of a point from two loads when the records allow it (32-byte PointXYZRGB records, 16-byte aligned):
+// xyz in one 16-byte load, the rgb word once (it is both the float PCL adds and the three bytes).
+struct VoxRaw {
+    float x, y, z;
+    uint32_t rgb;
+};
+__device__ __forceinline__ VoxRaw vox_load(const char *rec, bool vec)
+{
+    VoxRaw r;
+    if (vec) {
+        const float4 a = *reinterpret_cast<const float4 *>(rec);
+        r.x = a.x; r.y = a.y; r.z = a.z;
+    } else {
+        const float *f = reinterpret_cast<const float *>(rec);
+        r.x = f[0]; r.y = f[1]; r.z = f[2];
+    }
+    r.rgb = *reinterpret_cast<const uint32_t *>(rec + 16);
+    return r;
+}
+
+// One wave per long run (a 1 m leaf puts 10^4..10^5 points in a run, and the largest run IS the filter's run time: its
+// seven sums are chains of dependent float additions in input order, like PCL's, ~8 cycles a link).  64 lanes fetch 64
+// points at a time and pass them through LDS (component-major); lanes 0..6 each add one component in input order.
+// Nothing but the chain may be on the critical path: the point indices are fetched eight chunks ahead and the records
+// four chunks ahead (a gather from HBM takes longer than four chunks of additions), and chunk k + 1 is written to the
+// other half of the LDS buffer before chunk k is added.  Positions past the end of the run contribute +0.0f, which
+// leaves a float sum unchanged.
 __global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, size_t stride, uint32_t n, const uint32_t *skeys,
                                                            const uint32_t *svals, const uint32_t *start, const uint32_t *stats,
                                                            float *cent, uint32_t *ekey, uint32_t *erun, const uint32_t *long_runs)
 {
-    __shared__ __attribute__((aligned(16))) float sh[kVBlock / 64][8][64];
+    constexpr int kAhead = 4;
+    __shared__ __attribute__((aligned(16))) float sh[kVBlock / 64][2][8][64];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nr = stats[0], nfin = stats[1], n_long = stats[2];
+    const bool vec = (stride % 16 == 0) && ((reinterpret_cast<size_t>(recs) & 15) == 0);
     for (uint32_t k = wave; k < n_long; k += n_waves) {
         const uint32_t r = long_runs[k];
         const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
-        float acc = 0.0f;
-        float t[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (a + lane < b) vox_terms(recs + (size_t)svals[a + lane] * stride, t);
-        for (uint32_t p0 = a; p0 < b; p0 += 64) {
-            for (int c = 0; c < 7; ++c) sh[w][c][lane] = t[c];
-            for (int c = 0; c < 7; ++c) t[c] = 0.0f;
-            if (p0 + 64 + lane < b) vox_terms(recs + (size_t)svals[p0 + 64 + lane] * stride, t);   // next chunk, in flight
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 7) {
-                const float4 *v = reinterpret_cast<const float4 *>(&sh[w][lane][0]);
+        const uint32_t n_chunks = (b - a + 63) / 64;
+        // chunk c covers sorted positions a + 64 c + lane; idx[j] / raw[j]: what is in flight for chunk == j (mod kAhead)
+        uint32_t idx[kAhead];
+        VoxRaw raw[kAhead];
+        auto fetch_idx = [&](uint32_t c) -> uint32_t {
+            const uint32_t p = a + 64 * c + lane;
+            return p < b ? svals[p] : 0xffffffffu;
+        };
+        auto fetch_raw = [&](uint32_t i) -> VoxRaw {
+            if (i == 0xffffffffu) return VoxRaw{0.0f, 0.0f, 0.0f, 0u};
+            return vox_load(recs + (size_t)i * stride, vec);
+        };
+        auto stage = [&](int half, const VoxRaw &v, uint32_t i) {   // a lane's point into its column of the LDS half
+            float *col = &sh[w][half][0][lane];
+            const bool in = i != 0xffffffffu;
+            col[0 * 64] = v.x; col[1 * 64] = v.y; col[2 * 64] = v.z;
+            col[3 * 64] = __uint_as_float(v.rgb);
+            col[4 * 64] = in ? (float)((v.rgb >> 16) & 0xffu) : 0.0f;
+            col[5 * 64] = in ? (float)((v.rgb >> 8) & 0xffu) : 0.0f;
+            col[6 * 64] = in ? (float)(v.rgb & 0xffu) : 0.0f;
+        };
+        uint32_t was[kAhead];   // the index a staged record was fetched with (decides the padding)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float4 q = v[i];
-                    acc = __fadd_rn(acc, q.x);
-                    acc = __fadd_rn(acc, q.y);
-                    acc = __fadd_rn(acc, q.z);
-                    acc = __fadd_rn(acc, q.w);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < kAhead; ++j) {
+            was[j] = fetch_idx((uint32_t)j);
+            raw[j] = fetch_raw(was[j]);
         }
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) idx[j] = fetch_idx((uint32_t)(kAhead + j));
+        stage(0, raw[0], was[0]);
+        float acc = 0.0f;
+        // one step: chunk c is added; J = c mod kAhead, spelled out so that every register array index is a constant
+#define RSREG_VOX_STEP(J)                                                                                               \
+    {                                                                                                                   \
+        const uint32_t c = c0 + (J);                                                                                    \
+        if (c >= n_chunks) break;                                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                          \
+        __builtin_amdgcn_wave_barrier();                                                                                \
+        /* chunk c + 1 into the other half (its records were asked for three steps ago); then these registers take     \
+           chunk c + kAhead (indices asked for four steps ago) and the indices of chunk c + 2 kAhead go out */         \
+        stage((int)((c + 1) & 1u), raw[((J) + 1) % kAhead], was[((J) + 1) % kAhead]);                                   \
+        was[(J)] = idx[(J)];                                                                                            \
+        raw[(J)] = fetch_raw(idx[(J)]);                                                                                 \
+        idx[(J)] = fetch_idx(c + 2 * kAhead);                                                                           \
+        if (lane < 7) {                                                                                                 \
+            const float4 *v = reinterpret_cast<const float4 *>(&sh[w][c & 1u][lane][0]);                                \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                              \
+            {                                                                                                           \
+                const float4 q = v[i];                                                                                  \
+                acc = __fadd_rn(acc, q.x);                                                                              \
+                acc = __fadd_rn(acc, q.y);                                                                              \
+                acc = __fadd_rn(acc, q.z);                                                                              \
+                acc = __fadd_rn(acc, q.w);                                                                              \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+        static_assert(kAhead == 4, "the steps below are spelled out for four chunks in flight");
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += kAhead) {
+            RSREG_VOX_STEP(0)
+            RSREG_VOX_STEP(1)
+            RSREG_VOX_STEP(2)
+            RSREG_VOX_STEP(3)
+        }
+#undef RSREG_VOX_STEP
+        __builtin_amdgcn_wave_barrier();
         float all[7];
         for (int c = 0; c < 7; ++c) all[c] = __shfl(acc, c);
         if (lane == 0) vox_store_run(all, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);

@@ -301,6 +301,11 @@ const void *rsreg_cloud_device_ptr(const rsreg_cloud *cloud);
 int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
 /* ApproximateVoxelGrid::filter, same records in the same order as the host filter; in == out allowed */
 int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);
+/* The same on a side stream of the context: returns once the number of output records is known, the sums of the voxels
+ * still running; whichever call touches `out` next waits for them.  The frame loops filter frame k + 1 this way before
+ * they align frame k (incremental_icp.hpp:54-55 filters every frame independently of the registration).  `in` must stay
+ * alive and unchanged until `out` has been used; in != out. */
+int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);
 /* pcl::transformPointCloud; in == out allowed */
 int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float transform[16], rsreg_cloud *out);
 /* PointCloud::operator+ : out = a followed by b (width = size, height = 1, is_dense = both); out may be a or b */

@@ -486,6 +486,13 @@ template <typename PointT> class ApproximateVoxelGrid {
     {
         check(rsreg_cloud_filter(input.context()->get(), input.handle(), leaf_, output.handle()), input.context()->get());
     }
+    // the same on the context's side stream: returns once the size of the result is known, the voxel sums still
+    // running; whatever touches `output` next waits for them.  `input` must stay alive and unchanged until then;
+    // output must not be the input (rsreg_cloud_filter_async)
+    void filter_async(const DeviceCloud<PointT> &input, DeviceCloud<PointT> &output)
+    {
+        check(rsreg_cloud_filter_async(input.context()->get(), input.handle(), leaf_, output.handle()), input.context()->get());
+    }
   private:
     float leaf_[3] = {1.f, 1.f, 1.f};  // PCL default: IncrementalICP never sets it (incremental_icp.hpp:36)
     typename PointCloud<PointT>::Ptr input_;

@@ -14,6 +14,7 @@
 // edge points of the organized frame, rsreg_extract_edge_features) unless a `feature_fn` is plugged in.
 #pragma once
 
+#include <algorithm>
 #include <cassert>
 #include <functional>
 #include <iostream>
@@ -95,12 +96,16 @@ class IncrementalICP : public RegistrationScheme {
         ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
-        rgb_device_cloud model(*clouds[0]), reduced, aligned, frames[2], moved;
-        if (clouds.size() > 1) frames[1].upload_async(*clouds[1]);
-        for (size_t k = 1; k < clouds.size(); ++k) {
-            rgb_device_cloud &frame = frames[k & 1];
-            if (k + 1 < clouds.size()) frames[(k + 1) & 1].upload_async(*clouds[k + 1]);   // on the link while frame k is aligned
-            voxel.filter(frame, reduced);
+        // two frames ahead on the PCIe link, one frame ahead in the voxel filter: the 1 m filter is one wave adding floats
+        // one after the other, and runs under the alignment of the frame before on a stream of its own
+        const size_t n = clouds.size();
+        rgb_device_cloud model(*clouds[0]), reduced_of[2], aligned, frames[3], moved;
+        for (size_t k = 1; k < std::min<size_t>(3, n); ++k) frames[k % 3].upload_async(*clouds[k]);
+        if (n > 1) voxel.filter_async(frames[1], reduced_of[1]);
+        for (size_t k = 1; k < n; ++k) {
+            rgb_device_cloud &frame = frames[k % 3], &reduced = reduced_of[k & 1];
+            if (k + 2 < n) frames[(k + 2) % 3].upload_async(*clouds[k + 2]);
+            if (k + 1 < n) voxel.filter_async(frames[(k + 1) % 3], reduced_of[(k + 1) & 1]);
             icp.setInputSource(reduced);
             icp.setInputTarget(model);
             icp.align(aligned);

@@ -471,6 +471,15 @@ class ApproximateVoxelGrid:
     def setInputCloud(self, cloud):
         self._in = cloud
 
+    def filter_async(self):
+        """filter() of a device cloud on the context's side stream: returns once the size of the result is known, the
+        voxel sums still running; whatever touches the result next waits for them (rsreg_cloud_filter_async).  The
+        input must stay alive and unchanged until the result has been used."""
+        out = DeviceCloud(ctx=self._in.ctx)
+        _l.check(_l.lib().rsreg_cloud_filter_async(self._in.ctx.h, self._in.h, self.leaf.ctypes.data, out.h), self._in.ctx.h)
+        out._filtered_from = self._in   # (keeps the input alive)
+        return out
+
     def filter(self):
         if isinstance(self._in, DeviceCloud):
             out = DeviceCloud(ctx=self._in.ctx)

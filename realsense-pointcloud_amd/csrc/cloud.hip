@@ -35,7 +35,7 @@ constexpr size_t kScanSourceLimit = 64;       // (= kScanMaxSource of icp_kernel
 constexpr size_t kScanTargetFloor = 32768;    // ... target points at least, for the search without an index
 
 namespace rsreg {
-int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out);   // voxel.hip
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, bool side);   // voxel.hip
 }
 
 namespace {
@@ -350,10 +350,49 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
     RSREG_HIP(ctx, settle(out));
     uint32_t nr = 0;
     const size_t stride = in->stride;
-    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr);
+    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, false);
     if (rc) return rc;
     RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
     if (nr) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream));
+    out->version++;
+    out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
+    return RSREG_OK;
+}
+
+// rsreg_cloud_filter on the context's side stream, with scratch of its own: the call returns once the number of output
+// records is known (a short host wait on the side stream), with the runs' sums -- for PCL's default 1 m leaf one wave
+// adding 10^5 floats one after the other -- still running; whoever touches `out` next waits for them (settle).  The
+// frame loops filter frame k + 1 this way before they align frame k.  `in` must stay alive and unchanged until `out`
+// has been used; in != out.
+int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc || !leaf || in == out) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
+    if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(in));
+    RSREG_HIP(ctx, settle(out));
+    if (!ctx->stream_side) {
+        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_side, hipStreamNonBlocking));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
+    }
+    // what the main stream holds so far comes first: `in` may have been produced there, and the buffer `out` is about
+    // to get may come from the pool with work of its previous owner still queued
+    RSREG_HIP(ctx, hipEventRecord(ctx->ev_side_gate, ctx->stream));
+    RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_side_gate, 0));
+    if (ctx->src_pending) RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_src_done, 0));
+    uint32_t nr = 0;
+    const size_t stride = in->stride;
+    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, true);
+    if (rc) return rc;
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));
+    if (nr) {
+        if (!out->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&out->ev_filled, hipEventDisableTiming));
+        RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->vs_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream_side));
+        RSREG_HIP(ctx, hipEventRecord(out->ev_filled, ctx->stream_side));
+        out->filling = true;
+    }
     out->version++;
     out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
     return RSREG_OK;

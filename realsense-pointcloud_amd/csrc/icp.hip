@@ -1135,7 +1135,9 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
-                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys};
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys,
+                      &ctx->vs_out, &ctx->vs_keys, &ctx->vs_keys_alt, &ctx->vs_vals, &ctx->vs_vals_alt, &ctx->vs_flags, &ctx->vs_scan, &ctx->vs_cent,
+                      &ctx->vs_misc, &ctx->vs_tmp};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
     ctx->h_smisc.release();
@@ -1153,6 +1155,12 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
     }
     for (rsreg::PinnedBuf &b : ctx->h_up) b.release();
+    if (ctx->stream_side) {
+        (void)hipStreamSynchronize(ctx->stream_side);
+        (void)hipStreamDestroy(ctx->stream_side);
+        (void)hipEventDestroy(ctx->ev_side_gate);
+    }
+    ctx->vs_host.release();
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

@@ -177,6 +177,12 @@ struct rsreg_ctx {
 
     // ---- ApproximateVoxelGrid on the device (voxel.hip)
     rsreg::DevBuf d_vox_in, d_vox_out, d_vox_cent;
+    // rsreg_cloud_filter_async: a second scratch set and a side stream, so that the filter of the next frame (one wave
+    // per long run, latency-bound) runs under the alignment of this one; ev_side_gate lets it start after the main stream
+    hipStream_t stream_side = nullptr;
+    hipEvent_t ev_side_gate = nullptr;
+    rsreg::DevBuf vs_out, vs_keys, vs_keys_alt, vs_vals, vs_vals_alt, vs_flags, vs_scan, vs_cent, vs_misc, vs_tmp;
+    rsreg::PinnedBuf vs_host;
 
     // ---- NDT
     bool have_ndt_target = false;

@@ -282,35 +282,44 @@ using namespace rsreg;
 namespace rsreg {
 
 // The filter on records already in HBM (d_in, N records of `stride` bytes); the filtered records
-// land in ctx->d_vox_out, *n_out of them.  One host synchronisation (the number of runs).
-int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out)
+// land in the scratch set's `out`, *n_out of them.  One host synchronisation (the number of runs); what follows it
+// (the runs' sums, their order, the output records) is only queued.  `side`: the context's second scratch set and its
+// side stream (rsreg_cloud_filter_async: the filter of the next frame under the alignment of this one).
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, bool side)
 {
     *n_out = 0;
     if (N == 0) return RSREG_OK;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = side ? ctx->stream_side : ctx->stream;
     const size_t n = N;
     const float ivx = 1.0f / leaf[0], ivy = 1.0f / leaf[1], ivz = 1.0f / leaf[2];
-    // buffers (all reused from the context; nothing here overlaps an ICP call in flight)
-    RSREG_HIP(ctx, ctx->d_vox_out.reserve(n * stride));
-    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_vox_cent.reserve(n * 32));
-    RSREG_HIP(ctx, ctx->d_misc.reserve(256));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(2048));
-    char *d_out = ctx->d_vox_out.as<char>();
-    uint32_t *keys = ctx->d_keys.as<uint32_t>(), *skeys = ctx->d_keys_alt.as<uint32_t>();
-    uint32_t *vals = ctx->d_vals.as<uint32_t>(), *svals = ctx->d_vals_alt.as<uint32_t>();
-    uint32_t *flag = ctx->d_flags.as<uint32_t>(), *rid = ctx->d_scan.as<uint32_t>();
+    // buffers (the main set is shared with the ICP index build: nothing on the main stream overlaps an ICP call in
+    // flight; the side set is the side stream's own)
+    DevBuf &b_out = side ? ctx->vs_out : ctx->d_vox_out, &b_keys = side ? ctx->vs_keys : ctx->d_keys,
+           &b_keys_alt = side ? ctx->vs_keys_alt : ctx->d_keys_alt, &b_vals = side ? ctx->vs_vals : ctx->d_vals,
+           &b_vals_alt = side ? ctx->vs_vals_alt : ctx->d_vals_alt, &b_flags = side ? ctx->vs_flags : ctx->d_flags,
+           &b_scan = side ? ctx->vs_scan : ctx->d_scan, &b_cent = side ? ctx->vs_cent : ctx->d_vox_cent,
+           &b_misc = side ? ctx->vs_misc : ctx->d_misc, &b_tmp = side ? ctx->vs_tmp : ctx->d_tmp;
+    PinnedBuf &b_host = side ? ctx->vs_host : ctx->h_sums;
+    RSREG_HIP(ctx, b_out.reserve(n * stride));
+    RSREG_HIP(ctx, b_keys.reserve(n * 8));
+    RSREG_HIP(ctx, b_keys_alt.reserve(n * 8));
+    RSREG_HIP(ctx, b_vals.reserve(n * 8));
+    RSREG_HIP(ctx, b_vals_alt.reserve(n * 8));
+    RSREG_HIP(ctx, b_flags.reserve(n * 8));
+    RSREG_HIP(ctx, b_scan.reserve(n * 8));
+    RSREG_HIP(ctx, b_cent.reserve(n * 32));
+    RSREG_HIP(ctx, b_misc.reserve(256));
+    RSREG_HIP(ctx, b_host.reserve(2048));
+    char *d_out = b_out.as<char>();
+    uint32_t *keys = b_keys.as<uint32_t>(), *skeys = b_keys_alt.as<uint32_t>();
+    uint32_t *vals = b_vals.as<uint32_t>(), *svals = b_vals_alt.as<uint32_t>();
+    uint32_t *flag = b_flags.as<uint32_t>(), *rid = b_scan.as<uint32_t>();
     uint32_t *start = keys;                 // keys are dead once sorted
     uint32_t *ekey = vals, *erun = flag;    // vals dead once sorted, flag dead after the starts
     uint32_t *ekey2 = keys + N, *order = vals + N;
     uint32_t *long_runs = rid;              // the run ids are dead once the starts are written
-    float *cent = ctx->d_vox_cent.as<float>();
-    uint32_t *stats = ctx->d_misc.as<uint32_t>() + 32;
+    float *cent = b_cent.as<float>();
+    uint32_t *stats = b_misc.as<uint32_t>() + 32;
     RSREG_HIP(ctx, hipMemsetAsync(stats, 0, 16, st));
     const uint32_t nb = div_up_u(N, kVBlock);
     k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals);
@@ -319,14 +328,14 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
+    RSREG_HIP(ctx, b_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
     k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
     k_vox_starts<<<nb, kVBlock, 0, st>>>(skeys, flag, rid, N, start, stats);
     RSREG_HIP(ctx, hipGetLastError());
-    uint32_t *h = ctx->h_sums.as<uint32_t>();
+    uint32_t *h = b_host.as<uint32_t>();
     RSREG_HIP(ctx, hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t nr = h[0];
@@ -336,7 +345,7 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     k_vox_long_runs<<<std::min(div_up_u(nr, 4u), 2048u), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun,
                                                                            long_runs);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.ptr, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
     k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, order, stats, stride, d_out);
     RSREG_HIP(ctx, hipGetLastError());
     *n_out = nr;
@@ -365,7 +374,7 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     }
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
     uint32_t nr = 0;
-    int rc = voxel_filter_device(ctx, ctx->d_vox_in.as<char>(), (uint32_t)n, stride, leaf, &nr);
+    int rc = voxel_filter_device(ctx, ctx->d_vox_in.as<char>(), (uint32_t)n, stride, leaf, &nr, false);
     if (rc || nr == 0) return rc;
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));

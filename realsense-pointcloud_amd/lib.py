@@ -28,7 +28,7 @@ EXPORTS = [
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
     "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_upload_async", "rsreg_cloud_download", "rsreg_cloud_info",
-    "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_transform", "rsreg_cloud_concat",
+    "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_filter_async", "rsreg_cloud_transform", "rsreg_cloud_concat",
     "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
     "rsreg_extract_edge_features", "rsreg_cloud_edge_features",
@@ -179,6 +179,7 @@ def lib():
     L.rsreg_cloud_device_ptr.restype = vp
     L.rsreg_cloud_copy.argtypes = [vp, vp, vp]
     L.rsreg_cloud_filter.argtypes = [vp, vp, vp, vp]
+    L.rsreg_cloud_filter_async.argtypes = [vp, vp, vp, vp]
     L.rsreg_cloud_transform.argtypes = [vp, vp, vp, vp]
     L.rsreg_cloud_concat.argtypes = [vp, vp, vp, vp]
     L.rsreg_icp_set_target_cloud.argtypes = [vp, vp, dbl]

@@ -177,13 +177,23 @@ class IncrementalICP(RegistrationScheme):
         voxel = b.voxel()                 # leaf never set -> PCL's 1 m default
         icp = b.icp()
         model = b.upload(clouds[0])       # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
-        ahead = b.prefetch(clouds[1]) if len(clouds) > 1 else None
+        n = len(clouds)
+        # two frames ahead on the PCIe link, one frame ahead in the voxel filter (the 1 m filter is one wave adding floats
+        # one after the other: it runs under the alignment of the frame before, on a stream of its own)
+        frames = {k: b.prefetch(clouds[k]) for k in range(1, min(3, n))}
+
+        def start_filter(k):
+            voxel.setInputCloud(frames[k])
+            return voxel.filter_async() if hasattr(voxel, "filter_async") and not isinstance(frames[k], PointCloud) else voxel.filter()
+
+        reduced_ahead = start_filter(1) if n > 1 else None
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
-        for k in range(1, len(clouds)):
-            frame, ahead = ahead, (b.prefetch(clouds[k + 1]) if k + 1 < len(clouds) else None)   # frame k + 1 on the link meanwhile
-            voxel.setInputCloud(frame)
-            reduced = voxel.filter()
+        for k in range(1, n):
+            if k + 2 < n:
+                frames[k + 2] = b.prefetch(clouds[k + 2])
+            frame, reduced = frames.pop(k), reduced_ahead
+            reduced_ahead = start_filter(k + 1) if k + 1 < n else None
             icp.setInputSource(reduced)
             icp.setInputTarget(model)
             icp.align()

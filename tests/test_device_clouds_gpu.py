@@ -298,3 +298,49 @@ def test_handful_of_queries_without_an_index(api, rs, frames, gate, monkeypatch)
     icp.align()
     assert icp.grid_info().index_kind == 1
     assert (icp.getFinalTransformation().tobytes(), icp.result.iterations, icp.result.n_correspondences) == d[3:6]
+
+
+@pytest.mark.parametrize("leaf", [(1.0, 1.0, 1.0), (0.02, 0.02, 0.02)])
+def test_filter_async_equals_filter(api, rs, frames, leaf):
+    """rsreg_cloud_filter_async runs the filter on a side stream with scratch of its own and returns with the voxel sums
+    still running: the records are those of the blocking filter, whatever touches the result first (download, an
+    alignment as source or target, a transform), also with several filters issued back to back, with the main stream busy
+    in between, and with inputs whose own upload was still in flight."""
+    ctx = api.Context(0)
+    a, b = frames[0], frames[2]
+    T = rs.synth.small_transform(2.0, (0.01, 0.02, -0.01)).astype(np.float32)
+
+    def vox():
+        v = api.ApproximateVoxelGrid(ctx)
+        v.setLeafSize(*leaf)
+        return v
+
+    def blocking(c):
+        v = vox()
+        v.setInputCloud(api.DeviceCloud(c, ctx))
+        return v.filter().download()
+
+    def side(c, in_flight=False):
+        v = vox()
+        v.setInputCloud(api.DeviceCloud(ctx=ctx).upload_async(c) if in_flight else api.DeviceCloud(c, ctx))
+        return v.filter_async()
+
+    ra, rb = blocking(a), blocking(b)
+    _same_records(side(a).download(), ra)
+    _same_records(side(b, in_flight=True).download(), rb)
+    outs = [side(a), side(b), side(a, True), side(b, True)]          # back to back: one scratch set, in stream order
+    big = api.DeviceCloud(a, ctx)
+    for _ in range(3):
+        big = big + big                                               # main stream busy meanwhile
+    for o, r in zip(outs, (ra, rb, ra, rb)):
+        _same_records(o.download(), r)
+    _same_records(api.transformPointCloud(side(a), T, ctx).download(), api.transformPointCloud(ra, T, ctx))
+    res = []
+    for src in (side(b), api.DeviceCloud(rb, ctx)):
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, max_correspondence_distance=0.5)
+        icp.setInputSource(src)
+        icp.setInputTarget(api.DeviceCloud(a, ctx))
+        icp.align()
+        res.append((icp.getFinalTransformation().tobytes(), icp.result.n_correspondences))
+    assert res[0] == res[1]

@@ -182,9 +182,9 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.pos_of = ctx->d_pos_of.as<uint32_t>();
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
-    // how far the x order of a sorted run can be off: one 2^-16 bucket of the sort key, plus the float
+    // how far the x order of a sorted run can be off: one bucket of the sort key (2^-xbits of a cell), plus the float
     // rounding of (x - ox) * inv_cell, which grows with the grid (ulp of the largest in-grid position)
-    g.x_slack = p.cell * (1.52587890625e-5f + 9.5367431640625e-7f * (float)std::max(p.dims[0], 1));
+    g.x_slack = p.cell * (std::ldexp(1.0f, -(p.xbits > 0 ? p.xbits : 16)) + 9.5367431640625e-7f * (float)std::max(p.dims[0], 1));
     return g;
 }
 
@@ -200,6 +200,59 @@ long long dense_cell_budget()
 }
 
 // Dense-table index (icp_dense.hpp).  The grid geometry (ctx->grid) is already decided.
+// KeyT: the sort key's type -- uint32_t when the cell id and at least 6 bits of x position fit 32 bits (build_dense).
+template <typename KeyT>
+int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, int id_bits)
+{
+    hipStream_t st = ctx->stream;
+    GridParams &gp = ctx->grid;
+    const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
+    RSREG_HIP(ctx, ctx->d_keys.reserve(n * sizeof(KeyT)));
+    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * sizeof(KeyT)));
+    const DenseDev g = dense_dev(ctx, max_dist);
+    auto *keys = ctx->d_keys.as<KeyT>();
+    auto *keys2 = ctx->d_keys_alt.as<KeyT>();
+    auto *vals = ctx->d_vals.as<uint32_t>();
+    auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
+    auto *flags = ctx->d_flags.as<unsigned long long>(), *scan = ctx->d_scan.as<unsigned long long>();   // keep | cstart << 32 and its scan
+    uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
+    uint32_t *table = ctx->d_dense.as<uint32_t>();
+    const uint32_t xbits = (uint32_t)gp.xbits;
+    // a table that is only read where an occupancy bit points is written by the scatter kernel, occupied cells only: no
+    // clear, no scan of (nx+2)(ny+2)(nz+2) entries; the occupancy words behind it are OR-ed together and start from zero
+    if (gp.table_sparse) RSREG_HIP(ctx, hipMemsetAsync(table + (total + 2), 0, (total + 2) * 4, st));
+    else RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));
+    k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, keys, vals);
+    RSREG_HIP(ctx, hipGetLastError());
+    const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
+    size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    const uint32_t nbf = div_up(nfin, kBlock);
+    k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
+    RSREG_HIP(ctx, hipGetLastError());
+    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
+    k_dense_scatter<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags, scan, ctx->d_tgt_sorted.as<float4>(),
+                                                  ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8,
+                                                  gp.table_sparse ? table : nullptr);
+    RSREG_HIP(ctx, hipGetLastError());
+    if (!gp.table_sparse) {
+        k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
+        RSREG_HIP(ctx, hipGetLastError());
+        // counts -> first sorted point of every cell (in place), entry [total] = number of points
+        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+    }
+    // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
+    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, table + (total + 2));
+    RSREG_HIP(ctx, hipGetLastError());
+    return RSREG_OK;
+}
+
 int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, hipEvent_t ev0,
                 hipEvent_t ev1)
 {
@@ -207,11 +260,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     GridParams &gp = ctx->grid;
     gp.dense = 1;
     const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
-    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
-    const size_t misc_bytes = 16 * sizeof(uint32_t);
-    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
-    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_flags.reserve(n * 8));
@@ -221,40 +270,18 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_dense.reserve((total + 2) * 4 * 2));   // cell starts, then the neighbourhood occupancy words
     RSREG_HIP(ctx, ctx->d_tgt_sorted.reserve(((size_t)nfin + 8) * sizeof(float4)));
     RSREG_HIP(ctx, ctx->d_pos_of.reserve((n + 1) * 4));
-    const DenseDev g = dense_dev(ctx, max_dist);
-    auto *keys = ctx->d_keys.as<unsigned long long>();
-    auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
-    auto *vals = ctx->d_vals.as<uint32_t>();
-    auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
-    auto *flags = ctx->d_flags.as<unsigned long long>(), *scan = ctx->d_scan.as<unsigned long long>();   // keep | cstart << 32 and its scan
-    uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
-    uint32_t *table = ctx->d_dense.as<uint32_t>();
-    RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));   // (the table and the occupancy words behind it)
-    k_dense_keys<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
-    RSREG_HIP(ctx, hipGetLastError());
     int id_bits = 1;
     while ((1ull << id_bits) <= total) ++id_bits;   // all-ones (non-finite) stays above every valid id
-    const unsigned end_bit = (unsigned)std::min(64, 16 + id_bits);
-    size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
-    const uint32_t nbf = div_up(nfin, kBlock);
-    k_dense_flag<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, flags);
-    RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
-    k_dense_scatter<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, flags, scan, ctx->d_tgt_sorted.as<float4>(),
-                                            ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8);
-    RSREG_HIP(ctx, hipGetLastError());
-    k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
-    RSREG_HIP(ctx, hipGetLastError());
-    // counts -> first sorted point of every cell (in place), entry [total] = number of points
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
-    // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
-    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, table + (total + 2));
-    RSREG_HIP(ctx, hipGetLastError());
+    static const bool wide_keys = std::getenv("RSREG_KEYS64") && std::getenv("RSREG_KEYS64")[0] == '1';
+    static const bool full_table = std::getenv("RSREG_FULL_TABLE") && std::getenv("RSREG_FULL_TABLE")[0] == '1';
+    const bool narrow = !wide_keys && id_bits <= 26;   // at least 6 bits of x order inside a cell
+    gp.xbits = narrow ? std::min(16, 32 - id_bits) : 16;
+    // the searches of gates up to four cells go through the occupancy words only (icp_dense.hpp: dense_far_blocks);
+    // the row search of wider or unbounded gates reads table entries of empty cells too and needs all of them
+    gp.table_sparse = (gp.max_ring <= 4 && !full_table && !std::getenv("RSREG_FAR_ROWS")) ? 1 : 0;
+    int rc = narrow ? build_dense_keyed<uint32_t>(ctx, d_pts, n, stride, max_dist, nfin, id_bits)
+                    : build_dense_keyed<unsigned long long>(ctx, d_pts, n, stride, max_dist, nfin, id_bits);
+    if (rc) return rc;
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
     RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in the pinned buffer)
     gp.n_cells = h_misc[8];
@@ -541,31 +568,65 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         double extent = 0;
         for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
         // fine Morton resolution (a few mm): consecutive points then form compact blobs
-        const float cell = (float)std::max(cell_cap_from_env() / 8.0, extent / 60000.0);
+        float cell = (float)std::max(cell_cap_from_env() / 8.0, extent / 60000.0);
+        // a 32-bit key (31 bits of Morton code + the invalid bit) halves the bytes the radix sort moves and saves it a pass
+        // or two: the cell grows (by at most 2x: the search time moves by +- 1.5 % between 1.5 and 3 mm)
+        // until the three axes need 31 bits together
+        static const bool wide_keys = std::getenv("RSREG_KEYS64") && std::getenv("RSREG_KEYS64")[0] == '1';
+        auto axis_bits_of = [](double ext, double c) {
+            int b = 1;
+            while (b < 16 && (double)(1u << b) <= ext / c + 2.0) ++b;
+            return b;
+        };
+        MortonBits mb{0, 0, 0};
+        bool narrow = false;
+        if (!wide_keys) {
+            for (double c = cell; c <= 2.0 * (double)cell + 1e-12; c *= 1.05) {
+                mb = MortonBits{axis_bits_of((double)mx[0] - (double)mn[0], c), axis_bits_of((double)mx[1] - (double)mn[1], c),
+                                axis_bits_of((double)mx[2] - (double)mn[2], c)};
+                if (mb.x + mb.y + mb.z <= 31 && std::max(mb.x, std::max(mb.y, mb.z)) <= 12) {
+                    narrow = true;
+                    cell = (float)c;
+                    break;
+                }
+            }
+        }
         RSREG_HIP(ctx, ctx->d_skeys.reserve(n * 8));
         RSREG_HIP(ctx, ctx->d_skeys_alt.reserve(n * 8));
         RSREG_HIP(ctx, ctx->d_svals.reserve(n * 4));
         RSREG_HIP(ctx, ctx->d_sflags.reserve(n * 4));
         RSREG_HIP(ctx, ctx->d_sscan.reserve(n * 4));
-        auto *keys = ctx->d_skeys.as<unsigned long long>();
-        auto *keys2 = ctx->d_skeys_alt.as<unsigned long long>();
         auto *vals = ctx->d_svals.as<uint32_t>();
         uint32_t *perm = ctx->d_perm.as<uint32_t>();
         uint32_t *keep = ctx->d_sflags.as<uint32_t>(), *pos = ctx->d_sscan.as<uint32_t>();
         const uint32_t nb = div_up((uint32_t)n, kBlock);
-        // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
-        int axis_bits = 1;
-        while (axis_bits < 16 && (double)(1u << axis_bits) <= extent / (double)cell + 2.0) ++axis_bits;
-        const unsigned sort_bits = 3u * (unsigned)axis_bits + 1u;
-        k_source_keys<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), keys, vals);
-        RSREG_HIP(ctx, hipGetLastError());
         size_t sort_bytes = 0, scan_bytes = 0;
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
         RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-        RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
-        k_gather_source<<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
-        RSREG_HIP(ctx, hipGetLastError());
+        if (narrow) {
+            auto *keys = ctx->d_skeys.as<uint32_t>();
+            auto *keys2 = ctx->d_skeys_alt.as<uint32_t>();
+            const unsigned sort_bits = (unsigned)(mb.x + mb.y + mb.z) + 1u;
+            k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys, vals);
+            RSREG_HIP(ctx, hipGetLastError());
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            k_gather_source<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
+            RSREG_HIP(ctx, hipGetLastError());
+        } else {
+            auto *keys = ctx->d_skeys.as<unsigned long long>();
+            auto *keys2 = ctx->d_skeys_alt.as<unsigned long long>();
+            // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
+            const int axis_bits = axis_bits_of(extent, (double)cell);
+            const unsigned sort_bits = 3u * (unsigned)axis_bits + 1u;
+            k_source_keys<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), mb, keys, vals);
+            RSREG_HIP(ctx, hipGetLastError());
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            k_gather_source<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
+            RSREG_HIP(ctx, hipGetLastError());
+        }
         RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
                                                ctx->d_uniq_of.as<uint32_t>(), d_misc + 12, h_misc + 32);   // the number of distinct points: read at the join
@@ -1501,7 +1562,8 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
         uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;
         uint32_t h = 0;
         RSREG_HIP(ctx, hipMemsetAsync(d, 0, 4, ctx->stream));
-        k_dense_max_count<<<2048, kBlock, 0, ctx->stream>>>(ctx->d_dense.as<uint32_t>(), total, d);
+        (void)total;
+        k_dense_max_count<<<256, kBlock, 0, ctx->stream>>>(ctx->d_cellpos.as<uint32_t>(), ctx->d_misc.as<uint32_t>() + 8, d);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
         RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1535,7 +1597,7 @@ int rsreg_transform_cloud(rsreg_ctx *ctx, const void *in, void *out, size_t n, s
     RSREG_HIP(ctx, hipMemcpyAsync(d_raw, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
     Mat4f T;
     std::memcpy(T.m, transform, 64);
-    k_gather_source<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_raw, 12, (uint32_t)n, nullptr, d_pts, nullptr);
+    k_gather_source<uint32_t><<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_raw, 12, (uint32_t)n, nullptr, d_pts, nullptr);
     RSREG_HIP(ctx, hipGetLastError());
     k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(d_pts, (uint32_t)n, to_mat34(T), nullptr,
                                                                             reinterpret_cast<float *>(d_raw));

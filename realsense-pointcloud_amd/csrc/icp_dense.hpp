@@ -46,21 +46,24 @@ __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int 
     return (uint32_t)(((z + 1) * (g.ny + 2) + (y + 1)) * (g.nx + 2) + (x + 1));
 }
 
-// sort key: [padded cell id | x position inside the cell, 16 bits]: a cell's points are sorted
-// by x, which lets a search stop inside a cell (dense_walk); non-finite points sort to the very end
-__global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t stride, uint32_t n, DenseDev g,
-                                                       unsigned long long *keys, uint32_t *vals)
+// sort key: [padded cell id | x position inside the cell, `xbits` bits]: a cell's points are sorted
+// by x, which lets a search stop inside a cell (dense_walk); non-finite points sort to the very end (all-ones key).
+// KeyT = uint32_t whenever cell id and x position fit 32 bits together (any room-scale cloud: 23 + 9 bits at 1 M
+// points): the radix sort then moves half the bytes in four passes instead of six.
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t stride, uint32_t n, DenseDev g, uint32_t xbits,
+                                                       KeyT *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = rec_xyz(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    unsigned long long key = kEmptyKey;
+    KeyT key = (KeyT)~(KeyT)0;
     if (finite3(x, y, z)) {
         const int cx = min(max(cell_coord(x, g.ox, g.inv_cell), 0), g.nx - 1), cy = min(max(cell_coord(y, g.oy, g.inv_cell), 0), g.ny - 1),
                   cz = min(max(cell_coord(z, g.oz, g.inv_cell), 0), g.nz - 1);
-        const float fx = (cell_pos(x, g.ox, g.inv_cell) - (float)cx) * 65536.0f;
-        key = ((unsigned long long)dense_cell_id(g, cx, cy, cz) << 16) | (unsigned long long)min(max((int)fx, 0), 65535);
+        const float fx = (cell_pos(x, g.ox, g.inv_cell) - (float)cx) * (float)(1u << xbits);
+        key = ((KeyT)dense_cell_id(g, cx, cy, cz) << xbits) | (KeyT)min(max((int)fx, 0), (int)(1u << xbits) - 1);
     }
     keys[i] = key;
     vals[i] = i;
@@ -69,15 +72,16 @@ __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t s
 // flags[i] = keep | cstart << 32.  keep: not a value-equal duplicate of its predecessor in the same (cell, x bucket)
 // run; cstart: first point of a cell (always kept).  One 64-bit exclusive scan of the flags gives both running
 // counts at once: pos (low word) and cid (high word).
-__global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long *keys, const uint32_t *vals, const char *pts,
-                                                       size_t stride, uint32_t nfin, unsigned long long *flags)
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_dense_flag(const KeyT *keys, const uint32_t *vals, const char *pts,
+                                                       size_t stride, uint32_t nfin, uint32_t xbits, unsigned long long *flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
     uint32_t kp = 1, cs = 1;
     if (i > 0) {
-        const unsigned long long k = keys[i], kprev = keys[i - 1];
-        cs = (k >> 16) != (kprev >> 16);
+        const KeyT k = keys[i], kprev = keys[i - 1];
+        cs = (k >> xbits) != (kprev >> xbits);
         if (k == kprev) {
             const float *a = rec_xyz(pts, stride, vals[i]);
             const float *b = rec_xyz(pts, stride, vals[i - 1]);
@@ -89,16 +93,23 @@ __global__ __launch_bounds__(kBlock) void k_dense_flag(const unsigned long long 
 
 // the sorted point array, and for every occupied cell (in sorted order) its table slot and the
 // position of its first point; scan[i] = exclusive scan of flags: pos | cid << 32.
-// stats[0] = occupied cells, stats[2] = kept points
-__global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long long *keys, const uint32_t *vals, const char *pts,
-                                                          size_t stride, uint32_t nfin, const unsigned long long *flags,
+// stats[0] = occupied cells, stats[2] = kept points.
+// table != null (grids searched through the occupancy words only, max_ring <= 4): the two table entries a search can
+// ever read of an occupied cell -- its first point and, one slot on, its end (= the first point of the next occupied
+// cell in sorted order) -- are written here, and the table is neither cleared nor scanned (stale
+// entries of earlier builds lie only where no occupancy bit points).
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_dense_scatter(const KeyT *keys, const uint32_t *vals, const char *pts,
+                                                          size_t stride, uint32_t nfin, uint32_t xbits, const unsigned long long *flags,
                                                           const unsigned long long *scan, float4 *sorted, uint32_t *pos_of,
-                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats, uint32_t *host_stats)
+                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats, uint32_t *host_stats,
+                                                          uint32_t *table)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nfin) return;
     const unsigned long long f = flags[i], sc = scan[i];
     const uint32_t keep = (uint32_t)f, cstart = (uint32_t)(f >> 32), pos = (uint32_t)sc, cid = (uint32_t)(sc >> 32);
+    const uint32_t slot = (uint32_t)(keys[i] >> xbits);
     if (keep) {
         const uint32_t v = vals[i];
         const float *p = rec_xyz(pts, stride, v);
@@ -106,8 +117,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         pos_of[v] = pos;
     }
     if (cstart) {
-        cellslot[cid] = (uint32_t)(keys[i] >> 16);
+        cellslot[cid] = slot;
         cellpos[cid] = pos;
+        if (table) {
+            table[slot] = pos;
+            if (i > 0) table[(uint32_t)(keys[i - 1] >> xbits) + 1u] = pos;   // (the same value when the two slots coincide)
+        }
     }
     if (i == nfin - 1) {
         const uint32_t nu = pos + keep, nc = cid + cstart;
@@ -116,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const unsigned long lo
         host_stats[0] = nc;   // (pinned host memory: what the host reads when the build has drained, no copy queued)
         host_stats[2] = nu;
         cellpos[nc] = nu;   // sentinel
+        if (table) table[slot + 1u] = nu;
         // far-away points behind the last sorted point: a 4-wide candidate read may run past it
         for (uint32_t k = 0; k < 4; ++k) sorted[nu + k] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
     }
@@ -131,12 +147,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_counts(const uint32_t *cellslo
     table[cellslot[c]] = cellpos[c + 1] - cellpos[c];
 }
 
-// largest cell population, from the finished table (introspection only: rsreg_icp_grid_info)
-__global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *table, size_t total, uint32_t *out)
+// largest cell population, from the starts of the occupied cells (introspection only: rsreg_icp_grid_info)
+__global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *cellpos, const uint32_t *stats, uint32_t *out)
 {
     uint32_t v = 0;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x)
-        v = max(v, table[c + 1] - table[c]);
+    const uint32_t nc = stats[0];
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) v = max(v, cellpos[c + 1] - cellpos[c]);
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off));
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
@@ -337,8 +353,10 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     // the three first loads (neighbourhood word, own cell's range, the seed point) go out together:
     // a search is a chain of dependent loads, and every round trip saved shortens the slowest waves
     const uint32_t occ = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
-    const u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
+    u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
     dense_seed(rs, q, seed_pos, b, limit2);
+    // (an empty cell's table entry may be left over from an earlier build: k_dense_scatter writes occupied cells only)
+    if (!(occ & (1u << 13))) se = u32x2{0u, 0u};
     // ---- ring 0: the query's own cell (it usually holds the nearest point)
     const float x_slack = g.x_slack;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column

@@ -328,18 +328,41 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long v)
 
 // Spatial sort key of a source point: Morton (Z-order) code of its cell in the source's own
 // grid, so that any run of consecutive points is a compact patch in all three dimensions.
+// 32-bit form: the axes carry bits.x / bits.y / bits.z bits (what the extent needs at this cell size); the low
+// min(bits) levels interleave like the 64-bit code, longer axes keep contributing alone -- the key has
+// bits.x + bits.y + bits.z bits, the invalid key is one bit above.
+struct MortonBits {
+    int x, y, z;
+};
+
+__device__ __forceinline__ uint32_t morton_mixed(uint32_t cx, uint32_t cy, uint32_t cz, MortonBits b)
+{
+    uint32_t key = 0;
+    int out = 0;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+        if (l < b.x) key |= ((cx >> l) & 1u) << out++;
+        if (l < b.y) key |= ((cy >> l) & 1u) << out++;
+        if (l < b.z) key |= ((cz >> l) & 1u) << out++;
+    }
+    return key;
+}
+
+template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t stride, uint32_t n, float ox, float oy,
-                                                        float oz, float inv_cell, unsigned long long invalid_key,
-                                                        unsigned long long *keys, uint32_t *vals)
+                                                        float oz, float inv_cell, KeyT invalid_key, MortonBits bits,
+                                                        KeyT *keys, uint32_t *vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = rec_xyz(raw, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    unsigned long long key = invalid_key;   // one bit above every Morton code: non-finite points sort last
-    if (finite3(x, y, z))
-        key = spread3((unsigned)cell_coord(x, ox, inv_cell)) | spread3((unsigned)cell_coord(y, oy, inv_cell)) << 1 |
-              spread3((unsigned)cell_coord(z, oz, inv_cell)) << 2;
+    KeyT key = invalid_key;   // one bit above every Morton code: non-finite points sort last
+    if (finite3(x, y, z)) {
+        const unsigned cx = (unsigned)cell_coord(x, ox, inv_cell), cy = (unsigned)cell_coord(y, oy, inv_cell), cz = (unsigned)cell_coord(z, oz, inv_cell);
+        if (sizeof(KeyT) == 4) key = (KeyT)morton_mixed(min(cx, (1u << bits.x) - 1u), min(cy, (1u << bits.y) - 1u), min(cz, (1u << bits.z) - 1u), bits);
+        else key = (KeyT)(spread3(cx) | spread3(cy) << 1 | spread3(cz) << 2);
+    }
     keys[i] = key;
     vals[i] = i;
 }
@@ -347,8 +370,9 @@ __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t 
 // src[j] = {xyz of original point perm[j], valid}; cur = copy
 // keys + keep (both or neither): also flags the sorted point j that is not an exact copy of its predecessor (same Morton
 // key, same xyz; invalid points are never merged: they carry weight 0 anyway), from the predecessor's own record
+template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_t stride, uint32_t n, const uint32_t *perm,
-                                                          float4 *src, float4 *cur, const unsigned long long *keys = nullptr,
+                                                          float4 *src, float4 *cur, const KeyT *keys = nullptr,
                                                           uint32_t *keep = nullptr)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -91,6 +91,8 @@ struct GridParams {
     uint32_t n_bricks;     // occupied 4x4x4-cell bricks
     int max_ring;          // rings (cells) needed to cover the correspondence gate
     int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos), 2: no index (scan_target)
+    int xbits;             // dense: bits of the x position inside a cell in the sort key (16, or what a 32-bit key leaves)
+    int table_sparse;      // dense: only the table entries of occupied cells (and the slot behind each) are valid
 };
 
 struct BrickEntry {          // 32 B, one hash-table slot

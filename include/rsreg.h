@@ -256,6 +256,13 @@ int rsreg_ndt_align(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
 int rsreg_ndt_derivatives(rsreg_ctx *ctx, const void *source, size_t n, size_t stride,
                           int is_dense, const double pose[6], double *score, double gradient[6],
                           double hessian[36]);
+/* Which point a voxel is searched by (VoxelGridCovariance's centroid cloud, ndt_edge_based_registration.hpp:71-72 ->
+ * setInputTarget).  0 (default): the voxel's f64 mean rounded to float.  1: PCL's own arithmetic -- a float running
+ * sum over the voxel's points in input order, divided by float(n) (voxel_grid_covariance.hpp: leaf.centroid += pt;
+ * leaf.centroid /= nr_points) -- one sequential chain per voxel, for bit-level agreement with a PCL build.  Applies
+ * to the targets set afterwards.  Optionally reads the centroids back (3 floats per valid voxel). */
+int rsreg_ndt_set_centroid_mode(rsreg_ctx *ctx, int mode);
+int rsreg_ndt_get_centroids(rsreg_ctx *ctx, float *centroids /*3 each*/, int32_t capacity);
 /* Read back the valid voxels: per voxel 3 (mean) + 9 (cov) + 9 (icov) doubles and a count. */
 int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_icov /*21 each*/,
                          int32_t *counts, int32_t capacity);
@@ -298,6 +305,12 @@ int rsreg_cloud_download(const rsreg_cloud *cloud, void *out, size_t capacity_re
 int rsreg_cloud_info(const rsreg_cloud *cloud, size_t *n, size_t *stride, uint32_t *width, uint32_t *height,
                      int *is_dense);
 const void *rsreg_cloud_device_ptr(const rsreg_cloud *cloud);
+/* Which cloud this is (`id`, unique per handle) and how often its records have been rewritten (`version`: every upload,
+ * filter, transform, concatenation or alignment INTO the handle counts).  A host layer that keeps PCL's
+ * "setInputSource once, align many times" habit compares the pair with what it loaded last and loads again when the
+ * cloud has changed in place in between (pcl_compat.hpp; PCL itself would see the new points through its pointer:
+ * incremental_icp.hpp:57-59 sets both inputs before every align anyway). */
+int rsreg_cloud_version(const rsreg_cloud *cloud, uint64_t *id, uint64_t *version);
 int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
 /* ApproximateVoxelGrid::filter, same records in the same order as the host filter; in == out allowed */
 int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);

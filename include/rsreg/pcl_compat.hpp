@@ -52,6 +52,14 @@ inline void check(int status, rsreg_ctx *ctx = nullptr)
     throw Error(status, msg);
 }
 
+// (id, version) of a device cloud: the pair changes whenever its records in HBM are rewritten (rsreg_cloud_version)
+inline std::pair<uint64_t, uint64_t> cloud_stamp(const rsreg_cloud *c)
+{
+    uint64_t id = 0, version = 0;
+    check(rsreg_cloud_version(c, &id, &version));
+    return {id, version};
+}
+
 // ---- pcl::PointXYZRGB: 32 bytes, 16-byte aligned, rgb at byte 16
 struct alignas(16) PointXYZRGB {
     float x = 0.f, y = 0.f, z = 0.f, data3 = 1.f;
@@ -352,14 +360,20 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     {
         if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
         rsreg_ctx *c = ctx_->get();
+        // a device cloud rewritten in place since it was loaded (filter(x, x), +=, a transform or an alignment into it) is
+        // loaded again: PCL would see the new points through its pointer
+        if (!source_dirty_ && cloud_stamp(dsource_->handle()) != source_stamp_) source_dirty_ = true;
+        if (!target_dirty_ && cloud_stamp(dtarget_->handle()) != target_stamp_) target_dirty_ = true;
         if (source_dirty_ || ctx_->icp_source_owner != this) {
             check(rsreg_icp_set_source_cloud(c, dsource_->handle()), c);
+            source_stamp_ = cloud_stamp(dsource_->handle());
             source_dirty_ = false;
             ctx_->icp_source_owner = this;
         }
         if (target_dirty_ || ctx_->icp_target_owner != this) {
             if (!(reuse_target_index_ && rsreg_icp_target_is_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance)))
                 check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
+            target_stamp_ = cloud_stamp(dtarget_->handle());
             target_dirty_ = false;
             ctx_->icp_target_owner = this;
         }
@@ -381,6 +395,7 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     const DeviceCloud<PointSource> *dsource_ = nullptr;
     const DeviceCloud<PointTarget> *dtarget_ = nullptr;
     bool source_dirty_ = true, target_dirty_ = true, reuse_target_index_ = false;
+    std::pair<uint64_t, uint64_t> source_stamp_{0, 0}, target_stamp_{0, 0};   // (id, version) of the device clouds as loaded
 };
 
 // ---- pcl::NormalDistributionsTransform
@@ -402,6 +417,13 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
         prm_.resolution = r;
     }
     void setMaximumIterations(int n) { prm_.max_iterations = n; }
+    // engine extra: search the voxels by PCL's own centroid arithmetic (float running sum per voxel in input order,
+    // rsreg_ndt_set_centroid_mode) instead of the rounded f64 mean
+    void setPclCentroids(bool on)
+    {
+        if (on != pcl_centroids_) target_dirty_ = true;
+        pcl_centroids_ = on;
+    }
     void setInputSource(const SourcePtr &cloud) { source_ = cloud; dsource_ = nullptr; }
     void setInputTarget(const TargetPtr &cloud) { target_ = cloud; dtarget_ = nullptr; target_dirty_ = true; }
 
@@ -411,6 +433,7 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
         if (!source_ || !target_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget not called");
         rsreg_ctx *c = ctx_->get();
         if (target_dirty_ || ctx_->ndt_target_owner != this) {
+            check(rsreg_ndt_set_centroid_mode(c, pcl_centroids_ ? 1 : 0), c);
             check(rsreg_ndt_set_target(c, target_->points.data(), target_->size(), sizeof(PointTarget), target_->is_dense,
                                        prm_.resolution), c);
             target_dirty_ = false;
@@ -430,8 +453,11 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
     {
         if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
         rsreg_ctx *c = ctx_->get();
+        if (!target_dirty_ && cloud_stamp(dtarget_->handle()) != target_stamp_) target_dirty_ = true;   // rewritten in place since
         if (target_dirty_ || ctx_->ndt_target_owner != this) {
+            check(rsreg_ndt_set_centroid_mode(c, pcl_centroids_ ? 1 : 0), c);
             check(rsreg_ndt_set_target_cloud(c, dtarget_->handle(), prm_.resolution), c);
+            target_stamp_ = cloud_stamp(dtarget_->handle());
             target_dirty_ = false;
             ctx_->ndt_target_owner = this;
         }
@@ -453,7 +479,8 @@ template <typename PointSource, typename PointTarget> class NormalDistributionsT
     TargetPtr target_;
     const DeviceCloud<PointSource> *dsource_ = nullptr;
     const DeviceCloud<PointTarget> *dtarget_ = nullptr;
-    bool target_dirty_ = true;
+    bool target_dirty_ = true, pcl_centroids_ = false;
+    std::pair<uint64_t, uint64_t> target_stamp_{0, 0};   // (id, version) of the device target as loaded
 };
 
 // ---- pcl::ApproximateVoxelGrid (host, sequential: order-dependent by definition)
@@ -579,6 +606,29 @@ inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
         else if (fields[k] == "rgb" || fields[k] == "rgba") ic = (int)k;
     }
     if (ix < 0 || iy < 0 || iz < 0) return -2;
+    // the header is untrusted input: every field needs a SIZE and a TYPE, sizes are positive, and the fields this reader
+    // copies four bytes of (x, y, z, the packed colour) are four bytes wide; the body must fit what is left of the file
+    if (sizes.size() != fields.size() || types.size() != fields.size()) return -2;
+    for (int sz : sizes)
+        if (sz <= 0 || sz > 8) return -2;
+    if (sizes[ix] != 4 || sizes[iy] != 4 || sizes[iz] != 4 || (ic >= 0 && sizes[ic] != 4)) return -2;
+    size_t remaining = 0;
+    {
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end = f.tellg();
+        f.seekg(here);
+        if (here < 0 || end < here) return -4;
+        remaining = (size_t)(end - here);
+    }
+    {
+        size_t rec_bytes = 0;
+        for (int sz : sizes) rec_bytes += (size_t)sz;
+        // ascii needs at least "0 " per field; the binary forms are checked exactly below
+        const size_t least = data_mode == "binary" ? rec_bytes : (data_mode == "ascii" ? 2 * fields.size() - 1 : 0);
+        if (n > 0 && least > 0 && n > remaining / least + 1) return -4;
+        if (n > (size_t)1 << 32) return -4;
+    }
     cloud.points.assign(n, PointXYZRGB());
     cloud.width = width;
     cloud.height = height;
@@ -588,7 +638,7 @@ inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
             PointXYZRGB &p = cloud.points[i];
             for (size_t k = 0; k < fields.size(); ++k) {
                 std::string tok;
-                f >> tok;
+                if (!(f >> tok)) return -4;
                 if ((int)k == ic) {
                     if (types[k] == "F") { float v = std::stof(tok); std::memcpy(&p.rgba, &v, 4); }
                     else p.rgba = (uint32_t)std::stoul(tok);
@@ -603,8 +653,10 @@ inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
         size_t rec = 0;
         std::vector<size_t> off(fields.size());
         for (size_t k = 0; k < fields.size(); ++k) { off[k] = rec; rec += (size_t)sizes[k]; }
+        if (rec * n > remaining) return -4;
         std::vector<char> buf(rec * n);
         f.read(buf.data(), (std::streamsize)buf.size());
+        if ((size_t)f.gcount() != buf.size()) return -4;
         for (size_t i = 0; i < n; ++i) {
             PointXYZRGB &p = cloud.points[i];
             const char *r = buf.data() + i * rec;
@@ -622,7 +674,7 @@ inline int loadPCDFile(const std::string &path, PointCloud<PointXYZRGB> &cloud)
         size_t rec = 0;
         std::vector<size_t> foff(fields.size());
         for (size_t k = 0; k < fields.size(); ++k) { foff[k] = rec * n; rec += (size_t)sizes[k]; }
-        if (!f || (size_t)usize != rec * n) return -4;
+        if (!f || (size_t)usize != rec * n || remaining < 8 || (size_t)csize > remaining - 8) return -4;
         std::vector<uint8_t> comp(csize), soa(usize);
         f.read(reinterpret_cast<char *>(comp.data()), (std::streamsize)csize);
         if (!f || (usize && lzf::decode(comp.data(), csize, soa.data(), usize) != usize)) return -4;

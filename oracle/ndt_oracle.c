@@ -215,6 +215,13 @@ int orc_ndt_get_voxels(orc_ndt *o, int32_t *n_voxels, double *mci, int32_t *coun
     return 0;
 }
 
+/* the search centroids of the valid leaves, 3 floats each (what the radius search of computeDerivatives runs on) */
+int orc_ndt_get_centroids(orc_ndt *o, float *centroids, int32_t cap)
+{
+    for (int i = 0; i < o->n_leaves && i < cap; i++) memcpy(centroids + 3 * i, o->leaves[i].centroid, 12);
+    return 0;
+}
+
 static void gauss_constants(orc_ndt *o, const orc_ndt_params *prm)
 {
     double c1 = 10.0 * (1 - prm->outlier_ratio);

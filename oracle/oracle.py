@@ -119,6 +119,7 @@ def lib():
         L.orc_ndt_set_centroid_mode.restype = None
         L.orc_ndt_set_target.argtypes = [vp, vp, sz, sz, i32, dbl]
         L.orc_ndt_get_voxels.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, C.c_int32]
+        L.orc_ndt_get_centroids.argtypes = [vp, vp, C.c_int32]
         L.orc_ndt_derivatives.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(dbl), vp, vp]
         L.orc_ndt_align.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp, sz]
         _lib = L
@@ -237,6 +238,13 @@ class NdtOracle:
         c = np.zeros(n.value, np.int32)
         lib().orc_ndt_get_voxels(self._h, C.byref(n), m.ctypes.data, c.ctypes.data, n.value)
         return m, c
+
+    def centroids(self):
+        n = C.c_int32(0)
+        lib().orc_ndt_get_voxels(self._h, C.byref(n), None, None, 0)
+        out = np.zeros((n.value, 3), np.float32)
+        lib().orc_ndt_get_centroids(self._h, out.ctypes.data, n.value)
+        return out
 
     def derivatives(self, src, pose, params):
         a, p, n, s = _pts(src)

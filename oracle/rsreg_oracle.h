@@ -121,6 +121,7 @@ void orc_ndt_destroy(orc_ndt *o);
 void orc_ndt_set_centroid_mode(orc_ndt *o, int mode); /* 0 PCL f32 running sum, 1 f64 mean rounded */
 int orc_ndt_set_target(orc_ndt *o, const void *pts, size_t n, size_t stride, int is_dense,
                        double resolution);
+int orc_ndt_get_centroids(orc_ndt *o, float *centroids /*3 each*/, int32_t capacity);
 int orc_ndt_get_voxels(orc_ndt *o, int32_t *n_voxels, double *mean_cov_icov, int32_t *counts,
                        int32_t capacity);
 int orc_ndt_derivatives(orc_ndt *o, const void *src, size_t n, size_t stride, int is_dense,

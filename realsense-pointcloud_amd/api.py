@@ -151,6 +151,13 @@ class DeviceCloud:
         return self.info()[0]
 
     @property
+    def stamp(self):
+        """(id, version): changes whenever the records in HBM are rewritten (upload, filter, transform, concat, align into it)."""
+        import ctypes as C
+        i, v = C.c_uint64(), C.c_uint64()
+        _l.check(_l.lib().rsreg_cloud_version(self.h, C.byref(i), C.byref(v)))
+        return (i.value, v.value)
+
     def device_ptr(self):
         return _l.lib().rsreg_cloud_device_ptr(self.h)
 
@@ -263,10 +270,17 @@ class IterativeClosestPoint:
             raise ValueError("setInputSource / setInputTarget not called")
         # the source first, as the reference does (incremental_icp.hpp:57-58): the library loads it on a stream of its own,
         # beside the target's index build
+        # a device cloud rewritten in place since it was loaded (filter(x, x), +=, a transform or an alignment into it) is
+        # loaded again, as PCL would see the new points through its pointer
+        if isinstance(self._src, DeviceCloud) and getattr(self, "_src_stamp", None) != self._src.stamp:
+            self._src_dirty = True
+        if isinstance(self._tgt, DeviceCloud) and getattr(self, "_tgt_stamp", None) != self._tgt.stamp:
+            self._tgt_dirty = True
         if self._src_dirty or self.ctx.icp_source_owner is not self:
             if isinstance(self._src, DeviceCloud):
                 _l.check(L.rsreg_icp_set_source_cloud(h, self._src.h), h)
                 n = len(self._src)
+                self._src_stamp = self._src.stamp
             elif isinstance(self._src, tuple):
                 _, p, n, s = self._src
                 _l.check(L.rsreg_icp_set_source_device(h, p, n, s, 0), h)
@@ -282,6 +296,7 @@ class IterativeClosestPoint:
                 # (reuse_target_index: another ICP object of this context has just built the index of this very cloud)
                 if not (self.reuse_target_index and L.rsreg_icp_target_is_cloud(h, self._tgt.h, self.params.max_correspondence_distance)):
                     _l.check(L.rsreg_icp_set_target_cloud(h, self._tgt.h, self.params.max_correspondence_distance), h)
+                self._tgt_stamp = self._tgt.stamp
             elif isinstance(self._tgt, tuple):
                 _, p, n, s = self._tgt
                 _l.check(L.rsreg_icp_set_target_device(h, p, n, s, 0, self.params.max_correspondence_distance), h)
@@ -371,6 +386,21 @@ class NormalDistributionsTransform:
         self._src = self._tgt = None
         self._tgt_dirty = True
         self.result = None
+        self._pcl_centroids = False
+
+    def setPclCentroids(self, on):
+        """Engine extra: search the voxels by PCL's own centroid arithmetic (a float running sum per voxel in input order,
+        rsreg_ndt_set_centroid_mode) instead of the rounded f64 mean."""
+        if bool(on) != self._pcl_centroids:
+            self._tgt_dirty = True
+        self._pcl_centroids = bool(on)
+
+    def centroids(self):
+        n = C.c_int32(0)
+        _l.check(_l.lib().rsreg_ndt_get_voxels(self.ctx.h, C.byref(n), None, None, 0), self.ctx.h)
+        out = np.zeros((n.value, 3), np.float32)
+        _l.check(_l.lib().rsreg_ndt_get_centroids(self.ctx.h, out.ctypes.data, n.value), self.ctx.h)
+        return out
 
     def setTransformationEpsilon(self, e):
         self.params.transformation_epsilon = float(e)
@@ -396,9 +426,13 @@ class NormalDistributionsTransform:
     def _sync_target(self):
         if self._tgt is None or self._src is None:
             raise ValueError("setInputSource / setInputTarget not called")
+        if isinstance(self._tgt, DeviceCloud) and getattr(self, "_tgt_stamp", None) != self._tgt.stamp:
+            self._tgt_dirty = True   # (rewritten in place since the voxel grid was built)
         if self._tgt_dirty or self.ctx.ndt_target_owner is not self:
+            _l.check(_l.lib().rsreg_ndt_set_centroid_mode(self.ctx.h, 1 if self._pcl_centroids else 0), self.ctx.h)
             if isinstance(self._tgt, DeviceCloud):
                 _l.check(_l.lib().rsreg_ndt_set_target_cloud(self.ctx.h, self._tgt.h, self.params.resolution), self.ctx.h)
+                self._tgt_stamp = self._tgt.stamp
             else:
                 keep, p, n, s = _records(self._tgt)
                 _l.check(_l.lib().rsreg_ndt_set_target(self.ctx.h, p, n, s, int(getattr(self._tgt, "is_dense", False)),

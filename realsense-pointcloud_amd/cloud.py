@@ -105,6 +105,8 @@ def load_pcd(path):
     n = int(hdr.get("POINTS", [width * height])[0])
     mode = hdr["DATA"][0].lower()
     assert all(c == 1 for c in counts), "COUNT != 1 unsupported"
+    if len(sizes) != len(fields) or len(types) != len(fields) or any(s <= 0 for s in sizes) or n < 0:
+        raise ValueError("malformed PCD header")
     if mode == "ascii":
         text = raw[pos:].decode("ascii").split()
         cols = len(fields)
@@ -120,9 +122,14 @@ def load_pcd(path):
     elif mode == "binary_compressed":
         # u32 compressed size, u32 uncompressed size, one LZF stream over the fields laid out
         # one after the other (all x, all y, ...)
-        csize, usize = np.frombuffer(raw, "<u4", count=2, offset=pos)
-        body = _lzf("rsreg_lzf_decode", raw[pos + 8:pos + 8 + int(csize)], int(usize))
-        if len(body) != int(usize) or int(usize) != n * sum(sizes):
+        if len(raw) < pos + 8:
+            raise ValueError("truncated binary_compressed PCD")
+        csize, usize = (int(v) for v in np.frombuffer(raw, "<u4", count=2, offset=pos))
+        # validate before anything is allocated from the (untrusted) header fields
+        if usize != n * sum(sizes) or pos + 8 + csize > len(raw):
+            raise ValueError("corrupt binary_compressed PCD: sizes in the header do not match the file")
+        body = _lzf("rsreg_lzf_decode", raw[pos + 8:pos + 8 + csize], usize)
+        if len(body) != usize:
             raise ValueError("corrupt binary_compressed PCD body")
         col, off = {}, 0
         for k, name in enumerate(fields):

@@ -79,6 +79,12 @@ hipError_t settle(const rsreg_cloud *c)
 void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
 {
     if (!b.ptr) return;
+    // a target set without an index (scan_target) still reads the cloud's own records, and rsreg_icp_begin may build the
+    // index from them later: once the buffer changes hands that target is gone
+    if (ctx->scan_raw && ctx->scan_raw >= static_cast<const char *>(b.ptr) && ctx->scan_raw < static_cast<const char *>(b.ptr) + b.cap) {
+        ctx->scan_raw = nullptr;
+        if (ctx->grid.dense == 2) ctx->have_target = false;
+    }
     CloudPool &pool = ctx->cloud_pool;
     if (b.cap <= pool.limit && pool.held + b.cap <= pool.limit) {
         if (ctx->src_pending) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_src_done, 0);
@@ -181,6 +187,7 @@ int rsreg_cloud_destroy(rsreg_cloud *c)
     (void)hipSetDevice(c->ctx->device);
     (void)settle(c);
     if (c->ev_filled) (void)hipEventDestroy(c->ev_filled);
+    if (c->ctx->src_cloud == c) c->ctx->src_cloud = nullptr;   // (rsreg_icp_align_cloud then refuses to write an aligned cloud)
     cloud_drop(c->ctx, c->buf);
     delete c;
     return RSREG_OK;
@@ -421,6 +428,16 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
 
 // pcl::PointCloud::operator+ / += (incremental_icp.hpp:64, icp_edge...hpp:119-120): out = a followed by b;
 // out may be a (the append of `target += transformed` then costs only the copy of b) or b
+const rsreg_ctx *rsreg_cloud_ctx_(const rsreg_cloud *c) { return c ? c->ctx : nullptr; }   // (internal: edges.hip)
+
+int rsreg_cloud_version(const rsreg_cloud *c, uint64_t *id, uint64_t *version)
+{
+    if (!c) return RSREG_ERR_INVALID_ARG;
+    if (id) *id = c->id;
+    if (version) *version = c->version;
+    return RSREG_OK;
+}
+
 int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b, rsreg_cloud *out)
 {
     int rc = check_pair(ctx, a, b);
@@ -437,8 +454,13 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     } else {
         DevBuf fresh;
         RSREG_HIP(ctx, cloud_reserve(ctx, fresh, total * stride + (out == a ? total * stride / 2 : 0) + 16));   // a growing model: room for the next frames
-        if (na) RSREG_HIP(ctx, hipMemcpyAsync(fresh.ptr, a->buf.ptr, na * stride, hipMemcpyDeviceToDevice, ctx->stream));
-        if (nb) RSREG_HIP(ctx, hipMemcpyAsync(static_cast<char *>(fresh.ptr) + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
+        hipError_t e = hipSuccess;
+        if (na) e = hipMemcpyAsync(fresh.ptr, a->buf.ptr, na * stride, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && nb) e = hipMemcpyAsync(static_cast<char *>(fresh.ptr) + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            cloud_drop(ctx, fresh);   // (DevBuf has no destructor: hand the buffer back before reporting the error)
+            RSREG_HIP(ctx, e);
+        }
         cloud_drop(ctx, out->buf);   // (a or b may be `out`: its old buffer is reused only by work queued after these copies)
         out->buf = fresh;
     }
@@ -481,6 +503,8 @@ int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
     int rc = rsreg_icp_set_source_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense);
     if (rc) return rc;
     ctx->src_cloud = c;
+    ctx->src_cloud_id = c->id;
+    ctx->src_cloud_version = c->version;
     return RSREG_OK;
 }
 
@@ -490,6 +514,9 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
 {
     if (!ctx || !params || !result) return RSREG_ERR_INVALID_ARG;
     if (aligned_out && (aligned_out->ctx != ctx || !ctx->src_cloud)) return fail(ctx, RSREG_ERR_STATE, "rsreg_icp_set_source_cloud not called");
+    // the aligned cloud is the SOURCE CLOUD's records under the final transform: the handle must still be the cloud that was loaded
+    if (aligned_out && (ctx->src_cloud->id != ctx->src_cloud_id || ctx->src_cloud->version != ctx->src_cloud_version))
+        return fail(ctx, RSREG_ERR_STATE, "the source cloud was rewritten after rsreg_icp_set_source_cloud");
     RSREG_HIP(ctx, settle(aligned_out));
     int rc = rsreg_icp_align(ctx, guess, params, result, nullptr, 0);
     if (rc || !aligned_out) return rc;

@@ -32,6 +32,7 @@ extern "C" {
 const void *rsreg_cloud_device_ptr(const rsreg_cloud *c);
 int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *width, uint32_t *height, int *is_dense);
 int rsreg_cloud_adopt_(rsreg_cloud *c, DevBuf *buf, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense);   // cloud.hip
+const rsreg_ctx *rsreg_cloud_ctx_(const rsreg_cloud *c);   // cloud.hip: the context a handle belongs to
 }
 
 namespace {
@@ -302,6 +303,8 @@ int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t wid
 int rsreg_cloud_edge_features(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
 {
     if (!ctx || !in || !out) return RSREG_ERR_INVALID_ARG;
+    // like every other rsreg_cloud_* operation: both handles belong to THIS context (its stream, scratch and device)
+    if (rsreg_cloud_ctx_(in) != ctx || rsreg_cloud_ctx_(out) != ctx) return RSREG_ERR_INVALID_ARG;
     size_t n = 0, stride = 0;
     uint32_t w = 0, h = 0;
     int dense = 0;

@@ -1340,6 +1340,7 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     }
     if (ctx->grid.dense == 2 && (ctx->n_work > kScanMaxSource || filters_on(*params))) {
         // the target was set for a handful of queries (scan_target); this alignment needs the index after all
+        if (!ctx->scan_raw) return fail(ctx, RSREG_ERR_NO_TARGET, "the target cloud was released before its index was built");
         int rcb = build_grid(ctx, ctx->scan_raw, ctx->n_target_raw, ctx->scan_stride, ctx->gate_built_for);
         if (rcb) return rcb;
     }

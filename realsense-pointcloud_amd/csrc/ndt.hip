@@ -519,6 +519,14 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     RSREG_HIP(ctx, hipGetLastError());
     std::vector<double> stats((size_t)nseg * 10);
     RSREG_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->d_ndt_out.ptr, stats.size() * 8, hipMemcpyDeviceToHost, st));
+    std::vector<float> csum;   // PCL-mode centroids (rsreg_ndt_set_centroid_mode)
+    if (ctx->ndt_centroid_mode == 1) {
+        csum.resize((size_t)nseg * 3);
+        RSREG_HIP(ctx, ctx->d_scan.reserve(std::max<size_t>(n * 4, (size_t)nseg * 12)));   // (sid is no longer needed)
+        k_ndt_voxel_csum<<<nseg, 64, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_scan.as<float>());
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, hipMemcpyAsync(csum.data(), ctx->d_scan.ptr, csum.size() * 4, hipMemcpyDeviceToHost, st));
+    }
     RSREG_HIP(ctx, hipStreamSynchronize(st));
 
     // ---- host: mean, single-pass covariance, eigenvalue floor, inverse (App. A.6)
@@ -560,7 +568,8 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
         std::memset(&nv, 0, sizeof(nv));
         for (int k = 0; k < 3; ++k) {
             nv.mean[k] = mean[k];
-            nv.centroid[k] = (float)mean[k];  // PCL: f32 running sum / n; here the f64 mean rounded
+            // PCL: f32 running sum / n (mode 1); default: the f64 mean rounded
+            nv.centroid[k] = csum.empty() ? (float)mean[k] : csum[(size_t)v * 3 + k];
         }
         std::memcpy(nv.icov, icov, sizeof(icov));
         table.push_back(nv);
@@ -590,6 +599,22 @@ int rsreg_ndt_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
     if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
     return rsreg_ndt_set_target_device(ctx, n ? ctx->d_tgt_raw.ptr : nullptr, n, 12, is_dense, resolution);
+}
+
+int rsreg_ndt_set_centroid_mode(rsreg_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != 0 && mode != 1)) return RSREG_ERR_INVALID_ARG;
+    ctx->ndt_centroid_mode = mode;
+    return RSREG_OK;
+}
+
+int rsreg_ndt_get_centroids(rsreg_ctx *ctx, float *centroids, int32_t capacity)
+{
+    if (!ctx || (capacity > 0 && !centroids)) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->have_ndt_target) return fail(ctx, RSREG_ERR_NO_TARGET, "rsreg_ndt_set_target not called");
+    const int m = std::min<int>(capacity, ctx->ndt_n_voxels);
+    if (m > 0) std::memcpy(centroids, ctx->ndt_centroid.data(), (size_t)m * 3 * sizeof(float));
+    return RSREG_OK;
 }
 
 int rsreg_ndt_get_voxels(rsreg_ctx *ctx, int32_t *n_voxels, double *mean_cov_icov, int32_t *counts, int32_t capacity)

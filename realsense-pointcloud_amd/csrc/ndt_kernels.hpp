@@ -124,6 +124,36 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_voxel_stats(const uint32_t *v
     if (threadIdx.x == 0) out[(size_t)v * 10] = (double)(e - b);
 }
 
+// PCL's voxel centroid (VoxelGridCovariance::applyFilter: leaf.centroid += pt for every point in input order, all in
+// float; leaf.centroid /= float(n)): a sequential float chain per voxel and component.  One wave per voxel: the wave
+// stages 64 points at a time in LDS (the sort by voxel is stable, so a segment lists its points in input order),
+// lanes 0-2 add one component each.  out[v*3 + k] = centroid component k.
+__global__ __launch_bounds__(64) void k_ndt_voxel_csum(const uint32_t *vals, const uint32_t *seg_begin, const char *pts, size_t stride,
+                                                       float *out)
+{
+    const uint32_t v = blockIdx.x, lane = threadIdx.x;
+    const uint32_t b = seg_begin[v], e = seg_begin[v + 1];
+    __shared__ float sh[2][3][64];
+    float s = 0.0f;
+    int buf = 0;
+    if (b + lane < e) {
+        const float *p = reinterpret_cast<const float *>(pts + (size_t)vals[b + lane] * stride);
+        sh[0][0][lane] = p[0]; sh[0][1][lane] = p[1]; sh[0][2][lane] = p[2];
+    }
+    for (uint32_t i0 = b; i0 < e; i0 += 64, buf ^= 1) {
+        __syncthreads();
+        if (i0 + 64 + lane < e) {   // the next chunk while this one is added
+            const float *p = reinterpret_cast<const float *>(pts + (size_t)vals[i0 + 64 + lane] * stride);
+            sh[buf ^ 1][0][lane] = p[0]; sh[buf ^ 1][1][lane] = p[1]; sh[buf ^ 1][2][lane] = p[2];
+        }
+        if (lane < 3) {
+            const uint32_t cnt = min(64u, e - i0);
+            for (uint32_t k = 0; k < cnt; ++k) s = __fadd_rn(s, sh[buf][lane][k]);
+        }
+    }
+    if (lane < 3) out[(size_t)v * 3 + lane] = __fdiv_rn(s, (float)(e - b));
+}
+
 __device__ __forceinline__ double dot3d(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // f32 transform of a source record by the pose, PCL's operation order

@@ -147,6 +147,7 @@ struct rsreg_ctx {
     // ---- ICP source
     bool have_source = false;
     const struct rsreg_cloud *src_cloud = nullptr;   // set by rsreg_icp_set_source_cloud: where the aligned cloud's records come from
+    uint64_t src_cloud_id = 0, src_cloud_version = 0;   // ... as it was then: a handle destroyed or rewritten since is refused (RSREG_ERR_STATE)
     size_t n_source = 0;          // source points handed in
     size_t n_work = 0;            // distinct source points the iteration works on (exact copies merged)
     // the source is loaded on a stream of its own (so that it runs beside the target's index build when the
@@ -189,6 +190,7 @@ struct rsreg_ctx {
     // ---- NDT
     bool have_ndt_target = false;
     double ndt_resolution = 0;
+    int ndt_centroid_mode = 0;              // 1: PCL's float running sum per voxel (rsreg_ndt_set_centroid_mode)
     int ndt_n_voxels = 0;
     rsreg::DevBuf d_scan_keys;           // no-index search (scan_target): one (distance, index) key per source point
     const char *scan_raw = nullptr;      // ... and the records the index is built from if an alignment needs it after all

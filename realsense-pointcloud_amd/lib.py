@@ -14,6 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip", "edges.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
 NUM_SUMS = 17
+RSREG_ERR_INVALID_ARG, RSREG_ERR_STATE = -1, -9   # include/rsreg.h: rsreg_status
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/rsreg.h declares (checked by tests/test_abi.py)
@@ -25,10 +26,10 @@ EXPORTS = [
     "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_begin",
     "rsreg_icp_search", "rsreg_icp_sums", "rsreg_icp_update", "rsreg_icp_end",
     "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
-    "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels",
+    "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels", "rsreg_ndt_set_centroid_mode", "rsreg_ndt_get_centroids",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
     "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_upload_async", "rsreg_cloud_download", "rsreg_cloud_info",
-    "rsreg_cloud_device_ptr", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_filter_async", "rsreg_cloud_transform", "rsreg_cloud_concat",
+    "rsreg_cloud_device_ptr", "rsreg_cloud_version", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_filter_async", "rsreg_cloud_transform", "rsreg_cloud_concat",
     "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
     "rsreg_extract_edge_features", "rsreg_cloud_edge_features",
@@ -163,6 +164,8 @@ def lib():
     L.rsreg_ndt_align.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp, sz]
     L.rsreg_ndt_derivatives.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(dbl), vp, vp]
     L.rsreg_ndt_get_voxels.argtypes = [vp, C.POINTER(C.c_int32), vp, vp, C.c_int32]
+    L.rsreg_ndt_set_centroid_mode.argtypes = [vp, C.c_int]
+    L.rsreg_ndt_get_centroids.argtypes = [vp, vp, C.c_int32]
     L.rsreg_comm_unique_id.argtypes = [vp]
     L.rsreg_comm_init.argtypes = [vp, vp, i32, i32]
     L.rsreg_comm_destroy.argtypes = [vp]
@@ -177,6 +180,7 @@ def lib():
     L.rsreg_cloud_info.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)]
     L.rsreg_cloud_device_ptr.argtypes = [vp]
     L.rsreg_cloud_device_ptr.restype = vp
+    L.rsreg_cloud_version.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rsreg_cloud_copy.argtypes = [vp, vp, vp]
     L.rsreg_cloud_filter.argtypes = [vp, vp, vp, vp]
     L.rsreg_cloud_filter_async.argtypes = [vp, vp, vp, vp]

@@ -344,3 +344,62 @@ def test_filter_async_equals_filter(api, rs, frames, leaf):
         icp.align()
         res.append((icp.getFinalTransformation().tobytes(), icp.result.n_correspondences))
     assert res[0] == res[1]
+
+
+def test_device_cloud_rewritten_in_place_is_loaded_again(api, rs, frames):
+    """PCL reads its inputs through pointers: a cloud rewritten in place between two align() calls is what the second
+    one registers.  The wrappers compare (id, version) of a device cloud with what they loaded (rsreg_cloud_version)
+    and load it again; the C ABI itself refuses to write an aligned cloud from a source handle that has changed or
+    gone since rsreg_icp_set_source_cloud (RSREG_ERR_STATE) instead of touching freed memory."""
+    import ctypes as C
+
+    from rsreg_amd import lib
+    L = lib.lib()
+    ctx = api.Context(0)
+    prm = dict(max_iterations=3, criteria_mode=1, max_correspondence_distance=0.05)
+    tgt, src = api.DeviceCloud(frames[0], ctx), api.DeviceCloud(frames[2], ctx)
+    icp = api.IterativeClosestPoint(ctx)
+    icp.params = api.icp_params(**prm)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    icp.align()
+    s0 = src.stamp
+    assert src.stamp == s0 and tgt.stamp[0] != s0[0]
+    tgt.append(api.DeviceCloud(frames[1], ctx))          # target grown in place, setInputTarget not called again
+    T = rs.synth.small_transform(0.4, (0.002, 0.001, -0.003)).astype(np.float32)
+    _check = lib.check
+    _check(L.rsreg_cloud_transform(ctx.h, src.h, np.ascontiguousarray(T.T).ctypes.data, src.h), ctx.h)   # source moved in place
+    assert src.stamp == (s0[0], s0[1] + 1)
+    icp.align()
+    fresh = api.IterativeClosestPoint(api.Context(0))
+    fresh.params = api.icp_params(**prm)
+    fresh.setInputSource(api.transformPointCloud(frames[2], T))
+    fresh.setInputTarget(frames[0] + frames[1])
+    fresh.align()
+    assert icp.getFinalTransformation().tobytes() == fresh.getFinalTransformation().tobytes()
+    ndt = api.NormalDistributionsTransform(ctx)
+    ndt.setInputSource(src)
+    ndt.setInputTarget(tgt)
+    ndt.align()
+    n0 = ndt.result.n_voxels
+    tgt.append(api.DeviceCloud(api.transformPointCloud(frames[1], rs.synth.small_transform(0.0, (0.0, 3.0, 0.0)).astype(np.float32)), ctx))
+    ndt.align()                                           # the voxel grid is rebuilt from the grown cloud
+    assert ndt.result.n_voxels > n0
+
+    # C ABI: the source handle is destroyed (or rewritten) before the aligned cloud is asked for
+    gone = api.DeviceCloud(frames[2], ctx)
+    out = api.DeviceCloud(ctx=ctx)
+    res, p = lib.IcpResult(), api.icp_params(**prm)
+    _check(L.rsreg_icp_set_source_cloud(ctx.h, gone.h), ctx.h)
+    _check(L.rsreg_icp_set_target_cloud(ctx.h, tgt.h, 0.05), ctx.h)
+    gone.close()
+    assert L.rsreg_icp_align_cloud(ctx.h, None, C.byref(p), C.byref(res), out.h) == lib.RSREG_ERR_STATE
+    assert L.rsreg_icp_align_cloud(ctx.h, None, C.byref(p), C.byref(res), None) == 0      # the 4x4 alone needs no handle
+    again = api.DeviceCloud(frames[2], ctx)
+    _check(L.rsreg_icp_set_source_cloud(ctx.h, again.h), ctx.h)
+    again.upload(frames[1])
+    assert L.rsreg_icp_align_cloud(ctx.h, None, C.byref(p), C.byref(res), out.h) == lib.RSREG_ERR_STATE
+    # edge extraction checks that both handles belong to the context it is called on
+    other_ctx = api.Context(0)
+    organized = api.DeviceCloud(rs.synth.render_frame(0, (64, 48), "parity"), ctx)
+    assert L.rsreg_cloud_edge_features(other_ctx.h, organized.h, out.h) == lib.RSREG_ERR_INVALID_ARG

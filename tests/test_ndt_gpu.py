@@ -97,6 +97,46 @@ def test_align_matches_oracle(api, orc, rs, edge_like, guess_kind):
         assert np.linalg.norm(n.getFinalTransformation() - gt) < np.linalg.norm(np.eye(4) - gt)
 
 
+@pytest.mark.parametrize("resolution", [1.0, 0.3])
+def test_pcl_centroid_mode_is_bit_equal_to_the_oracles_pcl_mode(api, orc, rs, edge_like, resolution):
+    """rsreg_ndt_set_centroid_mode(1): the voxels are searched by PCL's own centroid -- a float running sum over the
+    voxel's points in input order, divided by float(n) (VoxelGridCovariance::applyFilter) -- bit for bit what the
+    oracle's mode 0 computes, so that a pin against a real PCL build can be exact instead of "< 1e-4"; the alignment in
+    that mode agrees with the oracle in that mode as tightly as the default modes agree with each other."""
+    tgt, src = edge_like
+    shuffled = rs.PointCloud(np.ascontiguousarray(tgt.points[np.random.default_rng(5).permutation(len(tgt))]))
+    for cloud in (tgt, shuffled):                          # the sum depends on the input order: both orders must agree with the oracle
+        n = api.NormalDistributionsTransform(api.default_context())
+        n.params = api.ndt_params(reference=True)
+        n.setResolution(resolution)
+        n.setPclCentroids(True)
+        n.setInputSource(src)
+        n.setInputTarget(cloud)
+        guess = rs.synth.small_transform(0.5, (0.0, 0.0, 0.0)).astype(np.float32)
+        n.align(guess)
+        o = orc.NdtOracle()
+        o.set_centroid_mode(0)
+        o.set_target(cloud.points, resolution)
+        cg, co = n.centroids(), o.centroids()
+        assert cg.shape == co.shape and len(cg) > 3
+        np.testing.assert_array_equal(cg.view(np.uint32), co.view(np.uint32))
+        po = orc.NdtParams.reference()
+        po.resolution = resolution
+        ro = o.align(src.points, guess, po)
+        r = n.result
+        assert (r.converged, r.iterations, r.n_voxels, r.n_derivative_passes) == (ro.converged, ro.iterations, ro.n_voxels, ro.n_derivative_passes)
+        assert np.linalg.norm(n.getFinalTransformation() - ro.T) < 1e-5
+    # the default mode is what it was: the rounded f64 mean
+    d = api.NormalDistributionsTransform(api.default_context())
+    d.params = api.ndt_params(reference=True)
+    d.setResolution(resolution)
+    d.setInputSource(src)
+    d.setInputTarget(tgt)
+    d.align()
+    m, _ = d.voxels()
+    np.testing.assert_array_equal(d.centroids(), m[:, 0:3].astype(np.float32))
+
+
 @pytest.mark.parametrize("resolution", [0.3, 0.12])
 def test_many_voxels_several_table_chunks(api, orc, rs, edge_like, resolution):
     """The derivative pass stages the voxel table through LDS 64 voxels at a time and deals (point, voxel) pairs to the

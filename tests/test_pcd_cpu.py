@@ -144,3 +144,54 @@ def test_pcd_cross_language(tmp_path, rs, L):
     subprocess.run([exe, e, b, "binary_compressed"], check=True, stdout=subprocess.PIPE)
     _same(rs.load_pcd(b), c)
     assert subprocess.run([exe, str(tmp_path / "missing.pcd"), b, "binary"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
+
+
+def test_malformed_pcd_headers_are_rejected_under_asan(tmp_path, rs, L):
+    """An untrusted header must never index past what it declares (the binary_compressed branch used to copy four
+    bytes per field whatever SIZE said): the C++ reader, built with the CPU AddressSanitizer, rejects every malformed
+    file below with a status instead of reading out of bounds; the Python reader raises."""
+    from rsreg_amd import lib
+    exe = str(tmp_path / "pcd_convert_asan")
+    # header-only path: lzf.hpp + pcl_compat.hpp; the io functions need nothing from librsreg.so at run time, but the
+    # header declares the C ABI, so the library is linked like in the cross-language test
+    pkg = os.path.dirname(lib.SO_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "pcd_convert.cpp"), "-o", exe, "-L", pkg, "-lrsreg", "-Wl,-rpath," + pkg,
+                    "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+    c = _cloud(rs, 40, 30)
+    good = str(tmp_path / "good.pcd")
+    rs.save_pcd(good, c, compressed=True)
+    raw = open(good, "rb").read()
+    head, body = raw.split(b"DATA binary_compressed\n", 1)
+    n = len(c)
+
+    def hdr(fields="x y z rgb", size="4 4 4 4", typ="F F F F", points=n, mode="binary_compressed"):
+        return ("# .PCD v0.7\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+                "POINTS %d\nDATA %s\n" % (fields, size, typ, " ".join("1" for _ in fields.split()), points, points, mode)).encode()
+
+    soa1 = bytes(3 * n)   # what SIZE 1 1 1 promises: three bytes per point
+    cases = {
+        "size1": hdr("x y z", "1 1 1", "U U U") + np.array([len(_enc(L, soa1)), len(soa1)], "<u4").tobytes() + _enc(L, soa1),
+        "short_sizes": hdr(size="4 4") + body,
+        "negative_size": hdr(size="4 4 -4 4") + body,
+        "huge_csize": hdr() + np.array([0xfffffff0, 16 * n], "<u4").tobytes() + body[8:],
+        "huge_usize": hdr() + np.array([len(body) - 8, 0xfffffff0], "<u4").tobytes() + body[8:],
+        "truncated_body": hdr() + body[:-30],
+        "no_sizes_at_all": hdr().replace(b"SIZE 4 4 4 4\n", b"") + body,
+        "binary_too_short": hdr(mode="binary") + bytes(16 * n - 5),
+        "points_beyond_file": hdr(points=1 << 30, mode="binary") + bytes(64),
+    }
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    for name, blob in cases.items():
+        p = str(tmp_path / (name + ".pcd"))
+        open(p, "wb").write(blob)
+        r = subprocess.run([exe, p, str(tmp_path / "out.pcd"), "binary"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        assert r.returncode == 1 and "loadPCDFile" in r.stderr and "AddressSanitizer" not in r.stderr, (name, r.returncode, r.stderr[-600:])
+        if name == "size1":   # a consistent file of one-byte fields: the Python reader handles any field width
+            assert len(rs.load_pcd(p)) == n
+        else:
+            with pytest.raises((ValueError, KeyError, AssertionError)):
+                rs.load_pcd(p)
+    r = subprocess.run([exe, good, str(tmp_path / "out.pcd"), "binary"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-600:]

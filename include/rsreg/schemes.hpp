@@ -18,6 +18,7 @@
 #include <cassert>
 #include <functional>
 #include <iostream>
+#include <string>
 #include <utility>
 
 #include "pcl_compat.hpp"
@@ -41,7 +42,10 @@ class RegistrationScheme {
   public:
     virtual ~RegistrationScheme() = default;
     virtual rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) = 0;
-    bool verbose = false;  // the reference prints progress lines to stdout
+    // true: the reference's progress lines on stdout, text for text (types.hpp:35-41, icp_edge_based_registration.hpp:27-32,
+    // 94-96,103-104,110,113,122,127, ndt_edge_based_registration.hpp:24-29,82-84,91-93,98,101,110,114); IncrementalICP
+    // prints nothing in the reference either.  Off by default: a library does not write to its caller's stdout.
+    bool verbose = false;
     // true (default): the frame loop runs on clouds resident in HBM -- a frame is uploaded once, every
     // step takes and leaves its clouds on the GPU, only what the caller gets back is downloaded.
     // false: every step on host clouds (one upload + download per step).  Same records either way.
@@ -64,7 +68,12 @@ class TwoPhaseRegistrationScheme : public RegistrationScheme {
     rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
     {
         PairList pairs;
-        for (auto &c : clouds) pairs.emplace_back(extract_features(c), c);   // phase 1
+        for (auto &c : clouds) {                                              // phase 1
+            if (verbose) std::cout << "[PCL] Extracting features..." << std::flush;
+            pairs.emplace_back(extract_features(c), c);
+            if (verbose) std::cout << "OK" << std::endl;
+        }
+        if (verbose) std::cout << "[PCL] Performing global registration..." << std::endl;
         return global_registration(pairs);                                    // phase 2
     }
     FeatureFn feature_fn;
@@ -160,11 +169,57 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) override
     {
         if (!device_resident || feature_fn) return TwoPhaseRegistrationScheme::registration(clouds);
+        if (verbose) {   // the same lines in the same order; the features themselves are extracted as each frame reaches the GPU
+            for (size_t k = 0; k < clouds.size(); ++k) std::cout << "[PCL] Extracting features..." << "OK" << std::endl;
+            std::cout << "[PCL] Performing global registration..." << std::endl;
+        }
         return global_registration_device(nullptr, &clouds);
     }
     std::vector<std::pair<Matrix4f, Matrix4f>> frame_transforms;  // (coarse, refine) per merged frame
+    // ICPEdgeBasedRegistration writes files while it runs (icp_edge_based_registration.hpp:66-69,126): every frame's edge
+    // cloud as <dir>/edge-<k>.pcd (frame 0's already voxel-filtered, the others as extracted) and the grown edge target
+    // as <dir>/edge_cloud.pcd at the end, all with savePCDFileBinary.  Opt-in here (a library does not write into its
+    // caller's working directory unasked); the directory must exist, as in the reference ("dataset").  The NDT scheme
+    // writes nothing in the reference and nothing here.
+    bool write_byproducts = false;
+    std::string byproduct_dir = "dataset";
 
   protected:
+    virtual const char *coarse_name() const = 0;       // "ICP" / "NDT": the reference's "Performing <name> iteration [k]..."
+    virtual bool has_byproducts() const { return false; }
+    bool byproducts_on() const { return write_byproducts && has_byproducts(); }
+    void save_edge(size_t k, const rgb_point_cloud &edge) const
+    {
+        if (io::savePCDFileBinary(byproduct_dir + "/edge-" + std::to_string(k) + ".pcd", edge) != 0)
+            throw Error(RSREG_ERR_INVALID_ARG, "rsreg: cannot write " + byproduct_dir + "/edge-" + std::to_string(k) + ".pcd");
+    }
+    void save_edge(size_t k, const rgb_device_cloud &edge) const
+    {
+        rgb_point_cloud host;
+        edge.download(host);
+        save_edge(k, host);
+    }
+    void save_edge_cloud(const rgb_point_cloud &target) const
+    {
+        if (io::savePCDFileBinary(byproduct_dir + "/edge_cloud.pcd", target) != 0)
+            throw Error(RSREG_ERR_INVALID_ARG, "rsreg: cannot write " + byproduct_dir + "/edge_cloud.pcd");
+    }
+    void say_header() const
+    {
+        if (!verbose) return;
+        std::cout << "[PCL] Performing edge-based registration";
+        if (use_imu) std::cout << " with dynamic initial rotation guesses..." << std::endl;
+        else std::cout << " with static initial rotation guesses..." << std::endl;
+    }
+    void say_iteration(const char *what, size_t k) const
+    {
+        if (verbose) std::cout << "[PCL]   Performing " << what << " iteration [" << k << "]..." << std::flush;
+    }
+    void say(const char *text) const
+    {
+        if (verbose) std::cout << text << std::endl;
+    }
+
     Matrix4f next_guess(size_t k, float &acc_rads)
     {
         if (use_imu) {
@@ -180,6 +235,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     rgb_point_cloud_pointer global_registration_device(PairList *pairs, std::vector<rgb_point_cloud_pointer> *frames)
     {
         const size_t n_frames = pairs ? pairs->size() : frames->size();
+        say_header();
         if (use_imu) assert(n_frames == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
@@ -192,6 +248,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         else extract_edge_features(merged, target);
         if (!pairs && n_frames > 1) fulls[1].upload_async(*(*frames)[1]);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
+        if (byproducts_on()) save_edge(0, target);   // (the reference writes all edge-k.pcd before the loop; the files are the same)
         float acc_rads = 0.f;
         frame_transforms.clear();
         for (size_t k = 1; k < n_frames; ++k) {
@@ -201,13 +258,21 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
                 if (k + 1 < n_frames) fulls[(k + 1) & 1].upload_async(*(*frames)[k + 1]);   // on the link while frame k is aligned
                 extract_edge_features(full, features);
             }
+            if (byproducts_on()) save_edge(k, features);
             voxel.filter(features, reduced);
             const Matrix4f guess = next_guess(k, acc_rads);
+            say_iteration(coarse_name(), k);
             const Matrix4f t_coarse = coarse_align_device(reduced, target, coarse_out, guess);
+            say("OK");
             icp.setInputSource(coarse_out);
             icp.setInputTarget(target);
+            say_iteration("ICP", k);
             icp.align(refined);
-            if (!icp.hasConverged()) continue;   // frame dropped silently, like the reference
+            if (!icp.hasConverged()) {   // frame dropped, like the reference
+                say("");
+                continue;
+            }
+            say("OK");
             if (pairs) full.upload(*(*pairs)[k].second);
             transformPointCloud(full, moved, t_coarse);
             transformPointCloud(moved, moved, icp.getFinalTransformation());
@@ -216,6 +281,12 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
         }
         if (pairs) target.download(*(*pairs)[0].first);   // the caller's frame-0 feature cloud has become the grown target
+        if (byproducts_on()) {
+            rgb_point_cloud grown;
+            if (pairs) save_edge_cloud(*(*pairs)[0].first);
+            else { target.download(grown); save_edge_cloud(grown); }
+        }
+        say("[PCL] Done");
         auto out = std::make_shared<rgb_point_cloud>();
         merged.download(*out);
         out->width = (uint32_t)out->size();   // `*merged = *merged + ...`: an unorganized cloud whatever came in
@@ -225,6 +296,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
 
     rgb_point_cloud_pointer global_registration_host(PairList &clouds)
     {
+        say_header();
         if (use_imu) assert(clouds.size() == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
@@ -238,6 +310,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         voxel.setInputCloud(target);
         voxel.filter(*target);
         auto reduced = std::make_shared<rgb_point_cloud>();
+        if (byproducts_on())
+            for (size_t k = 0; k < clouds.size(); ++k) save_edge(k, *clouds[k].first);   // icp_edge_based_registration.hpp:66-69
         float acc_rads = 0.f;
         frame_transforms.clear();
         for (size_t k = 1; k < clouds.size(); ++k) {
@@ -246,11 +320,18 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             voxel.setInputCloud(clouds[k].first);
             voxel.filter(*reduced);
             const Matrix4f guess = next_guess(k, acc_rads);
+            say_iteration(coarse_name(), k);
             const Matrix4f t_coarse = coarse_align(reduced, target, *coarse_out, guess);
+            say("OK");
             icp.setInputSource(coarse_out);
             icp.setInputTarget(target);
+            say_iteration("ICP", k);
             icp.align(refined);
-            if (!icp.hasConverged()) continue;   // frame dropped silently, like the reference
+            if (!icp.hasConverged()) {   // frame dropped, like the reference
+                say("");
+                continue;
+            }
+            say("OK");
             rgb_point_cloud moved;
             transformPointCloud(*clouds[k].second, moved, t_coarse);
             transformPointCloud(moved, moved, icp.getFinalTransformation());
@@ -258,6 +339,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             *merged = *merged + moved;
             frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
         }
+        if (byproducts_on()) save_edge_cloud(*target);   // icp_edge_based_registration.hpp:126
+        say("[PCL] Done");
         return merged;
     }
 
@@ -277,6 +360,8 @@ class ICPEdgeBasedRegistration : public EdgeBasedRegistrationBase {
   public:
     using EdgeBasedRegistrationBase::EdgeBasedRegistrationBase;
   protected:
+    const char *coarse_name() const override { return "ICP"; }
+    bool has_byproducts() const override { return true; }
     void configure_coarse() override { detail::reference_icp_parameters(coarse_); }
     Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
                           const Matrix4f &guess) override
@@ -306,6 +391,7 @@ class NDTEdgeBasedRegistration : public EdgeBasedRegistrationBase {
   public:
     using EdgeBasedRegistrationBase::EdgeBasedRegistrationBase;
   protected:
+    const char *coarse_name() const override { return "NDT"; }
     void configure_coarse() override
     {
         ndt_.setTransformationEpsilon(0.01);

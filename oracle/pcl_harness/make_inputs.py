@@ -19,4 +19,7 @@ for k in (0, 1):
 for k in range(4):
     rsreg_amd.save_pcd(os.path.join(out, "chain-%d.pcd" % k), synth.render_frame(k, "50k", "parity"))
 np.savetxt(os.path.join(out, "guess.txt"), synth.small_transform(0.1, (0.0, 0.0, 0.0)))
+# the per-frame yaw the edge schemes are constructed with: the "parity" preset's 0.15 degrees per frame, negative like the
+# reference's default (icp_edge_based_registration.hpp:133)
+open(os.path.join(out, "rads.txt"), "w").write("%.9g\n" % -0.0026179939)
 print("inputs written to", out)

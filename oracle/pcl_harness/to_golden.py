@@ -24,9 +24,15 @@ for name in sorted(os.listdir(os.path.join(ref, "out"))):
     p = os.path.join(ref, "out", name)
     key = os.path.splitext(name)[0]
     out[key] = read_matrix(p) if name.endswith(".txt") else rsreg_amd.load_pcd(p).points
+    if name.endswith("binary_compressed.pcd"):   # the file itself, byte for byte: the LZF stream PCL wrote
+        out[key + "_bytes"] = np.frombuffer(open(p, "rb").read(), np.uint8)
 for name in ("pair-0", "pair-1", "chain-0", "chain-1", "chain-2", "chain-3"):
     out["in_" + name.replace("-", "")] = rsreg_amd.load_pcd(os.path.join(ref, "inputs", name + ".pcd")).points
 out["in_guess"] = np.loadtxt(os.path.join(ref, "inputs", "guess.txt"))
+out["in_rads"] = np.loadtxt(os.path.join(ref, "inputs", "rads.txt")).reshape(1)
+for name in ("chain-0", "chain-1", "chain-2", "chain-3"):   # the frames are organized: keep their shape
+    c = rsreg_amd.load_pcd(os.path.join(ref, "inputs", name + ".pcd"))
+    out["in_" + name.replace("-", "") + "_shape"] = np.array([c.width, c.height])
 dst = os.path.join(ROOT, "tests", "golden", "pcl_pin.npz")
 np.savez_compressed(dst, **out)
 print("wrote", dst, "with", sorted(out))

@@ -116,8 +116,16 @@ def _assign(dst, src):
 
 
 class RegistrationScheme:
+    # True: the reference's progress lines on stdout, text for text (types.hpp:35-41, icp_edge_based_registration.hpp:27-32,
+    # 94-96,103-104,110,113,122,127, ndt_edge_based_registration.hpp:24-29,82-84,91-93,98,101,110,114)
+    verbose = False
+
     def __init__(self, backend=None):
         self.backend = backend or HipDeviceBackend()
+
+    def _say(self, text, end="\n"):
+        if self.verbose:
+            print(text, end=end, flush=True)
 
     def registration(self, clouds):
         raise NotImplementedError
@@ -136,7 +144,16 @@ class TwoPhaseRegistrationScheme(RegistrationScheme):
         # a frame goes to the GPU once: its features are extracted there and both stay there for the frame loop
         # (a plugged-in feature_fn is a host function: it gets, and returns, host clouds)
         if self.feature_fn:
-            return self.global_registration([(self.extract_features(f), f) for f in clouds])
+            pairs = []
+            for f in clouds:
+                self._say("[PCL] Extracting features...", end="")
+                pairs.append((self.extract_features(f), f))
+                self._say("OK")
+            self._say("[PCL] Performing global registration...")
+            return self.global_registration(pairs)
+        for _ in clouds:   # the same lines in the same order; the features themselves are extracted as each frame reaches the GPU
+            self._say("[PCL] Extracting features...OK")
+        self._say("[PCL] Performing global registration...")
         return self.global_registration(_FramePairs(self, clouds))
 
 
@@ -207,6 +224,20 @@ class IncrementalICP(RegistrationScheme):
 
 
 class _EdgeBased(TwoPhaseRegistrationScheme):
+    coarse_name = "ICP"
+    has_byproducts = False
+    # ICPEdgeBasedRegistration writes files while it runs (icp_edge_based_registration.hpp:66-69,126): every frame's edge
+    # cloud as <dir>/edge-<k>.pcd (frame 0's already voxel-filtered, the others as extracted) and the grown edge target as
+    # <dir>/edge_cloud.pcd, all with savePCDFileBinary.  Opt-in; the directory must exist (the reference's "dataset").
+    write_byproducts = False
+    byproduct_dir = "dataset"
+
+    def _save(self, name, cloud):
+        import os
+
+        from .cloud import save_pcd
+        save_pcd(os.path.join(self.byproduct_dir, name), cloud if isinstance(cloud, PointCloud) else self.backend.download(cloud), binary=True)
+
     def __init__(self, thetas=None, rads=-0.523599, backend=None):
         super().__init__(backend)
         self.thetas = None if thetas is None else [list(map(float, t)) for t in thetas]
@@ -221,6 +252,8 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
 
     def global_registration(self, pairs):
         b = self.backend
+        self._say("[PCL] Performing edge-based registration with %s initial rotation guesses..." % ("dynamic" if self.use_imu else "static"))
+        by = self.write_byproducts and self.has_byproducts
         if self.use_imu:
             assert len(pairs) == len(self.thetas)
         icp = b.icp()
@@ -231,9 +264,13 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         merged = b.upload(pairs[0][1])
         voxel.setInputCloud(b.upload(pairs[0][0]))
         target = voxel.filter()                    # frame-0 features: filtered in place, then grown
+        if by:
+            self._save("edge-0.pcd", target)       # (the reference writes all edge-k.pcd before the loop; the files are the same)
         acc = np.float32(0.0)
         self.frame_transforms = []
         for k in range(1, len(pairs)):
+            if by:
+                self._save("edge-%d.pcd" % k, pairs[k][0])
             voxel.setInputCloud(b.upload(pairs[k][0]))
             reduced = voxel.filter()
             if self.use_imu:
@@ -245,13 +282,18 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
                 guess = rot_y(float(acc))
             coarse.setInputSource(reduced)
             coarse.setInputTarget(target)
+            self._say("[PCL]   Performing %s iteration [%d]..." % (self.coarse_name, k), end="")
             coarse_out = coarse.align(guess)
+            self._say("OK")
             t_coarse = coarse.getFinalTransformation()
             icp.setInputSource(coarse_out)
             icp.setInputTarget(target)
+            self._say("[PCL]   Performing ICP iteration [%d]..." % k, end="")
             refined = icp.align()
             if not icp.hasConverged():
+                self._say("")
                 continue
+            self._say("OK")
             moved = b.transform(b.upload(pairs[k][1]), t_coarse)
             moved = b.transform(moved, icp.getFinalTransformation())
             target = b.concat(refined, target)     # new points first
@@ -259,11 +301,16 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
         if isinstance(pairs[0][0], PointCloud):
             _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
+        if by:
+            self._save("edge_cloud.pcd", target)
+        self._say("[PCL] Done")
         out = b.download(merged)
         return PointCloud(out.points, width=len(out), height=1, is_dense=out.is_dense)
 
 
 class ICPEdgeBasedRegistration(_EdgeBased):
+    has_byproducts = True
+
     def _coarse(self):
         return self.backend.icp()
 
@@ -272,6 +319,8 @@ class ICPEdgeBasedRegistration(_EdgeBased):
 
 
 class NDTEdgeBasedRegistration(_EdgeBased):
+    coarse_name = "NDT"
+
     def _coarse(self):
         return self.backend.ndt()
 

@@ -63,6 +63,14 @@ int main(int argc, char **argv)
         rgb_point_cloud_pointer out;
         // RSREG_SCHEME_HOST_LOOP=1: every step of the frame loop on host clouds instead of cloud handles in HBM
         const bool host_loop = std::getenv("RSREG_SCHEME_HOST_LOOP") && std::getenv("RSREG_SCHEME_HOST_LOOP")[0] == '1';
+        // RSREG_SCHEME_VERBOSE=1: the reference's progress lines on stdout; RSREG_SCHEME_BYPRODUCTS=<dir>: the edge-<k>.pcd /
+        // edge_cloud.pcd files ICPEdgeBasedRegistration writes while it runs (icp_edge_based_registration.hpp:66-69,126)
+        const bool verbose = std::getenv("RSREG_SCHEME_VERBOSE") && std::getenv("RSREG_SCHEME_VERBOSE")[0] == '1';
+        const char *by_dir = std::getenv("RSREG_SCHEME_BYPRODUCTS");
+        auto observables = [&](EdgeBasedRegistrationBase &s) {
+            s.verbose = verbose;
+            if (by_dir) { s.write_byproducts = true; s.byproduct_dir = by_dir; }
+        };
         if (mode == "incremental") {
             IncrementalICP s;
             s.device_resident = !host_loop;
@@ -73,11 +81,13 @@ int main(int argc, char **argv)
             if (mode == "icp_edge") {
                 ICPEdgeBasedRegistration s(rads);
                 s.device_resident = !host_loop;
+                observables(s);
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             } else {
                 NDTEdgeBasedRegistration s(rads);
                 s.device_resident = !host_loop;
+                observables(s);
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             }

@@ -73,3 +73,56 @@ def test_reference_example_pcd_files(rs):
         else:
             want = np.array([int(r[3]) for r in data], np.uint32)
         np.testing.assert_array_equal(c.points["rgba"], want)
+
+
+def test_icp_edge_scheme_prints_and_writes_what_the_reference_does(tmp_path, orc, rs, capsys):
+    """The observable by-products of ICPEdgeBasedRegistration (icp_edge_based_registration.hpp:27-32,66-69,94-96,110-127,
+    types.hpp:35-41): the progress lines on stdout, text for text, and dataset/edge-<k>.pcd + dataset/edge_cloud.pcd
+    written with savePCDFileBinary -- frame 0's edge cloud already voxel-filtered (`:59-60` run before `:66-69`), the
+    others as extracted, the grown edge target at the end.  Scheme logic: the product's; building blocks: the CPU checker."""
+    from oracle_backend import OracleBackend
+    from rsreg_amd import schemes
+    clouds = [rs.synth.render_frame(k, (160, 120), "parity") for k in range(3)]
+    out_dir = tmp_path / "dataset"
+    out_dir.mkdir()
+    s = schemes.ICPEdgeBasedRegistration(rads=-0.0026, backend=OracleBackend())
+    s.feature_fn = s.backend.edge_features            # host pairs: the reference's own two-phase flow
+    feats = [s.backend.edge_features(c) for c in clouds]
+    s.verbose, s.write_byproducts, s.byproduct_dir = True, True, str(out_dir)
+    merged = s.registration(clouds)
+    text = capsys.readouterr().out
+    n_ok = len(s.frame_transforms)
+    want = "[PCL] Extracting features...OK\n" * 3 + "[PCL] Performing global registration...\n" \
+        "[PCL] Performing edge-based registration with static initial rotation guesses...\n"
+    for k in (1, 2):
+        want += "[PCL]   Performing ICP iteration [%d]...OK\n" % k
+        want += "[PCL]   Performing ICP iteration [%d]...%s\n" % (k, "OK" if True else "")
+    want += "[PCL] Done\n"
+    assert n_ok == 2 and text == want, text
+    assert sorted(p.name for p in out_dir.iterdir()) == ["edge-0.pcd", "edge-1.pcd", "edge-2.pcd", "edge_cloud.pcd"]
+    e0 = rs.load_pcd(str(out_dir / "edge-0.pcd"))
+    filt = orc.approx_voxel_grid(np.ascontiguousarray(feats[0].points), (0.01, 0.01, 0.01))
+    np.testing.assert_array_equal(e0.xyz, np.stack([filt["x"], filt["y"], filt["z"]], 1))     # frame 0: filtered in place first
+    for k in (1, 2):
+        ek = rs.load_pcd(str(out_dir / ("edge-%d.pcd" % k)))
+        np.testing.assert_array_equal(ek.xyz, feats[k].xyz)                                    # the others: as extracted
+        np.testing.assert_array_equal(ek.points["rgba"], feats[k].points["rgba"])
+    grown = rs.load_pcd(str(out_dir / "edge_cloud.pcd"))
+    assert len(grown) > len(e0) and grown.height == 1
+    assert open(str(out_dir / "edge_cloud.pcd"), "rb").read(400).count(b"DATA binary\n") == 1
+    assert len(merged) == sum(len(c) for c in clouds)
+    # the NDT scheme prints its own lines and writes nothing (ndt_edge_based_registration.hpp has no savePCDFile)
+    nd = tmp_path / "nd"
+    nd.mkdir()
+    s2 = schemes.NDTEdgeBasedRegistration(rads=-0.0026, backend=OracleBackend())
+    s2.feature_fn = s2.backend.edge_features
+    s2.verbose, s2.write_byproducts, s2.byproduct_dir = True, True, str(nd)
+    s2.registration([rs.synth.render_frame(k, (160, 120), "parity") for k in range(2)])
+    text2 = capsys.readouterr().out
+    assert "[PCL]   Performing NDT iteration [1]...OK\n[PCL]   Performing ICP iteration [1]..." in text2 and text2.endswith("[PCL] Done\n")
+    assert list(nd.iterdir()) == []
+    # off by default: nothing on stdout, no files
+    s3 = schemes.ICPEdgeBasedRegistration(rads=-0.0026, backend=OracleBackend())
+    s3.feature_fn = s3.backend.edge_features
+    s3.registration([rs.synth.render_frame(k, (160, 120), "parity") for k in range(2)])
+    assert capsys.readouterr().out == ""

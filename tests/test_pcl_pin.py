@@ -76,3 +76,86 @@ def test_engine_matches_pcl(pin, rs):
     ndt.setInputTarget(tgt)
     ndt.align(pin["in_guess"].astype(np.float32))
     assert np.linalg.norm(ndt.getFinalTransformation() - pin["ndt_reference_T"]) < 1e-4
+
+
+# ---- round 3: what the engine grew in round 2 (sections (6)-(10) of oracle/pcl_harness/pcl_pin.cpp).  Each block looks
+# for its keys: a fixture recorded with the older harness only turns on the tests above.
+
+def _organized(pin, rs, k):
+    w, h = (int(v) for v in pin["in_chain%d_shape" % k])
+    return rs.PointCloud(pin["in_chain%d" % k].copy(), width=w, height=h, is_dense=False)
+
+
+def _same_points(got, want):
+    assert len(got) == len(want)
+    for f in ("x", "y", "z", "rgba"):
+        np.testing.assert_array_equal(got[f], want[f])
+
+
+def test_oracle_round2_components_match_pcl(pin, orc, rs):
+    if "edge_features_chain0" not in pin.files:
+        pytest.skip("fixture predates the round-3 harness")
+    frame = _organized(pin, rs, 0)
+    idx = orc.edge_features(np.ascontiguousarray(frame.points), frame.width, frame.height)
+    _same_points(frame.points[idx], pin["edge_features_chain0"])                    # label_indices[4], index for index
+    tgt, src = pin["in_pair0"], pin["in_pair1"]
+    o = orc.IcpOracle()
+    o.set_target(tgt)
+    o.set_source(src)
+    for key, kw in (("reciprocal", dict(use_reciprocal=1)), ("trimmed", dict(trim_overlap_ratio=0.8))):
+        p = orc.IcpParams.reference()
+        p.accum_mode = 0
+        for k, v in kw.items():
+            setattr(p, k, v)
+        r = o.align(None, p)
+        assert np.linalg.norm(r.T - pin["icp_%s_T" % key]) < 1e-4
+        o.begin(None, p)
+        oi, od = o.search()
+        c = pin["corr_%s_it0" % key]
+        kept = np.full(len(src), -1, np.int64)
+        kept[c[:, 0].astype(np.int64)] = c[:, 1].astype(np.int64)
+        assert ((oi >= 0) == (kept >= 0)).mean() > 0.999 and (oi == kept).mean() > 0.999
+    # a PCL-written binary_compressed file reads back as the cloud it was written from
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pcd") as f:
+        f.write(pin["pair1_binary_compressed_bytes"].tobytes())
+        f.flush()
+        _same_points(rs.load_pcd(f.name).points, src)
+
+
+@pytest.mark.gpu
+def test_engine_round2_components_match_pcl(pin, rs, tmp_path):
+    if "edge_features_chain0" not in pin.files:
+        pytest.skip("fixture predates the round-3 harness")
+    from rsreg_amd import api, schemes
+    frames = [_organized(pin, rs, k) for k in range(4)]
+    _same_points(api.extract_edge_features(frames[0]).points, pin["edge_features_chain0"])
+    rads = float(pin["in_rads"][0])
+    d = tmp_path / "dataset"
+    d.mkdir()
+    s = schemes.ICPEdgeBasedRegistration(rads=rads)
+    s.write_byproducts, s.byproduct_dir = True, str(d)
+    merged = s.registration([f.copy() for f in frames])
+    want = pin["icp_edge_merged"]
+    assert len(merged) == len(want)
+    np.testing.assert_allclose(merged.xyz, np.stack([want["x"], want["y"], want["z"]], 1), atol=1e-4)
+    for k in range(4):
+        got = rs.load_pcd(str(d / ("edge-%d.pcd" % k)))
+        _same_points(got.points, pin["icp_edge_byproduct_edge%d" % k])               # extracted / filtered, not yet moved: exact
+    grown = rs.load_pcd(str(d / "edge_cloud.pcd"))
+    w = pin["icp_edge_byproduct_edge_cloud"]
+    assert len(grown) == len(w)
+    np.testing.assert_allclose(grown.xyz, np.stack([w["x"], w["y"], w["z"]], 1), atol=1e-4)
+    n = schemes.NDTEdgeBasedRegistration(rads=rads)
+    merged = n.registration([f.copy() for f in frames])
+    want = pin["ndt_edge_merged"]
+    assert len(merged) == len(want)
+    np.testing.assert_allclose(merged.xyz, np.stack([want["x"], want["y"], want["z"]], 1), atol=1e-4)
+    tgt, src = rs.PointCloud(pin["in_pair0"].copy()), rs.PointCloud(pin["in_pair1"].copy())
+    for key, kw in (("reciprocal", dict(use_reciprocal_correspondences=1)), ("trimmed", dict(trim_overlap_ratio=0.8))):
+        icp = api.IterativeClosestPoint()
+        icp.params = api.icp_params(reference=True, **kw)
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        icp.align()
+        assert np.linalg.norm(icp.getFinalTransformation() - pin["icp_%s_T" % key]) < 1e-4

@@ -152,3 +152,50 @@ def test_cpp_host_layer_matches_python_path(env, frames, runner, tmp_path, rs):
         assert len(T) == len(ref)
         for a, b in zip(T, ref):
             np.testing.assert_allclose(a, b, atol=2e-6)
+
+
+def test_cpp_scheme_observables(env, frames, runner, tmp_path, rs, capsys):
+    """`verbose` and `write_byproducts` of the C++ scheme classes (icp_edge_based_registration.hpp:27-32,66-69,94-127,
+    types.hpp:35-41): the same stdout text and the same files from the device-resident frame loop, the host-cloud frame
+    loop and the Python mirror; nothing printed or written unless asked."""
+    api, schemes = env
+    paths = []
+    for k, f in enumerate(frames):
+        p = str(tmp_path / ("frame-%d.pcd" % k))
+        rs.save_pcd(p, f)
+        paths.append(p)
+    outs = {}
+    for loop in ("device", "host"):
+        d = tmp_path / ("by_" + loop)
+        d.mkdir()
+        e = dict(os.environ, RSREG_SCHEME_VERBOSE="1", RSREG_SCHEME_BYPRODUCTS=str(d))
+        if loop == "host":
+            e["RSREG_SCHEME_HOST_LOOP"] = "1"
+        r = subprocess.run([runner, "icp_edge", str(tmp_path / ("obs_" + loop))] + paths, check=True, env=e, stdout=subprocess.PIPE, text=True)
+        outs[loop] = (r.stdout, {p.name: open(str(p), "rb").read() for p in d.iterdir()})
+    assert outs["device"][0] == outs["host"][0]
+    n = len(frames)
+    assert outs["device"][0].startswith("[PCL] Extracting features...OK\n" * n + "[PCL] Performing global registration...\n"
+                                        "[PCL] Performing edge-based registration with static initial rotation guesses...\n"
+                                        "[PCL]   Performing ICP iteration [1]...OK\n[PCL]   Performing ICP iteration [1]...")
+    assert outs["device"][0].endswith("[PCL] Done\n")
+    assert sorted(outs["device"][1]) == sorted(["edge-%d.pcd" % k for k in range(n)] + ["edge_cloud.pcd"])
+    assert outs["device"][1] == outs["host"][1]                      # byte for byte the same files
+    py_dir = tmp_path / "by_py"
+    py_dir.mkdir()
+    s = schemes.ICPEdgeBasedRegistration(rads=RADS)
+    s.verbose, s.write_byproducts, s.byproduct_dir = True, True, str(py_dir)
+    capsys.readouterr()
+    s.registration([f.copy() for f in frames])
+    assert capsys.readouterr().out == outs["device"][0]
+    for name, blob in outs["device"][1].items():
+        a, b = rs.load_pcd(str(py_dir / name)), rs.load_pcd(str(tmp_path / "by_device" / name))
+        assert len(a) == len(b)
+        np.testing.assert_allclose(a.xyz, b.xyz, atol=2e-5)
+    quiet = subprocess.run([runner, "ndt_edge", str(tmp_path / "quiet")] + paths, check=True, stdout=subprocess.PIPE, text=True)
+    assert quiet.stdout == ""
+    nd = tmp_path / "by_ndt"
+    nd.mkdir()
+    r = subprocess.run([runner, "ndt_edge", str(tmp_path / "obs_ndt")] + paths, check=True, stdout=subprocess.PIPE, text=True,
+                       env=dict(os.environ, RSREG_SCHEME_VERBOSE="1", RSREG_SCHEME_BYPRODUCTS=str(nd)))
+    assert "[PCL]   Performing NDT iteration [1]...OK\n" in r.stdout and list(nd.iterdir()) == []

@@ -45,6 +45,9 @@ def parse():
                     help="dev: take the multi-rank code path (process group, native RCCL transport, all-reduce per iteration) "
                          "even with one rank, e.g. under `torch.distributed.run --nproc-per-node 1`")
     ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the native RCCL transport (rsreg_comm_init) cannot be set up, carry the 17 sums over torch.distributed "
+                         "instead of exiting with an error (the line then says so in config.sharding)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
     ap.add_argument("--workload", default="pair", choices=["pair", "chain"],
                     help="pair: ONE 1M pair, source sharded over the ranks (configs[1]/[3], the headline line); "
@@ -241,6 +244,15 @@ def main():
         transport = "rccl-native" if int(flag.item()) == 1 else "torch-distributed"
         if transport != "rccl-native" and ok:
             lib.lib().rsreg_comm_destroy(ctx.h)
+        if transport != "rccl-native" and not a.allow_fallback:
+            # the line the driver records must be the transport BASELINE configs[3] names; a silent change of transport
+            # would be measured as if it were RCCL over xGMI
+            if rank == 0:
+                print("[bench] --gpus %d: the native RCCL transport is not available on every rank; re-run with --allow-fallback to "
+                      "measure the torch.distributed transport instead" % world, file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     import ctypes as C
 
@@ -369,6 +381,65 @@ def main():
                  "n_cells": int(gi.n_cells), "n_unique_points": n_unique, "n_source_distinct": n_distinct,
                  "index_bytes": int(gi.index_bytes)},
     }
+
+    # the roofline that binds (profiles/*_issue.json: SQ counters of this command + the VALU issue microbenchmark, both
+    # collected on MI355X; PMC counters cannot be read from inside this process)
+    try:
+        ij = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_issue.json"))
+        if ij and world == 1 and a.size == "N1M" and a.pipeline >= 1:
+            t = json.load(open(os.path.join(ROOT, "profiles", ij[-1])))
+            bound_us = t["valu_insts"] * t["ns_per_valu_inst_per_simd"] / t["simds"] * 1e-3
+            out["roofline_issue"] = {
+                "bound": "valu-issue", "kernel": kern, "valu_insts": t["valu_insts"], "salu_insts": t["salu_insts"], "vmem_insts": t["vmem_insts"],
+                "cycles_per_inst": t["cycles_per_inst_at_2p4ghz"], "ns_per_inst_per_simd": t["ns_per_valu_inst_per_simd"],
+                "cycles_per_inst_source": t["cycles_per_inst_source"], "simds": t["simds"], "bound_us": bound_us,
+                "avg_launch_us": avg_ms * 1e3, "frac": bound_us / (avg_ms * 1e3) if avg_ms > 0 else None,
+                "lane_utilisation": t.get("lane_utilisation"),
+                "source": "profiles/%s (static: rocprofv3 --pmc SQ_* passes of this command + tools/microbench/valu_issue.hip; the launch "
+                          "time is this run's)" % ij[-1],
+            }
+            out["roofline"]["binding"] = "VALU issue, not HBM: see roofline_issue (the contract's roofline stays the HBM one)"
+    except Exception:  # noqa: BLE001
+        pass
+    # the index build as a rate: SURVEY.md §8d prices it at 116 algorithmic bytes per target point
+    if ms_build > 0:
+        gb = 116.0 * n_tgt / (ms_build / a.steps * 1e-3) / 1e9
+        out["grid_build"] = {"ms": ms_build / a.steps, "algorithmic_bytes": 116 * n_tgt, "achieved": gb, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                             "frac": gb / HBM_PEAK_GBS}
+    if world == 1 and a.pipeline == 2:
+        # the north star's default pipeline next to the headline: fused kernel, 136 bytes to the host and a host 3x3
+        # solve per iteration (pipeline 1), without the HIP events of the roofline leg
+        ctx1 = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=False)
+        prm1 = api.icp_params(max_iterations=a.iterations, criteria_mode=1, pipeline_mode=1, max_correspondence_distance=a.max_dist)
+        res1 = lib.IcpResult()
+
+        def step1():
+            lib.check(L.rsreg_icp_set_source_device(ctx1.h, d_src.data_ptr(), n_src, stride, 0), ctx1.h)
+            lib.check(L.rsreg_icp_set_target_device(ctx1.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx1.h)
+            lib.check(L.rsreg_icp_align(ctx1.h, g.ctypes.data, C.byref(prm1), C.byref(res1), None, 0), ctx1.h)
+
+        for _ in range(2):
+            step1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps1 = max(3, min(a.steps, 10))
+        for _ in range(reps1):
+            step1()
+        torch.cuda.synchronize()
+        out["pipeline1_ms_per_step"] = (time.perf_counter() - t1) / reps1 * 1e3
+        out["pipeline1_same_transform"] = bool((api._rowmajor(res1.transform) == T_gpu).all())
+        # does ICP move the pair at all?  The headline's guess is 1 % of the motion off; from the identity (the whole
+        # motion of the "bench" preset off: 1.5 degrees, 16 mm) the same 30 iterations must close most of the gap
+        gt_ = synth.ground_truth(1, 0, "bench")
+        eye = np.ascontiguousarray(np.eye(4, dtype=np.float32))
+        lib.check(L.rsreg_icp_set_source_device(ctx1.h, d_src.data_ptr(), n_src, stride, 0), ctx1.h)
+        lib.check(L.rsreg_icp_set_target_device(ctx1.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx1.h)
+        prm2_ = api.icp_params(max_iterations=a.iterations, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=a.max_dist)
+        lib.check(L.rsreg_icp_align(ctx1.h, eye.ctypes.data, C.byref(prm2_), C.byref(res1), None, 0), ctx1.h)
+        out["convergence_from_identity"] = {
+            "initial_error_frobenius": float(np.linalg.norm(np.eye(4) - gt_)),
+            "final_error_frobenius": float(np.linalg.norm(api._rowmajor(res1.transform) - gt_)), "iterations": int(res1.iterations),
+            "note": "same pair and gate, guess = identity (the frame-to-frame motion of the bench preset is 1.5 degrees + 16 mm)"}
 
     if not a.no_cpu_baseline:
         import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product

@@ -139,8 +139,9 @@ def _pair_worker(rank, world, port, out_dir, size, iters):
     src = synth.render_frame(1, size, "bench")
     guess = synth.small_transform(*GUESS).astype(np.float32)
     lo, hi = sharded.shard_range(len(src), rank, world)
-    ctx = api.Context(0)
-    # native transport: one RCCL communicator over the two processes (RCCL may refuse two ranks
+    # rank r on device r where the box has that many GPUs: the first multi-GPU box runs ncclCommInitRank(nranks = 2) by itself
+    ctx = api.Context(rank if api.device_count() >= world else 0)
+    # native transport: one RCCL communicator over the two processes (RCCL refuses two ranks
     # on one device: then every rank agrees to carry the 17 sums over gloo instead)
     uid = [api.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, 0)

@@ -34,7 +34,8 @@ def _worker(rank, world, port, out_dir):
         dist.all_reduce(t)
         return t.numpy()
 
-    icp = api.IterativeClosestPoint(api.Context(0))
+    # one device per rank where the box has them (the first multi-GPU box then runs this test across GPUs by itself)
+    icp = api.IterativeClosestPoint(api.Context(rank if api.device_count() >= world else 0))
     icp.params = api.icp_params(max_iterations=6, criteria_mode=1, max_correspondence_distance=0.05)
     icp.setInputSource(np.ascontiguousarray(src.points[lo:hi]))
     icp.setInputTarget(tgt)
@@ -67,6 +68,62 @@ def test_two_ranks_one_gpu_matches_single_process(tmp_path, rs):
     m0, m1 = np.load(tmp_path / "meta_rank0.npy"), np.load(tmp_path / "meta_rank1.npy")
     np.testing.assert_array_equal(m0, m1)
     assert tuple(m0) == (icp.result.iterations, icp.result.state, icp.result.converged, icp.result.n_correspondences)
+
+
+def _worker_native(rank, world, port, out_dir):
+    """rank r on device r: ncclCommInitRank(nranks = world) and the all-reduce of the 17 sums inside rsreg_icp_align"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import rsreg_amd  # noqa: F401
+    from rsreg_amd import api, sharded, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # (only to hand the 128-byte id around)
+    box = [api.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx = api.Context(rank)
+    ctx.comm_init(box[0], rank, world)
+    tgt = synth.render_frame(0, "50k", "bench")
+    src = synth.render_frame(1, "50k", "bench")
+    guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    lo, hi = sharded.shard_range(len(src), rank, world)
+    out = []
+    for pipeline in (1, 2):                                            # host solve per iteration; device-resident loop
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=6, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=0.05)
+        icp.setInputSource(np.ascontiguousarray(src.points[lo:hi]))
+        icp.setInputTarget(tgt)
+        icp.align(guess)
+        out.append(api._rowmajor(icp.result.transform))
+        out.append(np.array([icp.result.iterations, icp.result.state, icp.result.converged, icp.result.n_correspondences], np.float64).reshape(1, 4).repeat(4, 0))
+    np.save(os.path.join(out_dir, "native_rank%d.npy" % rank), np.stack(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_rccl_transport_two_ranks_two_gpus(tmp_path, rs):
+    """BASELINE configs[3] over the native transport with more than one rank: needs two GPUs (RCCL refuses two ranks on
+    one device), so it runs by itself on the first multi-GPU box and is skipped, visibly, on the one-GPU boxes."""
+    import torch.multiprocessing as mp
+    from rsreg_amd import api, lib, synth
+    lib.build()
+    if api.device_count() < 2:
+        pytest.skip("one GPU on this box: ncclCommInitRank(nranks = 2) needs two devices (the 1-rank communicator is tested below)")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_native, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "native_rank0.npy"), np.load(tmp_path / "native_rank1.npy")
+    np.testing.assert_array_equal(a, b)                                # every rank solves the same sums: identical bits
+    np.testing.assert_array_equal(a[0], a[2])                          # both pipelines
+    tgt, src = synth.render_frame(0, "50k", "bench"), synth.render_frame(1, "50k", "bench")
+    icp = api.IterativeClosestPoint()
+    icp.params = api.icp_params(max_iterations=6, criteria_mode=1, max_correspondence_distance=0.05)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    icp.align(synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32))
+    assert np.linalg.norm(a[0] - icp.getFinalTransformation()) < 1e-6
+    assert tuple(a[1][0]) == (icp.result.iterations, icp.result.state, icp.result.converged, icp.result.n_correspondences)
 
 
 def test_native_rccl_transport_single_rank(rs):

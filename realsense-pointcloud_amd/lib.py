@@ -84,6 +84,7 @@ class GridInfo(C.Structure):
         ("n_target_points", C.c_uint32), ("n_unique_points", C.c_uint32), ("n_cells", C.c_uint32),
         ("max_points_per_cell", C.c_uint32), ("ms_build", C.c_double),
         ("index_kind", C.c_uint32), ("n_source_distinct", C.c_uint32), ("index_bytes", C.c_uint64),
+        ("n_updates", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

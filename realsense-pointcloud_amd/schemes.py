@@ -88,6 +88,10 @@ class HipBackend:
     def concat(self, a, b):
         return a + b
 
+    def concat_front(self, new, target):
+        """`*target = *new + *target` (icp_edge_based_registration.hpp:119): returns the grown target"""
+        return new + target
+
 
 class HipDeviceBackend(HipBackend):
     """The product path with the frame loop resident in HBM: a frame is uploaded once, every step
@@ -107,6 +111,11 @@ class HipDeviceBackend(HipBackend):
 
     def download(self, cloud):
         return cloud.download()
+
+    def concat_front(self, new, target):
+        # in place: the handle then knows it grew by len(new) records in front, and the index the refining ICP has just used
+        # is updated instead of rebuilt when the next frame's coarse aligner sets the grown cloud as its target
+        return target.prepend(new)
 
 
 def _assign(dst, src):
@@ -296,7 +305,7 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             self._say("OK")
             moved = b.transform(b.upload(pairs[k][1]), t_coarse)
             moved = b.transform(moved, icp.getFinalTransformation())
-            target = b.concat(refined, target)     # new points first
+            target = b.concat_front(refined, target) if hasattr(b, "concat_front") else b.concat(refined, target)     # new points first
             merged = b.concat(merged, moved)
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
         if isinstance(pairs[0][0], PointCloud):

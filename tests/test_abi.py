@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.IcpParams) == 64
     assert C.sizeof(L.NdtParams) == 40
     assert C.sizeof(L.IcpResult) == 64 + 16 + 8 + 8 + 17 * 8 + 4 * 8 + 8
-    assert C.sizeof(L.GridInfo) == 72
+    assert C.sizeof(L.GridInfo) == 80   # (round 3: + n_updates, reserved)
 
 
 def test_reference_presets(rs, L):

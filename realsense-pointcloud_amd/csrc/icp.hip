@@ -180,6 +180,8 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
     g.nbr = ctx->d_dense.as<uint32_t>() + g.table_bytes / 4;   // the occupancy words lie right behind the table (one memset clears both)
     g.pos_of = ctx->d_pos_of.as<uint32_t>();
+    static const uint32_t debug_skip = std::getenv("RSREG_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("RSREG_DEBUG_SKIP")) : 0u;   // timing experiments only
+    g.debug_skip = debug_skip;
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
     // how far the x order of a sorted run can be off: one bucket of the sort key (2^-xbits of a cell), plus the float

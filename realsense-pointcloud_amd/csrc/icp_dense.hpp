@@ -39,6 +39,7 @@ struct DenseDev {
     float x_slack;           // metres: slack on the x order of a sorted run (sort-key bucket + float rounding of the position)
     const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
     const uint32_t *pos_of;  // original index -> position in pts (kept points only)
+    uint32_t debug_skip;     // timing experiments only (RSREG_DEBUG_SKIP, results WRONG): 1 = no search beyond ring 1, 3 = nothing beyond the own cell
 };
 
 __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int y, int z)
@@ -529,7 +530,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     gx0 *= gx0; gx2 *= gx2; gy0 *= gy0; gy2 *= gy2; gz0 *= gz0; gz2 *= gz2;
     const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis: 0 is always a valid lower bound
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
-    if (!any_face || !(occ & ~(1u << 13))) return occ;
+    if (!any_face || !(occ & ~(1u << 13)) || (g.debug_skip & 2u)) return occ;
     uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
@@ -579,7 +580,7 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
 __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
 {
     const float reach = (1.0f - g.margin) * g.cell;   // ring 1 proves everything up to here
-    return g.max_ring >= 2 && limit2 > reach * reach;
+    return g.max_ring >= 2 && limit2 > reach * reach && !g.debug_skip;
 }
 
 // Everything beyond rings 0-1, row by row: the cells of one (y, z) row are one contiguous run of

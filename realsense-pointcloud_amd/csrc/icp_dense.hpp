@@ -495,10 +495,18 @@ __device__ __forceinline__ void dense_seed(const DRes &rs, const DQuery &q, int 
     }
 }
 
-// rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
+// what the ring-1 search of a query needs after its own cell has been read
+struct DRing1 {
+    float gx0, gx2, gy0, gy2, gz0, gz2;   // squared gaps (cell units, margin taken off) to the six neighbouring slabs
+    int base;                             // table index of the own cell
+    uint32_t mask;                        // bit j = dz*9 + dy*3 + dx: occupied neighbour whose box can hold something closer
+    bool right_half;
+};
+
+// ring 0: the seed and the query's own cell (it usually holds the nearest point), then which neighbours have to be opened
 template <bool kDiag = false>
-__device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b,
-                                               float &limit2, DSplit sp, DDiag *dg = nullptr)
+__device__ __forceinline__ uint32_t dense_own(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b, float &limit2,
+                                              DSplit sp, DRing1 &r1, DDiag *dg = nullptr)
 {
     const f32x2 qxy = {q.qx, q.qy};
     const float qz = q.qz;
@@ -511,7 +519,6 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     dense_seed(rs, q, seed_pos, b, limit2);
     // (an empty cell's table entry may be left over from an earlier build: k_dense_scatter writes occupied cells only)
     if (!(occ & (1u << 13))) se = u32x2{0u, 0u};
-    // ---- ring 0: the query's own cell (it usually holds the nearest point)
     const float x_slack = g.x_slack;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
     DWalk w;
@@ -529,6 +536,10 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
     float gz0 = axis_gap(q.uz, q.cz - 1, q.cz - 1, g.margin), gz2 = axis_gap(q.uz, q.cz + 1, q.cz + 1, g.margin);
     gx0 *= gx0; gx2 *= gx2; gy0 *= gy0; gy2 *= gy2; gz0 *= gz0; gz2 *= gz2;
     const float gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;   // own slab on that axis: 0 is always a valid lower bound
+    r1.gx0 = gx0; r1.gx2 = gx2; r1.gy0 = gy0; r1.gy2 = gy2; r1.gz0 = gz0; r1.gz2 = gz2;
+    r1.base = base;
+    r1.right_half = right_half;
+    r1.mask = 0;
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
     if (!any_face || !(occ & ~(1u << 13)) || (g.debug_skip & 2u)) return occ;
     uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
@@ -540,9 +551,23 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
                          (dz == 0 ? gz0 : (dz == 1 ? gz1 : gz2));
         mask |= (lb <= lim_c) ? (1u << j) : 0u;
     }
-    mask &= occ;         // empty cells are never opened
-    // flat loop: a trip moves on to the next plausible cell and/or scores 4 candidates.  The range
-    // of the cell after the current one is already in flight (nse) while the current one is scored.
+    r1.mask = mask & occ;         // empty cells are never opened
+    return occ;
+}
+
+// ring 1, lane by lane: a flat loop -- a trip moves on to the next plausible cell and/or scores 4 candidates.  The range
+// of the cell after the current one is already in flight (nse) while the current one is scored.
+template <bool kDiag = false>
+__device__ __forceinline__ void dense_ring1_lane(const DenseDev &g, const DRes &rs, const DQuery &q, const DRing1 &r1, uint32_t mask, DBest &b,
+                                                 float &limit2, DSplit sp, DDiag *dg = nullptr)
+{
+    if (!mask) return;
+    const f32x2 qxy = {q.qx, q.qy};
+    const float qz = q.qz, cell2 = g.cell * g.cell, x_slack = g.x_slack;
+    const float gx0 = r1.gx0, gx2 = r1.gx2, gy0 = r1.gy0, gy2 = r1.gy2, gz0 = r1.gz0, gz2 = r1.gz2, gx1 = 0.0f, gy1 = 0.0f, gz1 = 0.0f;
+    const int base = r1.base;
+    const bool right_half = r1.right_half;
+    DWalk w;
     w.left = 0;
     u32x2 nse = {0u, 0u};
     float nlb2 = 0.0f, nyz2 = 0.0f;
@@ -573,6 +598,16 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
             dwalk_step(w, b, rs.pts, qxy, qz, x_slack, limit2);
         }
     }
+}
+
+// rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
+template <bool kDiag = false>
+__device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b,
+                                               float &limit2, DSplit sp, DDiag *dg = nullptr)
+{
+    DRing1 r1;
+    const uint32_t occ = dense_own<kDiag>(g, rs, q, seed_pos, b, limit2, sp, r1, dg);
+    dense_ring1_lane<kDiag>(g, rs, q, r1, r1.mask, b, limit2, sp, dg);
     return occ;
 }
 

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SO_PATH = os.path.join(_HERE, "librsreg.so")
+SO_PATH = os.environ.get("RSREG_SO") or os.path.join(_HERE, "librsreg.so")   # (RSREG_SO: dev, an experiment build of the library)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip", "edges.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
@@ -91,8 +91,9 @@ class GridInfo(C.Structure):
 def hipcc_command(out=SO_PATH):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("RSREG_CXXFLAGS", "").split()   # (dev: -D switches of experiment builds)
     return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-            "-Wno-unused-result", *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"]
+            "-Wno-unused-result", *extra, *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"]
 
 
 def needs_build():

@@ -1025,29 +1025,50 @@ SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
     return SchedBufs{p, p + 4 * t, p + 6 * t, p + 7 * t, p + 8 * t, p + 9 * t, p + 10 * t};
 }
 
-// sort key of a tile: how long its slower wave ran in the timed launch, in steps of 0.64 us, longest first
-// (the sort is stable: tiles of one step keep their spatial order)
-__global__ __launch_bounds__(kBlock) void k_sched_keys(const uint32_t *cost, uint32_t n_tiles, uint32_t *keys, uint32_t *vals)
+// The whole schedule in one workgroup (7 k tiles at 10^6 points; three kernels and a device-wide radix sort of 10-bit
+// keys cost 35 us between two search launches, this one a few): a counting sort of the tiles by how long their slower
+// wave ran in the timed launch, in steps of 0.64 us, longest first, then rank r -> its workgroups: the first n4 tiles
+// get four, the next n2 two, the others one.  Tiles of one step come in whatever order the atomics hand out: the order
+// of the workgroups decides when a tile runs, never what it computes.
+__global__ __launch_bounds__(1024) void k_sched_build(const uint32_t *cost, uint32_t n_tiles, uint32_t n4, uint32_t n2, uint32_t *items, uint32_t *done)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    uint32_t c = 0;
-    for (int w = 0; w < kTileWaves; ++w) c = max(c, cost[t * kTileWaves + w]);
-    keys[t] = 1023u - min(c >> 6, 1023u);
-    vals[t] = t;
-}
-
-// rank r of the sorted tiles -> its workgroups: the first n4 tiles get four, the next n2 two, the others one
-__global__ __launch_bounds__(kBlock) void k_sched_emit(const uint32_t *vals, uint32_t n_tiles, uint32_t n4, uint32_t n2, uint32_t *items)
-{
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_tiles) return;
-    const uint32_t tile = vals[r];
-    uint32_t lg, base;
-    if (r < n4) { lg = 2; base = 4 * r; }
-    else if (r < n4 + n2) { lg = 1; base = 4 * n4 + 2 * (r - n4); }
-    else { lg = 0; base = 4 * n4 + 2 * n2 + (r - n4 - n2); }
-    for (uint32_t p = 0; p < (1u << lg); ++p) items[base + p] = tile | p << 24 | lg << 28;
+    __shared__ uint32_t bins[1024];
+    __shared__ uint32_t part[16];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    auto key_of = [&](uint32_t t) {
+        uint32_t c = 0;
+        for (int w = 0; w < kTileWaves; ++w) c = max(c, cost[t * kTileWaves + w]);
+        return 1023u - min(c >> 6, 1023u);
+    };
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) {
+        atomicAdd(&bins[key_of(t)], 1u);
+        done[t] = 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins: one per thread
+    const uint32_t mine = bins[threadIdx.x], lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63u) part[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += part[w];
+    __syncthreads();
+    bins[threadIdx.x] = before + incl - mine;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) {
+        const uint32_t r = atomicAdd(&bins[key_of(t)], 1u);
+        uint32_t lg, base;
+        if (r < n4) { lg = 2; base = 4 * r; }
+        else if (r < n4 + n2) { lg = 1; base = 4 * n4 + 2 * (r - n4); }
+        else { lg = 0; base = 4 * n4 + 2 * n2 + (r - n4 - n2); }
+        for (uint32_t p = 0; p < (1u << lg); ++p) items[base + p] = t | p << 24 | lg << 28;
+    }
 }
 
 int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
@@ -1056,14 +1077,7 @@ int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     const uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
-    size_t bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, sb.keys, sb.keys_alt, sb.vals, sb.vals_alt, (size_t)n_tiles, 0, 10, st));
-    if (bytes > ctx->d_tmp.cap) return RSREG_OK;   // (never on the paths that get here: the index build sorted far more; no schedule then)
-    RSREG_HIP(ctx, hipMemsetAsync(sb.done, 0, (size_t)n_tiles * 4, st));
-    k_sched_keys<<<div_up(n_tiles, kBlock), kBlock, 0, st>>>(sb.cost, n_tiles, sb.keys, sb.vals);
-    RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, bytes, sb.keys, sb.keys_alt, sb.vals, sb.vals_alt, (size_t)n_tiles, 0, 10, st));
-    k_sched_emit<<<div_up(n_tiles, kBlock), kBlock, 0, st>>>(sb.vals_alt, n_tiles, n4, n2, sb.items);
+    k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, sb.items, sb.done);
     RSREG_HIP(ctx, hipGetLastError());
     ctx->icp.sched_items = n_tiles + 3 * n4 + n2;
     if (std::getenv("RSREG_SCHED_VERBOSE"))

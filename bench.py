@@ -395,10 +395,18 @@ def main():
                 "cycles_per_inst_source": t["cycles_per_inst_source"], "simds": t["simds"], "bound_us": bound_us,
                 "avg_launch_us": avg_ms * 1e3, "frac": bound_us / (avg_ms * 1e3) if avg_ms > 0 else None,
                 "lane_utilisation": t.get("lane_utilisation"),
+                # the other issue-side resource, and the one the launch time actually follows (profiles/r03_what_bounds_the_kernel.txt):
+                # vector memory wave-instructions through the CU's address unit
+                "vmem_cycles_per_inst": t.get("vmem_cycles_per_inst"), "vmem_bound_us": t.get("vmem_bound_us"),
+                "vmem_frac": (t["vmem_bound_us"] / (avg_ms * 1e3)) if t.get("vmem_bound_us") and avg_ms > 0 else None,
+                "vmem_cycles_source": t.get("vmem_cycles_source"),
+                "binding": "neither alone: +49 % VALU per trip costs +5 %, +100 % vector memory instructions per trip +38 % "
+                           "(profiles/r03_what_bounds_the_kernel.txt): the launch follows the vector memory instruction count and the "
+                           "dependent L2 round trip behind every trip",
                 "source": "profiles/%s (static: rocprofv3 --pmc SQ_* passes of this command + tools/microbench/valu_issue.hip; the launch "
                           "time is this run's)" % ij[-1],
             }
-            out["roofline"]["binding"] = "VALU issue, not HBM: see roofline_issue (the contract's roofline stays the HBM one)"
+            out["roofline"]["binding"] = "not HBM (the working set lives in the Infinity Cache): see roofline_issue (the contract's roofline stays the HBM one)"
     except Exception:  # noqa: BLE001
         pass
     # the index build as a rate: SURVEY.md §8d prices it at 116 algorithmic bytes per target point

@@ -51,5 +51,13 @@ out = {
     "wave_cycles_split": {k: counters.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU")},
 }
 out["bound_us"] = out["valu_insts"] * ns_mix / out["simds"] * 1e-3 if out["valu_insts"] else None
+# the vector memory side: a wave-instruction occupies the CU's address unit for (64 lanes x bytes per lane) / 64 B per
+# clock whatever the number of active lanes -- 16 cycles for the 128-bit loads that are nine tenths of this kernel's
+# (profiles/r03_what_bounds_the_kernel.txt: four more such loads per trip, by one lane or by all, cost the same +37 us)
+out["cus"] = 256
+out["vmem_cycles_per_inst"] = 16.0
+out["vmem_cycles_source"] = ("128-bit buffer loads: 64 lanes x 16 B at the L1's 64 B / clock; confirmed by profiles/r03_what_bounds_the_kernel.txt "
+                             "(+4 loads per trip = +37 us per launch, with one active lane as with all)")
+out["vmem_bound_us"] = (counters.get("SQ_INSTS_VMEM_RD", 0) * out["vmem_cycles_per_inst"] / out["cus"] / 2.3e9) * 1e6 if counters.get("SQ_INSTS_VMEM_RD") else None
 json.dump(out, open(out_path, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("valu_insts", "ns_per_valu_inst_per_simd", "bound_us", "lane_utilisation")}))
+print(json.dumps({k: out[k] for k in ("valu_insts", "ns_per_valu_inst_per_simd", "bound_us", "vmem_bound_us", "lane_utilisation")}))

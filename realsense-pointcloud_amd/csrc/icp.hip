@@ -28,6 +28,15 @@ namespace {
 // rocPRIM sorts up to 2^20 items by merge sort whatever the bit range asked for; the keys here have ~40
 // significant bits, and from ~10^5 items on the onesweep radix sort is the faster one (same result: both are stable)
 using RadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+// 32-bit keys with 32-bit values (the cell keys of the target, the Morton keys of the source): 1024 threads x 4 items per
+// workgroup and the match-based rank take 108 us for 10^6 pairs where rocPRIM's tuned default takes 146, 84 against 135 us
+// at 3 x 10^5 (tools/microbench/sort_configs.hip, profiles/r03_sort_configs.txt)
+using RadixCfg32 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8,
+                                                                                  rocprim::block_radix_rank_algorithm::match>,
+                                              65536>;
+template <typename KeyT> struct RadixCfgOf { using type = RadixCfg; };
+template <> struct RadixCfgOf<uint32_t> { using type = RadixCfg32; };
 
 inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n + kTile - 1) / kTile, 1); }  // depends on n only
 
@@ -230,11 +239,12 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     RSREG_HIP(ctx, hipGetLastError());
     const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
     size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    using SortCfg = typename RadixCfgOf<KeyT>::type;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     const uint32_t nbf = div_up(nfin, kBlock);
     k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
     RSREG_HIP(ctx, hipGetLastError());
@@ -341,9 +351,10 @@ int update_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t
     while ((1ull << id_bits) <= total) ++id_bits;
     const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
     size_t sort_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
+    using SortCfg = typename RadixCfgOf<KeyT>::type;
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(sort_bytes + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
     // exact copies among the new points go, as in a build; the kept pairs move back into keys / vals
     RSREG_HIP(ctx, ctx->d_scan.reserve((size_t)m * 8 + 16));
     uint32_t *keep = ctx->d_scan.as<uint32_t>(), *kpos = keep + m;
@@ -723,9 +734,9 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
             const unsigned sort_bits = (unsigned)(mb.x + mb.y + mb.z) + 1u;
             k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys, vals);
             RSREG_HIP(ctx, hipGetLastError());
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
             k_gather_source<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
             RSREG_HIP(ctx, hipGetLastError());
         } else {

@@ -20,6 +20,7 @@
 #include "icp_kernels.hpp"
 #include "icp_tile_kernel.hpp"
 #include "icp_dense.hpp"
+#include "sort_cfg.hpp"
 
 using namespace rsreg;
 
@@ -28,13 +29,6 @@ namespace {
 // rocPRIM sorts up to 2^20 items by merge sort whatever the bit range asked for; the keys here have ~40
 // significant bits, and from ~10^5 items on the onesweep radix sort is the faster one (same result: both are stable)
 using RadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
-// 32-bit keys with 32-bit values (the cell keys of the target, the Morton keys of the source): 1024 threads x 4 items per
-// workgroup and the match-based rank take 108 us for 10^6 pairs where rocPRIM's tuned default takes 146, 84 against 135 us
-// at 3 x 10^5 (tools/microbench/sort_configs.hip, profiles/r03_sort_configs.txt)
-using RadixCfg32 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 4>, 8,
-                                                                                  rocprim::block_radix_rank_algorithm::match>,
-                                              65536>;
 template <typename KeyT> struct RadixCfgOf { using type = RadixCfg; };
 template <> struct RadixCfgOf<uint32_t> { using type = RadixCfg32; };
 

@@ -26,6 +26,7 @@
 #include <cmath>
 
 #include "rsreg_ctx.hpp"
+#include "sort_cfg.hpp"
 
 namespace rsreg {
 namespace {
@@ -325,11 +326,11 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
     RSREG_HIP(ctx, b_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
+    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable (radix above 65 536 items: sort_cfg.hpp)
     k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));

@@ -95,7 +95,7 @@ void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
     }
     CloudPool &pool = ctx->cloud_pool;
     if (b.cap <= pool.limit && pool.held + b.cap <= pool.limit) {
-        if (ctx->src_pending) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_src_done, 0);
+        if (ctx->src_pending) { (void)ctx->source_enqueued(); (void)hipStreamWaitEvent(ctx->stream, ctx->ev_src_done, 0); }
         pool.slots.push_back({b.ptr, b.cap});
         pool.held += b.cap;
         b.ptr = nullptr;
@@ -257,7 +257,7 @@ int rsreg_cloud_upload_async(rsreg_cloud *c, const void *points, size_t n, size_
         // the buffer may come from the pool: work queued on its previous owner (main stream) goes first
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_copy_gate, ctx->stream));
         RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_copy_gate, 0));
-        if (ctx->src_pending) RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_src_done, 0));
+        if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_src_done, 0)); }
         RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, stage, n * stride, hipMemcpyHostToDevice, ctx->stream_copy));
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_up[slot], ctx->stream_copy));
         RSREG_HIP(ctx, hipEventRecord(c->ev_filled, ctx->stream_copy));
@@ -396,7 +396,7 @@ int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float 
     // to get may come from the pool with work of its previous owner still queued
     RSREG_HIP(ctx, hipEventRecord(ctx->ev_side_gate, ctx->stream));
     RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_side_gate, 0));
-    if (ctx->src_pending) RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_src_done, 0));
+    if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_src_done, 0)); }
     uint32_t nr = 0;
     const size_t stride = in->stride;
     rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, true);

@@ -631,52 +631,23 @@ int join_source(rsreg_ctx *ctx)
 {
     if (!ctx->src_pending) return RSREG_OK;
     ctx->src_pending = false;
+    const int rcw = ctx->source_enqueued();   // (the load's host side may still be running on the context's worker thread)
+    if (rcw) {
+        ctx->have_source = false;
+        return rcw;
+    }
     RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_src_done));
     ctx->n_work = ctx->h_smisc.as<uint32_t>()[32];
     return RSREG_OK;
 }
 
-// Loads the source: orders it spatially (Morton order of a few-mm grid, so the lanes of a wave
-// query neighbouring cells) and merges exact copies of a point into one weighted point (the
-// RealSense (0,0,0) pixels are ~11 % of a frame: they are searched once, not 10^5 times).
-// d_perm: sorted position -> caller's index; d_uniq_of: sorted position -> distinct point.
-// Everything after the bounding box (one host sync) is only queued -- on ctx->stream_src, behind whatever the
-// main stream holds so far -- and joined by join_source: when the caller sets the source before the target (the
-// reference's order, incremental_icp.hpp:57-58) the load runs beside the target's index build.
-int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
+// The part of a source load that queues work on stream_src (after one round trip for the bounding box); runs on the
+// context's worker thread (rsreg_ctx.hpp: SourceWorker) or, with RSREG_NO_WORKER=1, on the caller's.
+int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
 {
-    if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
-    int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
-    if (rcj) return rcj;
-    if (!ctx->stream_src) {
-        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
-        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
-        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
-    }
-    hipStream_t st = ctx->stream_src;
-    RSREG_HIP(ctx, ctx->d_src_all.reserve((n + 1) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_seed.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_perm.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
-    RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
-    RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
-    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
-    RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
-    RSREG_HIP(ctx, ctx->d_smisc.reserve((64 + 1024 * 8) * sizeof(uint32_t)));
-    RSREG_HIP(ctx, ctx->h_smisc.reserve(64 * sizeof(uint32_t)));
-    ctx->n_source = n;
-    ctx->n_work = 0;
-    ctx->src_cloud = nullptr;
-    ctx->have_source = false;
-    ctx->icp.active = 0;
-    if (n) {
-        // the raw cloud may have been produced (uploaded, filtered, transformed) on the main stream just now
-        RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+    {
+        RSREG_HIP(ctx, hipSetDevice(ctx->device));   // (this may be the context's worker thread)
+        hipStream_t st = ctx->stream_src;
         RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
@@ -755,6 +726,60 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
                                                 ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
+    }
+    return RSREG_OK;
+}
+
+// Loads the source: orders it spatially (Morton order of a few-mm grid, so the lanes of a wave
+// query neighbouring cells) and merges exact copies of a point into one weighted point (the
+// RealSense (0,0,0) pixels are ~11 % of a frame: they are searched once, not 10^5 times).
+// d_perm: sorted position -> caller's index; d_uniq_of: sorted position -> distinct point.
+// Everything after the bounding box (one host sync) is only queued -- on ctx->stream_src, behind whatever the
+// main stream holds so far -- and joined by join_source: when the caller sets the source before the target (the
+// reference's order, incremental_icp.hpp:57-58) the load runs beside the target's index build.
+int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
+{
+    if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
+    int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
+    if (rcj) return rcj;
+    if (!ctx->stream_src) {
+        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+    }
+    RSREG_HIP(ctx, ctx->d_src_all.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_src.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_cur.reserve((n + 1) * sizeof(float4)));
+    RSREG_HIP(ctx, ctx->d_corr_pos.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_corr_d2.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_seed.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_perm.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
+    RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
+    RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
+    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
+    RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->d_smisc.reserve((64 + 1024 * 8) * sizeof(uint32_t)));
+    RSREG_HIP(ctx, ctx->h_smisc.reserve(64 * sizeof(uint32_t)));
+    ctx->n_source = n;
+    ctx->n_work = 0;
+    ctx->src_cloud = nullptr;
+    ctx->have_source = false;
+    ctx->icp.active = 0;
+    if (n) {
+        // the raw cloud may have been produced (uploaded, filtered, transformed) on the main stream just now
+        RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        static const bool no_worker = std::getenv("RSREG_NO_WORKER") && std::getenv("RSREG_NO_WORKER")[0] == '1';
+        if (no_worker) {
+            int rc = load_source_queue(ctx, d_raw, n, stride);
+            if (rc) return rc;
+        } else {
+            // the rest -- a bounding-box round trip and ~25 launches -- on the context's worker thread: the caller goes on
+            // (to the target's index build, in the reference's order of calls) while the source's queue is being filled
+            if (!ctx->src_worker) ctx->src_worker = new rsreg::SourceWorker();
+            ctx->src_worker->post([ctx, d_raw, n, stride] { return load_source_queue(ctx, d_raw, n, stride); });
+        }
         ctx->src_pending = true;
     }
     ctx->have_source = true;
@@ -1318,6 +1343,11 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
 {
     if (!ctx) return RSREG_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->src_worker) {
+        ctx->src_worker->shutdown();
+        delete ctx->src_worker;
+        ctx->src_worker = nullptr;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_src) (void)hipStreamSynchronize(ctx->stream_src);
     rsreg_comm_destroy(ctx);

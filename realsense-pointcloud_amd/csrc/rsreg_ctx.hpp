@@ -9,6 +9,9 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -54,6 +57,64 @@ struct CloudPool {
         const char *e = std::getenv("RSREG_CLOUD_POOL_MB");
         return (size_t)(e ? std::max(0ll, std::atoll(e)) : 4096ll) << 20;
     }();
+};
+
+// The host side of a source load (a bounding-box round trip and ~25 launches: 0.13 ms of host time at any size) runs on a
+// thread of the context's own, so that the caller's thread goes straight on to the target's index build
+// (incremental_icp.hpp:57-58: setInputSource, then setInputTarget): the two queues are then FILLED side by side, not only
+// drained side by side.  One job at a time; whoever needs the source (or hands one of its buffers on) waits for the
+// job to have queued everything first (wait), then for the GPU as before (ev_src_done).
+struct SourceWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, busy = false, stop = false;
+    int rc = 0;
+
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop) return;
+            std::function<int()> f = std::move(job);
+            has_job = false;
+            busy = true;
+            lk.unlock();
+            const int r = f();
+            lk.lock();
+            rc = r;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        cv.wait(lk, [&] { return !has_job && !busy; });
+        job = std::move(f);
+        has_job = true;
+        rc = 0;
+        cv.notify_all();
+    }
+    int wait()   // until the posted job has run; its status
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !has_job && !busy; });
+        return rc;
+    }
+    void shutdown()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return !has_job && !busy; });
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
 };
 
 struct PinnedBuf {
@@ -160,6 +221,9 @@ struct rsreg_ctx {
     hipStream_t stream_src = nullptr;
     hipEvent_t ev_src_done = nullptr, ev_main = nullptr;
     bool src_pending = false;
+    rsreg::SourceWorker *src_worker = nullptr;   // (created with the first source load; RSREG_NO_WORKER=1: never, the load runs on the caller's thread)
+    // everything of a pending source load has been queued on stream_src (so that ev_src_done is the event of THIS load)
+    int source_enqueued() { return src_worker ? src_worker->wait() : 0; }
     rsreg::DevBuf d_skeys, d_skeys_alt, d_svals, d_sflags, d_sscan, d_stmp, d_smisc;   // its scratch (the target build has its own)
     rsreg::PinnedBuf h_smisc;
     rsreg::DevBuf d_src_all;      // float4 {x,y,z,valid} of every source point, spatially sorted

@@ -5,10 +5,13 @@ Bars: nearest-neighbour indices and float32 squared distances bit-exact; the 17 
 1e-11 relative; 4x4 transforms to 2e-6 per element after one iteration, and within the
 north-star tolerance of 1e-4 Frobenius (we assert 2e-5) after multi-iteration runs.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 T_TOL = 2e-6
 
@@ -364,3 +367,50 @@ def test_full_size_properties(api, rs, size):
     icp.align()
     assert icp.hasConverged() and icp.result.iterations == 1
     assert np.abs(icp.getFinalTransformation() - T).max() < 2e-5
+
+
+def test_source_load_on_the_worker_thread_gives_the_same_bits(rs):
+    """The host side of a source load runs on a thread of the context's own (rsreg_ctx.hpp: SourceWorker) so that the
+    caller's thread goes straight on to the target's index build; RSREG_NO_WORKER=1 keeps it on the caller's thread.
+    Same transform, same correspondences, bit for bit, in either call order, with host clouds and with cloud handles --
+    and a context is torn down cleanly while a load is still in flight."""
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import rsreg_amd
+from rsreg_amd import api, synth
+tgt, src = synth.render_frame(0, "50k", "bench"), synth.render_frame(1, "50k", "bench")
+h = hashlib.sha256()
+for order in ("source-first", "target-first"):
+    for dev in (False, True):
+        ctx = api.Context(0)
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, max_correspondence_distance=0.05)
+        s, t = (api.DeviceCloud(src, ctx), api.DeviceCloud(tgt, ctx)) if dev else (src, tgt)
+        if order == "source-first":
+            icp.setInputSource(s); icp.setInputTarget(t)
+        else:
+            icp.setInputTarget(t); icp.setInputSource(s)
+        for _ in range(3):                       # repeated loads: a job is posted while the last one may still be running
+            icp.setInputSource(s)
+        icp.align()
+        h.update(icp.getFinalTransformation().tobytes())
+        h.update(np.int64(icp.result.n_correspondences).tobytes())
+ctx = api.Context(0)                             # torn down with a load in flight
+icp = api.IterativeClosestPoint(ctx)
+icp.setInputSource(src)
+icp.setInputTarget(tgt)
+icp._sync_inputs()                           # source queued on the worker, target built: no align
+del icp, ctx
+print(h.hexdigest())
+''' % ROOT
+    out = {}
+    for no_worker in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSREG_NO_WORKER=no_worker), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[no_worker] = r.stdout.strip().splitlines()[-1]
+    assert out["0"] == out["1"] and len(out["0"]) == 64

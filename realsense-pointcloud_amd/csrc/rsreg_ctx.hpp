@@ -190,6 +190,7 @@ struct rsreg_ctx {
     bool own_stream = false;
     bool profiling = false;
     std::string last_error;
+    std::mutex error_mutex;
 
     // ---- ICP target index
     bool have_target = false;
@@ -302,6 +303,7 @@ void cloud_pool_clear(rsreg_ctx *ctx);   // cloud.hip: frees the buffers kept in
 inline int fail(rsreg_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {
     if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->error_mutex);   // (the context's source worker thread reports through here too)
         ctx->last_error = what;
         if (e != hipSuccess) {
             ctx->last_error += ": ";

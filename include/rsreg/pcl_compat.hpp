@@ -205,6 +205,7 @@ class Context {
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rsreg_ctx *get() const { return ctx_; }
+    void wait_downloads() { check(rsreg_ctx_wait_downloads(ctx_), ctx_); }   // every DeviceCloud::download_async of this context has landed
     // A context holds ONE ICP target index, ONE ICP source and ONE NDT voxel grid.  The object that
     // uploaded each of them last is remembered here, so that a second registration object sharing
     // the context (e.g. the default one) re-uploads its own clouds instead of silently using another's.
@@ -257,6 +258,19 @@ template <typename PointT> class DeviceCloud {
         host.width = w;
         host.height = h;
         host.is_dense = dense != 0;
+    }
+    // engine extra: download() that returns at once -- the records as they are now go to dst[0 .. size()) beside whatever
+    // the GPU does next; dst belongs to the copy until Context::wait_downloads() has returned (rsreg_cloud_download_async)
+    void download_async(PointT *dst, size_t capacity) const
+    {
+        check(rsreg_cloud_download_async(h_, dst, capacity), ctx_->get());
+    }
+    void info(size_t &n, uint32_t &width, uint32_t &height, bool &is_dense) const
+    {
+        size_t stride = 0;
+        int dense = 0;
+        check(rsreg_cloud_info(h_, &n, &stride, &width, &height, &dense), ctx_->get());
+        is_dense = dense != 0;
     }
     size_t size() const
     {

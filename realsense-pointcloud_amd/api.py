@@ -65,6 +65,10 @@ class Context:
     def synchronize(self):
         _l.check(_l.lib().rsreg_ctx_synchronize(self.h), self.h)
 
+    def wait_downloads(self):
+        """Every DeviceCloud.download_async of this context has landed in its host array when this returns."""
+        _l.check(_l.lib().rsreg_ctx_wait_downloads(self.h), self.h)
+
     def close(self):
         if getattr(self, "h", None):
             _l.lib().rsreg_ctx_destroy(self.h)
@@ -167,6 +171,19 @@ class DeviceCloud:
         pts = np.zeros(n, POINT_DTYPE)
         _l.check(_l.lib().rsreg_cloud_download(self.h, pts.ctypes.data, n), self.ctx.h)
         return PointCloud(pts, width=w, height=h, is_dense=dense)
+
+    def download_async(self, out, offset=0):
+        """download() that returns at once (rsreg_cloud_download_async): this cloud's records, as they are when the
+        context's stream gets here, go to out[offset:offset + len(self)] (a C-contiguous POINT_DTYPE array the caller
+        keeps alive and does not touch until ctx.wait_downloads() has returned); the cloud may be rewritten or dropped
+        right away.  Returns the number of records on their way."""
+        n = self.info()[0]
+        if not (isinstance(out, np.ndarray) and out.dtype == POINT_DTYPE and out.flags.c_contiguous and out.ndim == 1):
+            raise ValueError("download_async needs a C-contiguous 1-D POINT_DTYPE array")
+        if offset < 0 or offset + n > len(out):
+            raise ValueError("download_async: %d records do not fit behind offset %d of %d" % (n, offset, len(out)))
+        _l.check(_l.lib().rsreg_cloud_download_async(self.h, out.ctypes.data + offset * POINT_DTYPE.itemsize, n), self.ctx.h)
+        return n
 
     def copy(self):
         out = DeviceCloud(ctx=self.ctx)

@@ -25,6 +25,9 @@ struct rsreg_cloud {
     // rsreg_cloud_upload_async: the copy that fills this cloud may still be on the link
     hipEvent_t ev_filled = nullptr;
     mutable bool filling = false;
+    // rsreg_cloud_download_async: a copy of these records to the host may still be reading them
+    hipEvent_t ev_down = nullptr;
+    mutable bool downloading = false;
     // which cloud this is and how often its records have been rewritten: an index built from (id, version) is still
     // good while both are unchanged (rsreg_icp_set_target_cloud)
     uint64_t id = 0, version = 0;
@@ -74,7 +77,13 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
 // reader works on.
 hipError_t settle(const rsreg_cloud *c)
 {
-    if (!c || !c->filling) return hipSuccess;
+    if (!c) return hipSuccess;
+    if (c->downloading) {   // whatever the main stream does to the cloud next comes after the copy that is reading it
+        c->downloading = false;
+        hipError_t e = hipStreamWaitEvent(c->ctx->stream, c->ev_down, 0);
+        if (e != hipSuccess) return e;
+    }
+    if (!c->filling) return hipSuccess;
     c->filling = false;
     return hipEventSynchronize(c->ev_filled);
 }
@@ -195,6 +204,7 @@ int rsreg_cloud_destroy(rsreg_cloud *c)
     (void)hipSetDevice(c->ctx->device);
     (void)settle(c);
     if (c->ev_filled) (void)hipEventDestroy(c->ev_filled);
+    if (c->ev_down) (void)hipEventDestroy(c->ev_down);
     if (c->ctx->src_cloud == c) c->ctx->src_cloud = nullptr;   // (rsreg_icp_align_cloud then refuses to write an aligned cloud)
     cloud_drop(c->ctx, c->buf);
     delete c;
@@ -437,6 +447,50 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
 // pcl::PointCloud::operator+ / += (incremental_icp.hpp:64, icp_edge...hpp:119-120): out = a followed by b;
 // out may be a (the append of `target += transformed` then costs only the copy of b) or b
 const rsreg_ctx *rsreg_cloud_ctx_(const rsreg_cloud *c) { return c ? c->ctx : nullptr; }   // (internal: edges.hip)
+
+// rsreg_cloud_download that returns at once: the records as they are when the main stream gets here are copied to a pinned
+// staging buffer on a download stream and from there to `out` by a thread of the context; the cloud may be rewritten
+// or dropped right away (that work is queued behind the copy).  `out` belongs to the copy until
+// rsreg_ctx_wait_downloads has returned.  The frame loops download every frame's moved points this way while the next
+// frames are aligned: the merged cloud of sixteen 307 k-point frames is 157 MB, 4 ms on the link at the end otherwise.
+int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
+{
+    if (!c || (c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
+    rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(c));
+    if (!c->n) return RSREG_OK;
+    if (!ctx->stream_down) {
+        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking));
+        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_down_gate, hipEventDisableTiming));
+        for (hipEvent_t &e : ctx->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->down_worker = new rsreg::DownloadWorker();
+    }
+    rsreg_cloud *mc = const_cast<rsreg_cloud *>(c);
+    if (!mc->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&mc->ev_down, hipEventDisableTiming));
+    const size_t bytes = c->n * c->stride;
+    const int slot = ctx->down_next;
+    ctx->down_next = (ctx->down_next + 1) % 3;
+    ctx->down_worker->wait_slot(slot);   // (the copy-out that last used this staging buffer)
+    RSREG_HIP(ctx, ctx->h_down[slot].reserve(bytes));
+    RSREG_HIP(ctx, hipEventRecord(ctx->ev_down_gate, ctx->stream));
+    RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_down, ctx->ev_down_gate, 0));
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_down[slot].ptr, c->buf.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream_down));
+    RSREG_HIP(ctx, hipEventRecord(ctx->ev_down[slot], ctx->stream_down));
+    RSREG_HIP(ctx, hipEventRecord(mc->ev_down, ctx->stream_down));
+    c->downloading = true;
+    ctx->down_worker->post(rsreg::DownloadWorker::Job{ctx->ev_down[slot], ctx->h_down[slot].as<char>(), static_cast<char *>(out), bytes, slot, ctx->device});
+    return RSREG_OK;
+}
+
+int rsreg_ctx_wait_downloads(rsreg_ctx *ctx)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    if (!ctx->down_worker) return RSREG_OK;
+    const int e = ctx->down_worker->wait_idle();
+    if (e) return fail(ctx, RSREG_ERR_HIP, "an asynchronous download failed", (hipError_t)e);
+    return RSREG_OK;
+}
 
 int rsreg_cloud_version(const rsreg_cloud *c, uint64_t *id, uint64_t *version)
 {

@@ -1380,6 +1380,18 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
     }
     for (rsreg::PinnedBuf &b : ctx->h_up) b.release();
+    if (ctx->down_worker) {
+        ctx->down_worker->shutdown();
+        delete ctx->down_worker;
+        ctx->down_worker = nullptr;
+    }
+    if (ctx->stream_down) {
+        (void)hipStreamSynchronize(ctx->stream_down);
+        (void)hipStreamDestroy(ctx->stream_down);
+        (void)hipEventDestroy(ctx->ev_down_gate);
+        for (hipEvent_t e : ctx->ev_down) (void)hipEventDestroy(e);
+    }
+    for (rsreg::PinnedBuf &b : ctx->h_down) b.release();
     if (ctx->stream_side) {
         (void)hipStreamSynchronize(ctx->stream_side);
         (void)hipStreamDestroy(ctx->stream_side);

@@ -117,6 +117,85 @@ struct SourceWorker {
     }
 };
 
+// Downloads that run beside the frame loop (rsreg_cloud_download_async): the copy lands in one of a few pinned staging
+// buffers on a stream of its own; this thread waits for it and copies it out to the caller's (pageable) memory.
+struct DownloadWorker {
+    struct Job {
+        hipEvent_t ev;
+        const char *stage;
+        char *dst;
+        size_t bytes;
+        int slot, device;
+    };
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Job> queue;
+    bool busy = false, stop = false;
+    bool slot_busy[3] = {false, false, false};
+    int err = 0;
+
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return !queue.empty() || stop; });
+            if (queue.empty() && stop) return;
+            const Job j = queue.front();
+            queue.erase(queue.begin());
+            busy = true;
+            lk.unlock();
+            hipError_t e = hipSetDevice(j.device);
+            if (e == hipSuccess) e = hipEventSynchronize(j.ev);
+            if (e == hipSuccess) {
+                // a few threads: one core copies ~10 GB/s, a frame of 10 MB would take as long as the link needs for it
+                const size_t parts = j.bytes >= (size_t)4 << 20 ? 4 : 1, step = (j.bytes + parts - 1) / parts;
+                std::vector<std::thread> helpers;
+                for (size_t p = 1; p < parts; ++p)
+                    helpers.emplace_back([=] { const size_t lo = p * step, hi = std::min(j.bytes, lo + step); if (lo < hi) std::memcpy(j.dst + lo, j.stage + lo, hi - lo); });
+                std::memcpy(j.dst, j.stage, std::min(step, j.bytes));
+                for (auto &t : helpers) t.join();
+            }
+            lk.lock();
+            if (e != hipSuccess && !err) err = (int)e;
+            slot_busy[j.slot] = false;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void wait_slot(int slot)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !slot_busy[slot]; });
+        slot_busy[slot] = true;
+    }
+    void post(const Job &j)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        queue.push_back(j);
+        cv.notify_all();
+    }
+    int wait_idle()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return queue.empty() && !busy; });
+        const int e = err;
+        err = 0;
+        return e;
+    }
+    void shutdown()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return queue.empty() && !busy; });
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct PinnedBuf {
     void *ptr = nullptr;
     size_t cap = 0;
@@ -275,6 +354,12 @@ struct rsreg_ctx {
     rsreg::PinnedBuf h_up[2];
     bool up_busy[2] = {false, false};
     int up_next = 0;
+    // rsreg_cloud_download_async: a download stream, three pinned staging buffers with an event each, the copy-out thread
+    hipStream_t stream_down = nullptr;
+    hipEvent_t ev_down_gate = nullptr, ev_down[3] = {nullptr, nullptr, nullptr};
+    rsreg::PinnedBuf h_down[3];
+    int down_next = 0;
+    rsreg::DownloadWorker *down_worker = nullptr;
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;

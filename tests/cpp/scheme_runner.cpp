@@ -37,6 +37,9 @@ int main(int argc, char **argv)
         // every run goes to stderr (frames on the host in, merged cloud on the host out; the first run also pays for
         // the context and the first allocations)
         const int timed_reps = std::getenv("RSREG_SCHEME_TIME") ? std::atoi(std::getenv("RSREG_SCHEME_TIME")) : 0;
+        // RSREG_SCHEME_NO_STREAM=1: the merged cloud is built on the GPU and downloaded once at the end instead of being
+        // streamed to the host frame by frame (schemes.hpp `stream_result`)
+        const bool stream = !(std::getenv("RSREG_SCHEME_NO_STREAM") && std::getenv("RSREG_SCHEME_NO_STREAM")[0] == '1');
         for (int rep = 0; rep < timed_reps; ++rep) {
             std::vector<rgb_point_cloud_pointer> fresh;
             for (auto &c : clouds) fresh.push_back(std::make_shared<rgb_point_cloud>(*c));
@@ -46,14 +49,17 @@ int main(int argc, char **argv)
             if (mode == "incremental") {
                 IncrementalICP s;
                 s.device_resident = !host_loop_t;
+                s.stream_result = stream;
                 merged = s.registration(fresh)->size();
             } else if (mode == "icp_edge") {
                 ICPEdgeBasedRegistration s(-0.0261799f);
                 s.device_resident = !host_loop_t;
+                s.stream_result = stream;
                 merged = s.registration(fresh)->size();
             } else if (mode == "ndt_edge") {
                 NDTEdgeBasedRegistration s(-0.0261799f);
                 s.device_resident = !host_loop_t;
+                s.stream_result = stream;
                 merged = s.registration(fresh)->size();
             }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -74,6 +80,7 @@ int main(int argc, char **argv)
         if (mode == "incremental") {
             IncrementalICP s;
             s.device_resident = !host_loop;
+            s.stream_result = stream;
             out = s.registration(clouds);
             for (auto &T : s.transforms) dump(f, T);
         } else if (mode == "icp_edge" || mode == "ndt_edge") {
@@ -81,12 +88,14 @@ int main(int argc, char **argv)
             if (mode == "icp_edge") {
                 ICPEdgeBasedRegistration s(rads);
                 s.device_resident = !host_loop;
+                s.stream_result = stream;
                 observables(s);
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             } else {
                 NDTEdgeBasedRegistration s(rads);
                 s.device_resident = !host_loop;
+                s.stream_result = stream;
                 observables(s);
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }

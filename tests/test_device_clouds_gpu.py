@@ -486,3 +486,57 @@ def test_grown_target_takes_the_new_points_into_its_index(api, rs, frames, monke
     icp.setInputTarget(tgt2)
     icp.align()
     assert icp.grid_info().n_updates == 0
+
+
+def test_download_async_lands_what_the_stream_had_when_it_was_asked(api, rs, frames):
+    """rsreg_cloud_download_async returns at once; the host array holds the records the cloud had at the point of the
+    call once rsreg_ctx_wait_downloads has returned, whatever happened to the cloud right after: rewritten by an
+    upload, a transform INTO it, an append, or dropped.  More downloads in flight than the context has staging slots;
+    an empty cloud; a second wait is a no-op; the bad calls are refused."""
+    a, b, c = frames
+    ctx = api.Context(0)
+    T = rs.synth.small_transform(2.0, (0.01, 0.02, -0.01)).astype(np.float32)
+    na, nb, nc = len(a), len(b), len(c)
+    moved_b = api.transformPointCloud(b, T, ctx)
+    out = np.zeros(na * 3 + nb * 3 + nc + 7, api.POINT_DTYPE)
+    out["rgba"] = 0xDEADBEEF
+    at, want = 0, []
+
+    def push(dc, expect):
+        nonlocal at
+        got = dc.download_async(out, at)
+        assert got == len(expect)
+        want.append((at, expect))
+        at += got
+
+    da = api.DeviceCloud(a, ctx)
+    push(da, a)
+    da.upload(b)                               # rewritten at once: the copy in flight is of `a`
+    push(da, b)
+    db = api.DeviceCloud(ctx=ctx).upload_async(b)   # an upload still in flight behind it
+    push(db, b)
+    moved = api.transformPointCloud(db, T, ctx)
+    push(moved, moved_b)
+    del moved                                  # dropped with its download in flight
+    grown = api.DeviceCloud(a, ctx)
+    push(grown, a)
+    grown.append(api.DeviceCloud(c, ctx))      # grows (and may move) the buffer right after
+    push(api.DeviceCloud(c, ctx), c)           # a temporary
+    push(api.DeviceCloud(rs.PointCloud(), ctx), rs.PointCloud())
+    push(api.DeviceCloud(a, ctx), a)
+    ctx.wait_downloads()
+    ctx.wait_downloads()
+    for lo, expect in want:
+        for f in ("x", "y", "z", "w", "rgba"):
+            np.testing.assert_array_equal(out[f][lo:lo + len(expect)].view(np.uint32), expect.points[f].view(np.uint32))
+    assert at == na * 3 + nb * 3 + nc and (out["rgba"][at:] == 0xDEADBEEF).all()   # nothing written past the records
+    _same_records(grown.download(), a + c)
+    with pytest.raises(ValueError):
+        da.download_async(out, len(out) - 1)
+    with pytest.raises(ValueError):
+        da.download_async(np.zeros(nb, np.float32))
+    small = np.zeros(3, api.POINT_DTYPE)
+    from rsreg_amd import lib
+    assert lib.lib().rsreg_cloud_download_async(da.h, small.ctypes.data, 3) == lib.RSREG_ERR_INVALID_ARG
+    assert lib.lib().rsreg_cloud_download_async(None, small.ctypes.data, 3) != 0
+    assert lib.lib().rsreg_ctx_wait_downloads(None) != 0

@@ -142,6 +142,11 @@ def test_cpp_host_layer_matches_python_path(env, frames, runner, tmp_path, rs):
         subprocess.run([runner, mode, pre_h] + paths, check=True, env=dict(os.environ, RSREG_SCHEME_HOST_LOOP="1"))
         assert open(pre + ".pcd", "rb").read() == open(pre_h + ".pcd", "rb").read()
         assert open(pre + ".txt").read() == open(pre_h + ".txt").read()
+        # ... and so does the device loop with one download at the end instead of the merged cloud streamed frame by frame
+        pre_n = str(tmp_path / (mode + "_nostream"))
+        subprocess.run([runner, mode, pre_n] + paths, check=True, env=dict(os.environ, RSREG_SCHEME_NO_STREAM="1"))
+        assert open(pre + ".pcd", "rb").read() == open(pre_n + ".pcd", "rb").read()
+        assert open(pre + ".txt").read() == open(pre_n + ".txt").read()
         s = cls() if mode == "incremental" else cls(rads=RADS)
         merged = s.registration([f.copy() for f in frames])
         got = rs.load_pcd(pre + ".pcd")

@@ -301,6 +301,12 @@ int rsreg_cloud_upload(rsreg_cloud *cloud, const void *points, size_t n, size_t 
  * be reused when the call returns. */
 int rsreg_cloud_upload_async(rsreg_cloud *cloud, const void *points, size_t n, size_t stride, uint32_t width,
                              uint32_t height, int is_dense);
+/* rsreg_cloud_upload_async that returns before `points` has been read: the records are staged and their copy queued by a
+ * thread of the context.  `points` must stay valid and unchanged until a call that reads or rewrites the cloud (any of
+ * them waits for the upload) has returned.  For callers whose frames stay put for the whole registration -- the
+ * reference's schemes take the caller's vector of clouds (types.hpp:19) and read frame k + 2 while frame k is aligned. */
+int rsreg_cloud_upload_deferred(rsreg_cloud *cloud, const void *points, size_t n, size_t stride, uint32_t width,
+                                uint32_t height, int is_dense);
 int rsreg_cloud_download(const rsreg_cloud *cloud, void *out, size_t capacity_records);
 /* rsreg_cloud_download that returns at once: the records as they are when the context's stream gets here go to `out`
  * (capacity in records) on a download stream and a copy-out thread of the context; the cloud may be rewritten or

@@ -245,6 +245,13 @@ template <typename PointT> class DeviceCloud {
     {
         check(rsreg_cloud_upload_async(h_, host.points.data(), host.size(), sizeof(PointT), host.width, host.height, host.is_dense), ctx_->get());
     }
+    // upload_async() that returns before `host` has been read (rsreg_cloud_upload_deferred): a thread of the context
+    // stages the records and queues their copy.  `host` must stay as it is until a call that reads or rewrites this
+    // cloud has returned -- the frame loops hand over the caller's frames, which stay put for the whole registration.
+    void upload_deferred(const PointCloud<PointT> &host)
+    {
+        check(rsreg_cloud_upload_deferred(h_, host.points.data(), host.size(), sizeof(PointT), host.width, host.height, host.is_dense), ctx_->get());
+    }
     void download(PointCloud<PointT> &host) const
     {
         size_t n = 0, stride = 0;

@@ -21,6 +21,9 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 #include "pcl_compat.hpp"
@@ -117,8 +120,13 @@ class StreamedResult {
     }
     void finish(rgb_point_cloud &out)
     {
+        const auto t0 = std::chrono::steady_clock::now();
         if (copy0_.joinable()) copy0_.join();
+        const auto t1 = std::chrono::steady_clock::now();
         ctx_->wait_downloads();
+        if (std::getenv("RSREG_STREAM_VERBOSE"))
+            std::fprintf(stderr, "finish: join %.3f ms, wait %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         pending_ = false;
         pts_.resize(n_);
         out.points = std::move(pts_);
@@ -170,12 +178,12 @@ class IncrementalICP : public RegistrationScheme {
             for (auto &c : clouds) capacity += c->size();
             result.reset(new detail::StreamedResult(model.context(), *clouds[0], capacity));
         }
-        for (size_t k = 1; k < std::min<size_t>(3, n); ++k) frames[k % 3].upload_async(*clouds[k]);
+        for (size_t k = 1; k < std::min<size_t>(3, n); ++k) frames[k % 3].upload_deferred(*clouds[k]);
         if (n > 1) voxel.filter_async(frames[1], reduced_of[1]);
         size_t merged_frames = 0;
         for (size_t k = 1; k < n; ++k) {
             rgb_device_cloud &frame = frames[k % 3], &reduced = reduced_of[k & 1];
-            if (k + 2 < n) frames[(k + 2) % 3].upload_async(*clouds[k + 2]);
+            if (k + 2 < n) frames[(k + 2) % 3].upload_deferred(*clouds[k + 2]);
             if (k + 1 < n) voxel.filter_async(frames[(k + 1) % 3], reduced_of[(k + 1) & 1]);
             icp.setInputSource(reduced);
             icp.setInputTarget(model);
@@ -320,7 +328,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         }
         if (pairs) target.upload(*(*pairs)[0].first);
         else extract_edge_features(merged, target);
-        if (!pairs && n_frames > 1) fulls[1].upload_async(*(*frames)[1]);
+        if (!pairs && n_frames > 1) fulls[1].upload_deferred(*(*frames)[1]);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
         if (byproducts_on()) save_edge(0, target);   // (the reference writes all edge-k.pcd before the loop; the files are the same)
         float acc_rads = 0.f;
@@ -329,7 +337,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             rgb_device_cloud &full = fulls[k & 1];
             if (pairs) features.upload(*(*pairs)[k].first);
             else {
-                if (k + 1 < n_frames) fulls[(k + 1) & 1].upload_async(*(*frames)[k + 1]);   // on the link while frame k is aligned
+                if (k + 1 < n_frames) fulls[(k + 1) & 1].upload_deferred(*(*frames)[k + 1]);   // on the link while frame k is aligned
                 extract_edge_features(full, features);
             }
             if (byproducts_on()) save_edge(k, features);

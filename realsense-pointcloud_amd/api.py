@@ -145,6 +145,16 @@ class DeviceCloud:
                                                    int(cloud.is_dense)), self.ctx.h)
         return self
 
+    def upload_deferred(self, cloud):
+        """upload_async() that returns before the records have been read (rsreg_cloud_upload_deferred): a thread of the
+        context stages them and queues their copy.  `cloud.points` must not change until a call that reads or rewrites
+        this DeviceCloud has returned (the array itself is kept alive here)."""
+        pts = np.ascontiguousarray(cloud.points)
+        self._deferred_src = pts
+        _l.check(_l.lib().rsreg_cloud_upload_deferred(self.h, pts.ctypes.data, len(pts), pts.dtype.itemsize, cloud.width, cloud.height,
+                                                      int(cloud.is_dense)), self.ctx.h)
+        return self
+
     def info(self):
         n, s = C.c_size_t(0), C.c_size_t(0)
         w, h, d = C.c_uint32(0), C.c_uint32(0), C.c_int(0)

@@ -1373,6 +1373,11 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     cloud_pool_clear(ctx);
     for (hipEvent_t e : ctx->ev_copy) (void)hipEventDestroy(e);
+    if (ctx->up_worker) {
+        ctx->up_worker->shutdown();
+        delete ctx->up_worker;
+        ctx->up_worker = nullptr;
+    }
     if (ctx->stream_copy) {
         (void)hipStreamSynchronize(ctx->stream_copy);
         (void)hipStreamDestroy(ctx->stream_copy);

@@ -28,7 +28,7 @@ EXPORTS = [
     "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels", "rsreg_ndt_set_centroid_mode", "rsreg_ndt_get_centroids",
     "rsreg_comm_unique_id", "rsreg_comm_init", "rsreg_comm_destroy", "rsreg_comm_allreduce_f64",
-    "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_upload_async", "rsreg_cloud_download", "rsreg_cloud_download_async", "rsreg_ctx_wait_downloads", "rsreg_cloud_info",
+    "rsreg_cloud_create", "rsreg_cloud_destroy", "rsreg_cloud_upload", "rsreg_cloud_upload_async", "rsreg_cloud_upload_deferred", "rsreg_cloud_download", "rsreg_cloud_download_async", "rsreg_ctx_wait_downloads", "rsreg_cloud_info",
     "rsreg_cloud_device_ptr", "rsreg_cloud_version", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_filter_async", "rsreg_cloud_transform", "rsreg_cloud_concat",
     "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
@@ -178,6 +178,7 @@ def lib():
     L.rsreg_cloud_destroy.argtypes = [vp]
     L.rsreg_cloud_upload.argtypes = [vp, vp, sz, sz, u32, u32, i32]
     L.rsreg_cloud_upload_async.argtypes = [vp, vp, sz, sz, u32, u32, i32]
+    L.rsreg_cloud_upload_deferred.argtypes = [vp, vp, sz, sz, u32, u32, i32]
     L.rsreg_cloud_download.argtypes = [vp, vp, sz]
     L.rsreg_cloud_download_async.argtypes = [vp, vp, sz]
     L.rsreg_ctx_wait_downloads.argtypes = [vp]

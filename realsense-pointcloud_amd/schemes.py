@@ -107,15 +107,58 @@ class HipDeviceBackend(HipBackend):
         """upload() whose PCIe copy runs beside the GPU's work on the frame before (one frame ahead in the frame loops)"""
         if isinstance(cloud, self.api.DeviceCloud):
             return cloud
-        return self.api.DeviceCloud(ctx=self.ctx or self.api.default_context()).upload_async(cloud)
+        return self.api.DeviceCloud(ctx=self.ctx or self.api.default_context()).upload_deferred(cloud)   # (the caller's frames stay put)
 
     def download(self, cloud):
         return cloud.download()
+
+    def result_stream(self, frames):
+        """the merged cloud of `frames` (host clouds; frame 0 first) as a _StreamedResult, or None"""
+        if len(frames) < 2:
+            return None
+        return _StreamedResult(self.ctx or self.api.default_context(), frames[0], sum(len(f) for f in frames))
 
     def concat_front(self, new, target):
         # in place: the handle then knows it grew by len(new) records in front, and the index the refining ICP has just used
         # is updated instead of rebuilt when the next frame's coarse aligner sets the grown cloud as its target
         return target.prepend(new)
+
+
+class _StreamedResult:
+    """The merged cloud a scheme returns, filled while its frame loop runs (detail::StreamedResult of
+    include/rsreg/schemes.hpp): frame 0 is copied on the host by a thread of its own, every later frame's moved points
+    arrive by DeviceCloud.download_async behind the work that made them."""
+
+    def __init__(self, ctx, frame0, capacity):
+        import threading
+        self.ctx = ctx
+        self.out = np.empty(capacity, frame0.points.dtype)
+        self.n, self.dense, self.pending = len(frame0), bool(frame0.is_dense), False
+        self.copy0 = threading.Thread(target=np.copyto, args=(self.out[:self.n], frame0.points))
+        self.copy0.start()
+
+    def append(self, moved):
+        got = moved.download_async(self.out, self.n)
+        self.pending = True
+        self.n += got
+        self.dense = self.dense and moved.info()[4]
+
+    def settle(self):
+        """nothing writes to `out` any more (also the way out of a frame loop that raised)"""
+        self.copy0.join()
+        if self.pending:
+            self.pending = False
+            self.ctx.wait_downloads()
+
+    def finish(self):
+        self.settle()
+        return PointCloud(self.out[:self.n], width=self.n, height=1, is_dense=self.dense)
+
+
+def _host_frames(clouds):
+    """the host clouds of a frame list if every frame is one (else None: nothing to stream into)"""
+    clouds = list(clouds)
+    return clouds if all(isinstance(c, PointCloud) for c in clouds) else None
 
 
 def _assign(dst, src):
@@ -128,9 +171,18 @@ class RegistrationScheme:
     # True: the reference's progress lines on stdout, text for text (types.hpp:35-41, icp_edge_based_registration.hpp:27-32,
     # 94-96,103-104,110,113,122,127, ndt_edge_based_registration.hpp:24-29,82-84,91-93,98,101,110,114)
     verbose = False
+    # device-resident frame loop only: every frame's moved points go to the host while the next frames are aligned, so the
+    # merged cloud is complete when the loop ends instead of one download after it (16 frames of 307 k points: 157 MB, 4 ms
+    # on the link).  False: one download at the end.  Same records either way.
+    stream_result = True
 
     def __init__(self, backend=None):
         self.backend = backend or HipDeviceBackend()
+
+    def _result_stream(self, frames):
+        make = getattr(self.backend, "result_stream", None)
+        frames = _host_frames(frames) if (self.stream_result and make) else None
+        return make(frames) if frames else None
 
     def _say(self, text, end="\n"):
         if self.verbose:
@@ -215,21 +267,31 @@ class IncrementalICP(RegistrationScheme):
         reduced_ahead = start_filter(1) if n > 1 else None
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
-        for k in range(1, n):
-            if k + 2 < n:
-                frames[k + 2] = b.prefetch(clouds[k + 2])
-            frame, reduced = frames.pop(k), reduced_ahead
-            reduced_ahead = start_filter(k + 1) if k + 1 < n else None
-            icp.setInputSource(reduced)
-            icp.setInputTarget(model)
-            icp.align()
-            if not icp.hasConverged():
-                continue
-            moved = b.transform(frame, icp.getFinalTransformation())
-            model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
-            self.transforms.append(icp.getFinalTransformation())
-            self.merged_frames.append(k)
-        return _assign(clouds[0], b.download(model))   # the caller's frame 0 has become the merged cloud
+        result = self._result_stream(clouds)
+        try:
+            for k in range(1, n):
+                if k + 2 < n:
+                    frames[k + 2] = b.prefetch(clouds[k + 2])
+                frame, reduced = frames.pop(k), reduced_ahead
+                reduced_ahead = start_filter(k + 1) if k + 1 < n else None
+                icp.setInputSource(reduced)
+                icp.setInputTarget(model)
+                icp.align()
+                if not icp.hasConverged():
+                    continue
+                moved = b.transform(frame, icp.getFinalTransformation())
+                model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
+                if result:
+                    result.append(moved)     # on its way to the host while the next frame is aligned
+                self.transforms.append(icp.getFinalTransformation())
+                self.merged_frames.append(k)
+        finally:
+            if result:
+                result.settle()
+        # the caller's frame 0 has become the merged cloud
+        if result:
+            return _assign(clouds[0], result.finish()) if self.merged_frames else clouds[0]
+        return _assign(clouds[0], b.download(model))
 
 
 class _EdgeBased(TwoPhaseRegistrationScheme):
@@ -260,6 +322,15 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         raise NotImplementedError
 
     def global_registration(self, pairs):
+        # the merged cloud goes to the host frame by frame when the frames came from there
+        result = self._result_stream(pairs.clouds if isinstance(pairs, _FramePairs) else [p[1] for p in pairs])
+        try:
+            return self._global_registration(pairs, result)
+        finally:
+            if result:
+                result.settle()
+
+    def _global_registration(self, pairs, result):
         b = self.backend
         self._say("[PCL] Performing edge-based registration with %s initial rotation guesses..." % ("dynamic" if self.use_imu else "static"))
         by = self.write_byproducts and self.has_byproducts
@@ -270,7 +341,7 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             icp.reuse_target_index = True    # the coarse ICP of the ICP scheme has just built the index of the same target
         voxel = b.voxel((0.01, 0.01, 0.01))
         coarse = self._coarse()
-        merged = b.upload(pairs[0][1])
+        merged = b.upload(pairs[0][1])             # (the whole merged cloud only without `result`)
         voxel.setInputCloud(b.upload(pairs[0][0]))
         target = voxel.filter()                    # frame-0 features: filtered in place, then grown
         if by:
@@ -306,14 +377,17 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             moved = b.transform(b.upload(pairs[k][1]), t_coarse)
             moved = b.transform(moved, icp.getFinalTransformation())
             target = b.concat_front(refined, target) if hasattr(b, "concat_front") else b.concat(refined, target)     # new points first
-            merged = b.concat(merged, moved)
+            if result:
+                result.append(moved)               # `*global = *global + *transformed`: on its way to the host already
+            else:
+                merged = b.concat(merged, moved)
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
         if isinstance(pairs[0][0], PointCloud):
             _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
         if by:
             self._save("edge_cloud.pcd", target)
         self._say("[PCL] Done")
-        out = b.download(merged)
+        out = result.finish() if result else b.download(merged)
         return PointCloud(out.points, width=len(out), height=1, is_dense=out.is_dense)
 
 

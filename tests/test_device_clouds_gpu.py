@@ -91,22 +91,25 @@ def test_schemes_device_loop_equals_host_loop(api, rs, kind):
     from rsreg_amd import schemes
     frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
     res = []
-    for backend in (schemes.HipBackend(), schemes.HipDeviceBackend()):
+    # host clouds; cloud handles with the merged cloud streamed to the host frame by frame (default); ... downloaded once
+    for backend, stream in ((schemes.HipBackend(), True), (schemes.HipDeviceBackend(), True), (schemes.HipDeviceBackend(), False)):
         if kind == "incremental":
             s = schemes.IncrementalICP(backend=backend)
         else:
             cls = schemes.ICPEdgeBasedRegistration if kind == "icp_edge" else schemes.NDTEdgeBasedRegistration
             s = cls(rads=-0.0261799, backend=backend)
+        s.stream_result = stream
         clouds = [f.copy() for f in frames]
         merged = s.registration(clouds)
         tr = s.transforms if kind == "incremental" else [t for pair in s.frame_transforms for t in pair]
         res.append((merged, clouds[0], [np.asarray(t).tobytes() for t in tr]))
-    (ma, c0a, ta), (mb, c0b, tb) = res
-    assert ta == tb and len(ta) >= 1
-    _same_records(ma, mb)
-    _same_records(c0a, c0b)                 # what the scheme did to the caller's frame 0 is the same too
-    if kind == "incremental":
-        assert ma is c0a and mb is c0b      # the reference returns (and grows) the caller's frame 0
+    (ma, c0a, ta) = res[0]
+    for mb, c0b, tb in res[1:]:
+        assert ta == tb and len(ta) >= 1
+        _same_records(ma, mb)
+        _same_records(c0a, c0b)                 # what the scheme did to the caller's frame 0 is the same too
+        if kind == "incremental":
+            assert ma is c0a and mb is c0b      # the reference returns (and grows) the caller's frame 0
 
 
 def test_cloud_buffers_are_recycled_without_changing_results(api, rs, frames, monkeypatch):
@@ -540,3 +543,44 @@ def test_download_async_lands_what_the_stream_had_when_it_was_asked(api, rs, fra
     assert lib.lib().rsreg_cloud_download_async(da.h, small.ctypes.data, 3) == lib.RSREG_ERR_INVALID_ARG
     assert lib.lib().rsreg_cloud_download_async(None, small.ctypes.data, 3) != 0
     assert lib.lib().rsreg_ctx_wait_downloads(None) != 0
+
+
+def test_upload_deferred_is_waited_for_like_upload_async(api, rs, frames):
+    """rsreg_cloud_upload_deferred returns before the records have been read (a thread of the context stages them);
+    every consumer still sees them: download, copy, transform, an alignment, a second deferred upload into the same
+    handle, more uploads in flight than staging buffers, a drop right after the call, and deferred and async uploads
+    mixed on one context."""
+    a, b, c = frames
+    ctx = api.Context(0)
+    T = rs.synth.small_transform(2.0, (0.01, 0.02, -0.01)).astype(np.float32)
+
+    def later(cl):
+        return api.DeviceCloud(ctx=ctx).upload_deferred(cl)
+
+    _same_records(later(a).download(), a)
+    _same_records(later(b).copy().download(), b)
+    _same_records(api.transformPointCloud(later(a), T, ctx).download(), api.transformPointCloud(a, T, ctx))
+    again = later(a).upload_deferred(b)
+    _same_records(again.download(), b)
+    held = [later(x) for x in (a, b, c, a, b, c)]          # six in flight, two staging buffers
+    mixed = api.DeviceCloud(ctx=ctx).upload_async(c)
+    later(a)                                               # dropped at once
+    for dc, want in zip(held, (a, b, c, a, b, c)):
+        _same_records(dc.download(), want)
+    _same_records(mixed.download(), c)
+    _same_records((later(a) + later(b)).download(), a + b)
+    res = []
+    for src, tgt in ((later(b), later(a)), (api.DeviceCloud(b, ctx), api.DeviceCloud(a, ctx))):
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(max_iterations=5, criteria_mode=1, max_correspondence_distance=0.05)
+        icp.setInputSource(src)
+        icp.setInputTarget(tgt)
+        out = icp.align()
+        res.append((icp.getFinalTransformation().tobytes(), out.download()))
+    assert res[0][0] == res[1][0]
+    _same_records(res[0][1], res[1][1])
+    empty = later(rs.PointCloud())
+    assert len(empty) == 0 and len(empty.download()) == 0
+    from rsreg_amd import lib
+    assert lib.lib().rsreg_cloud_upload_deferred(None, None, 0, 32, 0, 0, 1) == lib.RSREG_ERR_INVALID_ARG
+    assert lib.lib().rsreg_cloud_upload_deferred(held[0].h, None, 5, 32, 5, 1, 1) == lib.RSREG_ERR_INVALID_ARG

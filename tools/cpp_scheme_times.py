@@ -27,7 +27,7 @@ with tempfile.TemporaryDirectory() as d:
         paths.append(p)
     for mode in ("incremental", "icp_edge", "ndt_edge"):
         for host_loop in ("0", "1"):
-            env = dict(os.environ, RSREG_SCHEME_TIME="3" if host_loop == "0" else "2", RSREG_SCHEME_HOST_LOOP=host_loop)
+            env = dict(os.environ, RSREG_SCHEME_TIME=os.environ.get("RSREG_SCHEME_REPS", "3") if host_loop == "0" else "2", RSREG_SCHEME_HOST_LOOP=host_loop)
             r = subprocess.run([exe, mode, os.path.join(d, "out_" + mode)] + paths, env=env, stderr=subprocess.PIPE, text=True, check=True)
             for line in r.stderr.strip().splitlines():
                 print(("device clouds  " if host_loop == "0" else "host clouds    ") + line)

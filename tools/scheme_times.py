@@ -29,6 +29,7 @@ for name, make in (("IncrementalICP", lambda b: schemes.IncrementalICP(backend=b
         for rep in range(3):
             fr = copy_frames()
             s = make(backend())
+            s.stream_result = os.environ.get("RSREG_SCHEME_NO_STREAM", "0") != "1"
             t = time.perf_counter()
             out = s.registration(fr)
             best = min(best, time.perf_counter() - t)

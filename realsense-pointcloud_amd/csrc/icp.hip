@@ -641,6 +641,14 @@ int join_source(rsreg_ctx *ctx)
     return RSREG_OK;
 }
 
+// Sources of at most this many points are searched in the caller's order (k_source_plain).  RSREG_SORT_SMALL=1: never.
+constexpr size_t kPlainSourceMax = 65536;
+bool source_is_small(size_t n)
+{
+    static const bool sort_small = std::getenv("RSREG_SORT_SMALL") && std::getenv("RSREG_SORT_SMALL")[0] == '1';
+    return n <= kPlainSourceMax && !sort_small;
+}
+
 // The part of a source load that queues work on stream_src (after one round trip for the bounding box); runs on the
 // context's worker thread (rsreg_ctx.hpp: SourceWorker) or, with RSREG_NO_WORKER=1, on the caller's.
 int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
@@ -651,6 +659,14 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
+        if (source_is_small(n)) {   // one launch, the caller's order
+            k_source_plain<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, ctx->d_src_all.as<float4>(), ctx->d_src.as<float4>(),
+                                                                           ctx->d_cur.as<float4>(), ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(),
+                                                                           ctx->d_first.as<uint32_t>(), d_misc + 12, h_misc + 32);
+            RSREG_HIP(ctx, hipGetLastError());
+            RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
+            return RSREG_OK;
+        }
         float mn[3], mx[3];
         uint32_t nfin = 0;
         int rc = device_bbox_on(ctx, st, d_misc, h_misc, d_misc + 64, d_raw, n, stride, mn, mx, &nfin);
@@ -771,7 +787,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         // the raw cloud may have been produced (uploaded, filtered, transformed) on the main stream just now
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         static const bool no_worker = std::getenv("RSREG_NO_WORKER") && std::getenv("RSREG_NO_WORKER")[0] == '1';
-        if (no_worker) {
+        if (no_worker || source_is_small(n)) {   // (a small source is one launch: not worth a hand-over)
             int rc = load_source_queue(ctx, d_raw, n, stride);
             if (rc) return rc;
         } else {

@@ -423,6 +423,31 @@ __global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all
     cur[u] = s;
 }
 
+// The whole load of a SMALL source in the caller's order (no Morton order, no merging of exact copies: at <= 65 536 points
+// neither buys the search anything -- 50 k raw frame, 36 k edge cloud: the same 30.1 us and 13 us per launch either way,
+// profiles/r03_small_sources.txt -- and together they are 17 launches and a round trip to the host):
+// src_all[j] = src[j] = cur[j] = {xyz, 1 or 0 (non-finite)}, perm / uniq_of / first = identity, count = n.
+__global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t stride, uint32_t n, float4 *src_all, float4 *src, float4 *cur,
+                                                         uint32_t *perm, uint32_t *uniq_of, uint32_t *first, uint32_t *count, uint32_t *host_count)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float *p = rec_xyz(raw, stride, j);
+    const float x = p[0], y = p[1], z = p[2];
+    const float4 s = make_float4(x, y, z, finite3(x, y, z) ? 1.0f : 0.0f);
+    src_all[j] = s;
+    src[j] = s;
+    cur[j] = s;
+    perm[j] = j;
+    uniq_of[j] = j;
+    first[j] = j;
+    if (j == n - 1) {
+        first[n] = n;
+        count[0] = n;
+        host_count[0] = n;   // (pinned host memory: read at the join)
+    }
+}
+
 // cur = guess * src (or src); also: no seeds yet
 __global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, uint32_t n, Mat34 guess, int apply_guess,
                                                            float4 *cur, int *seed)

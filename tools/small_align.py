@@ -22,6 +22,8 @@ vox.setInputCloud(db); sb = vox.filter()
 print("edge clouds: %d and %d points, filtered %d and %d" % (len(ea), len(eb), len(ta), len(sb)))
 icp = api.IterativeClosestPoint()
 icp.params = api.icp_params(reference=True)
+if len(sys.argv) > 2:   # <iterations>: that many iterations whatever the criteria say, 5 cm gate
+    icp.params = api.icp_params(max_iterations=int(sys.argv[2]), criteria_mode=1, max_correspondence_distance=0.05)
 for k in range(reps + 5):
     if k == 5:
         t = time.perf_counter()
@@ -29,4 +31,4 @@ for k in range(reps + 5):
     icp.setInputTarget(ta)
     icp.align()
 dt = (time.perf_counter() - t) / reps
-print("align with reference parameters: %.3f ms, %d iteration(s), %d correspondences" % (dt * 1e3, icp.result.iterations, icp.result.n_correspondences))
+print("align: %.3f ms, %d iteration(s), %d correspondences" % (dt * 1e3, icp.result.iterations, icp.result.n_correspondences))

@@ -168,23 +168,27 @@ class IncrementalICP : public RegistrationScheme {
         ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
-        // two frames ahead on the PCIe link, one frame ahead in the voxel filter: the 1 m filter is one wave adding floats
-        // one after the other, and runs under the alignment of the frame before on a stream of its own
+        // four frames ahead on the PCIe link, three frames ahead in the voxel filter: the 1 m filter is one wave adding
+        // floats one after the other (0.4 ms a frame) on a stream of its own; three of them run side by side under the
+        // alignments of the frames before
         const size_t n = clouds.size();
-        rgb_device_cloud model(*clouds[0]), reduced_of[2], aligned, frames[3], moved;
+        constexpr size_t kFilters = 3, kUploads = 4, kRing = kUploads + 1;
+        rgb_device_cloud model, reduced_of[kFilters + 1], aligned, frames[kRing], moved;
+        for (size_t k = 1; k < std::min<size_t>(kUploads + 1, n); ++k) frames[k % kRing].upload_deferred(*clouds[k]);   // (the worker starts on these ...)
+        model.upload(*clouds[0]);                                                                                        // (... while frame 0 goes up from here)
         std::unique_ptr<detail::StreamedResult> result;
         if (stream_result && n > 1) {
             size_t capacity = 0;
             for (auto &c : clouds) capacity += c->size();
             result.reset(new detail::StreamedResult(model.context(), *clouds[0], capacity));
         }
-        for (size_t k = 1; k < std::min<size_t>(3, n); ++k) frames[k % 3].upload_deferred(*clouds[k]);
-        if (n > 1) voxel.filter_async(frames[1], reduced_of[1]);
+        for (size_t k = 1; k < std::min<size_t>(kFilters + 1, n); ++k) voxel.filter_async(frames[k % kRing], reduced_of[k % (kFilters + 1)]);
         size_t merged_frames = 0;
         for (size_t k = 1; k < n; ++k) {
-            rgb_device_cloud &frame = frames[k % 3], &reduced = reduced_of[k & 1];
-            if (k + 2 < n) frames[(k + 2) % 3].upload_deferred(*clouds[k + 2]);
-            if (k + 1 < n) voxel.filter_async(frames[(k + 1) % 3], reduced_of[(k + 1) & 1]);
+            rgb_device_cloud &frame = frames[k % kRing], &reduced = reduced_of[k % (kFilters + 1)];
+            // (frame k + kUploads takes the buffer of frame k - 1, the filtered frame k + kFilters that of frame k - 1)
+            if (k + kUploads < n) frames[(k + kUploads) % kRing].upload_deferred(*clouds[k + kUploads]);
+            if (k + kFilters < n) voxel.filter_async(frames[(k + kFilters) % kRing], reduced_of[(k + kFilters) % (kFilters + 1)]);
             icp.setInputSource(reduced);
             icp.setInputTarget(model);
             icp.align(aligned);

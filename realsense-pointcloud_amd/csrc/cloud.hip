@@ -26,6 +26,11 @@ struct rsreg_cloud {
     hipEvent_t ev_filled = nullptr;
     mutable bool filling = false;
     uint64_t up_ticket = 0;   // the upload worker's job that stages the records and queues their copy
+    // rsreg_cloud_filter_async: the side worker's job that runs the filter INTO this cloud; until it has run, n / width are
+    // not known (resolve)
+    mutable bool filter_pending = false;
+    uint64_t filter_ticket = 0;
+    int filter_rc = 0;
     // rsreg_cloud_download_async: a copy of these records to the host may still be reading them
     hipEvent_t ev_down = nullptr;
     mutable bool downloading = false;
@@ -47,7 +52,7 @@ constexpr size_t kScanSourceLimit = 64;       // (= kScanMaxSource of icp_kernel
 constexpr size_t kScanTargetFloor = 32768;    // ... target points at least, for the search without an index
 
 namespace rsreg {
-int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, bool side);   // voxel.hip
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, int side_set);   // voxel.hip
 }
 
 namespace {
@@ -76,9 +81,23 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
 // Whoever reads or rewrites a cloud first waits (on the host) for an upload of it that is still in flight: by then a
 // frame prefetched one step of the frame loop earlier has long arrived, and a host wait is right whatever stream the
 // reader works on.
+// A cloud a filter is still being queued INTO (rsreg_cloud_filter_async) has no size yet: whoever wants to know it, or
+// to touch the records, waits for the side worker to have run that job.
+hipError_t resolve(const rsreg_cloud *c)
+{
+    if (!c || !c->filter_pending) return hipSuccess;
+    c->filter_pending = false;
+    (void)c->ctx->side_worker->wait(c->filter_ticket);
+    return c->filter_rc ? hipErrorUnknown : hipSuccess;   // (the job has left its message in the context: fail())
+}
+
 hipError_t settle(const rsreg_cloud *c)
 {
     if (!c) return hipSuccess;
+    {
+        const hipError_t e = resolve(c);
+        if (e != hipSuccess) return e;
+    }
     if (c->downloading) {   // whatever the main stream does to the cloud next comes after the copy that is reading it
         c->downloading = false;
         hipError_t e = hipStreamWaitEvent(c->ctx->stream, c->ev_down, 0);
@@ -323,8 +342,10 @@ int rsreg_cloud_upload_deferred(rsreg_cloud *c, const void *points, size_t n, si
 
 int rsreg_cloud_download(const rsreg_cloud *c, void *out, size_t capacity)
 {
-    if (!c || (c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
+    if (!c) return RSREG_ERR_INVALID_ARG;
     rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, resolve(c));
+    if ((c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
     if (!c->n) return RSREG_OK;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
@@ -360,6 +381,7 @@ int rsreg_cloud_download(const rsreg_cloud *c, void *out, size_t capacity)
 int rsreg_cloud_info(const rsreg_cloud *c, size_t *n, size_t *stride, uint32_t *width, uint32_t *height, int *is_dense)
 {
     if (!c) return RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(c->ctx, resolve(c));
     if (n) *n = c->n;
     if (stride) *stride = c->stride;
     if (width) *width = c->width;
@@ -406,6 +428,7 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
 {
     int rc = check_pair(ctx, in, out);
     if (rc || !leaf) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, resolve(in));
     if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
     if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
@@ -413,7 +436,7 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
     RSREG_HIP(ctx, settle(out));
     uint32_t nr = 0;
     const size_t stride = in->stride;
-    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, false);
+    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, -1);
     if (rc) return rc;
     RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));   // (in == out: the input has been consumed by now)
     if (nr) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream));
@@ -431,33 +454,54 @@ int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float 
 {
     int rc = check_pair(ctx, in, out);
     if (rc || !leaf || in == out) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, resolve(in));
     if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
     if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, settle(in));
     RSREG_HIP(ctx, settle(out));
-    if (!ctx->stream_side) {
-        RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_side, hipStreamNonBlocking));
-        RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
-    }
+    // the scratch sets take turns: a filter queues behind the one that used its set last (same stream) and runs beside
+    // the filters of the other sets
+    const int set = ctx->side_next;
+    ctx->side_next = (ctx->side_next + 1) % rsreg_ctx::kSideSets;
+    rsreg_ctx::SideSet &ss = ctx->side_sets[set];
+    if (!ss.stream) RSREG_HIP(ctx, hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+    if (!ctx->ev_side_gate) RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
+    if (!ctx->side_worker) ctx->side_worker = new rsreg::TicketWorker();
     // what the main stream holds so far comes first: `in` may have been produced there, and the buffer `out` is about
     // to get may come from the pool with work of its previous owner still queued
     RSREG_HIP(ctx, hipEventRecord(ctx->ev_side_gate, ctx->stream));
-    RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_side_gate, 0));
-    if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_side, ctx->ev_src_done, 0)); }
-    uint32_t nr = 0;
-    const size_t stride = in->stride;
-    rc = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, leaf, &nr, true);
-    if (rc) return rc;
-    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (size_t)nr * stride + 16));
-    if (nr) {
-        if (!out->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&out->ev_filled, hipEventDisableTiming));
-        RSREG_HIP(ctx, hipMemcpyAsync(out->buf.ptr, ctx->vs_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ctx->stream_side));
-        RSREG_HIP(ctx, hipEventRecord(out->ev_filled, ctx->stream_side));
-        out->filling = true;
-    }
+    RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_side_gate, 0));
+    if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_src_done, 0)); }
+    const size_t stride = in->stride, n_in = in->n;
+    // the filter's twenty launches and its round trip for the number of output records are a third of a frame's host time
+    // in IncrementalICP's loop: they run on the side worker's thread.  The output cannot be larger than the input: room
+    // for that is made here (the buffer pool is the caller's thread's), its size is known when the job has run (resolve).
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, n_in * stride + 16));
+    if (!out->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&out->ev_filled, hipEventDisableTiming));
+    const char *src = in->buf.as<char>();
+    const float l0 = leaf[0], l1 = leaf[1], l2 = leaf[2];
     out->version++;
-    out->n = nr; out->stride = stride; out->width = nr; out->height = 1; out->is_dense = 0;
+    out->n = 0; out->stride = stride; out->width = 0; out->height = 1; out->is_dense = 0;
+    out->filter_rc = 0;
+    out->filter_ticket = ctx->side_worker->post([ctx, out, src, n_in, stride, l0, l1, l2, set]() -> int {
+        rsreg_ctx::SideSet &ws = ctx->side_sets[set];
+        const float lf[3] = {l0, l1, l2};
+        uint32_t nr = 0;
+        int r = hipSetDevice(ctx->device) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
+        if (!r) r = voxel_filter_device(ctx, src, (uint32_t)n_in, stride, lf, &nr, set);
+        if (!r && nr) {
+            if (hipMemcpyAsync(out->buf.ptr, ws.out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ws.stream) != hipSuccess ||
+                hipEventRecord(out->ev_filled, ws.stream) != hipSuccess)
+                r = fail(ctx, RSREG_ERR_HIP, "queueing the filtered records");
+        }
+        out->filter_rc = r;
+        out->n = nr;
+        out->width = nr;
+        return 0;
+    });
+    out->filter_pending = true;
+    out->filling = true;   // (settle: the event behind the copy; never recorded when the output is empty)
     return RSREG_OK;
 }
 
@@ -493,8 +537,10 @@ const rsreg_ctx *rsreg_cloud_ctx_(const rsreg_cloud *c) { return c ? c->ctx : nu
 // frames are aligned: the merged cloud of sixteen 307 k-point frames is 157 MB, 4 ms on the link at the end otherwise.
 int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
 {
-    if (!c || (c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
+    if (!c) return RSREG_ERR_INVALID_ARG;
     rsreg_ctx *ctx = c->ctx;
+    RSREG_HIP(ctx, resolve(c));
+    if ((c->n && !out) || capacity < c->n) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, settle(c));
     if (!c->n) return RSREG_OK;
@@ -542,6 +588,8 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
 {
     int rc = check_pair(ctx, a, b);
     if (rc || !out || out->ctx != ctx) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, resolve(a));
+    RSREG_HIP(ctx, resolve(b));
     if (a->n && b->n && a->stride != b->stride) return fail(ctx, RSREG_ERR_INVALID_ARG, "record strides differ");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, settle(a));

@@ -338,7 +338,7 @@ int update_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t
     uint32_t *table = ctx->d_dense.as<uint32_t>();
     const uint32_t xbits = (uint32_t)gp.xbits;
     // counters: d_misc[16..19] = non-finite new points, new points outside the box, occupied cells, exact copies
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 16, 0, 20, st));
+    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 16, 0, 34 * 4, st));   // stats at words 16-20, merge_finish's two counts at 48-49
     k_dense_keys_new<KeyT><<<div_up(m, kBlock), kBlock, 0, st>>>(d_pts, stride, new_lo, m, g, xbits, keys, vals, d_misc + 16);
     RSREG_HIP(ctx, hipGetLastError());
     int id_bits = 1;
@@ -369,18 +369,18 @@ int update_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t
                                                                       ctx->d_pos_of.as<uint32_t>());
     RSREG_HIP(ctx, hipGetLastError());
     k_dense_merge_finish<KeyT><<<div_up(n_old + m, kBlock), kBlock, 0, st>>>(mkeys, ctx->d_tgt_merge.as<float4>(), d_misc + 16, n_old, m, xbits, new_lo, new_n,
-                                                                             g.sx, g.sxy, table, table + (total + 2), d_misc + 16);
+                                                                             g.sx, g.sxy, table, table + (total + 2), d_misc + 48);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 20, d_misc + 16, 20, hipMemcpyDeviceToHost, st));
+    RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 20, d_misc + 16, 34 * 4, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t outside = h_misc[21], copies = h_misc[23];
+    const uint32_t outside = h_misc[21], copies = h_misc[20 + 33];
     if (std::getenv("RSREG_INC_VERBOSE"))
         std::fprintf(stderr, "[rsreg] index update: %u old + %u new points, %u outside the box, %u exact copies -> %s\n", n_old, m, outside, copies,
                      outside || copies ? "build from scratch" : "merged");
     if (outside || copies) return 1;   // (the old index is untouched except for table entries and occupancy bits a fresh build rewrites)
     std::swap(ctx->d_tgt_sorted, ctx->d_tgt_merge);
     gp.n_points = n_old + m - h_misc[20];
-    gp.n_cells = h_misc[22];
+    gp.n_cells = h_misc[20 + 32];
     ctx->n_target_raw = n_total;
     rsreg_grid_info &gi = ctx->grid_info;
     gi.n_target_points = (uint32_t)(gi.n_target_points + m - h_misc[24]);
@@ -655,11 +655,12 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
 {
     {
         RSREG_HIP(ctx, hipSetDevice(ctx->device));   // (this may be the context's worker thread)
-        hipStream_t st = ctx->stream_src;
-        RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
-        if (source_is_small(n)) {   // one launch, the caller's order
+        if (source_is_small(n)) {
+            // one launch, the caller's order -- on the MAIN stream: the streams of a process share a few hardware queues,
+            // and a kernel on the source stream can find itself behind a 0.4 ms voxel filter of a side stream
+            hipStream_t st = ctx->stream;
             k_source_plain<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, ctx->d_src_all.as<float4>(), ctx->d_src.as<float4>(),
                                                                            ctx->d_cur.as<float4>(), ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(),
                                                                            ctx->d_first.as<uint32_t>(), d_misc + 12, h_misc + 32);
@@ -667,6 +668,8 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
             return RSREG_OK;
         }
+        hipStream_t st = ctx->stream_src;
+        RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         float mn[3], mx[3];
         uint32_t nfin = 0;
         int rc = device_bbox_on(ctx, st, d_misc, h_misc, d_misc + 64, d_raw, n, stride, mn, mx, &nfin);
@@ -1376,9 +1379,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
-                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys,
-                      &ctx->vs_out, &ctx->vs_keys, &ctx->vs_keys_alt, &ctx->vs_vals, &ctx->vs_vals_alt, &ctx->vs_flags, &ctx->vs_scan, &ctx->vs_cent,
-                      &ctx->vs_misc, &ctx->vs_tmp};
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys};
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
     ctx->h_smisc.release();
@@ -1413,12 +1414,20 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         for (hipEvent_t e : ctx->ev_down) (void)hipEventDestroy(e);
     }
     for (rsreg::PinnedBuf &b : ctx->h_down) b.release();
-    if (ctx->stream_side) {
-        (void)hipStreamSynchronize(ctx->stream_side);
-        (void)hipStreamDestroy(ctx->stream_side);
-        (void)hipEventDestroy(ctx->ev_side_gate);
+    if (ctx->side_worker) {
+        ctx->side_worker->shutdown();
+        delete ctx->side_worker;
+        ctx->side_worker = nullptr;
     }
-    ctx->vs_host.release();
+    for (rsreg_ctx::SideSet &ss : ctx->side_sets) {
+        if (ss.stream) {
+            (void)hipStreamSynchronize(ss.stream);
+            (void)hipStreamDestroy(ss.stream);
+        }
+        for (DevBuf *b : {&ss.out, &ss.keys, &ss.keys_alt, &ss.vals, &ss.vals_alt, &ss.flags, &ss.scan, &ss.cent, &ss.misc, &ss.tmp}) b->release();
+        ss.host.release();
+    }
+    if (ctx->ev_side_gate) (void)hipEventDestroy(ctx->ev_side_gate);
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_merge(const float4 *old_sorted
 
 // Over the merged run: the table entries of every cell (first point, and the end of the cell before: k_dense_scatter's
 // rule), the occupancy bits of cells that new points start, the far-away points behind the run, and two counts:
-// stats[2] = occupied cells, stats[3] = exact copies of a predecessor (the build would drop them: the caller builds
-// afresh when there is one).  [new_lo, new_lo + new_n): the original indices of the new points.
-// *counter += the number of lanes of this wave with `yes`: one atomic per wave (one per LANE on a single address is what
-// the kernel below used to spend 50 of its 57 us on: the occupied cells of a 5 x 10^5-point target are 10^5 atomics)
+// counts[0] = occupied cells, counts[1] = exact copies of a predecessor (the build would drop them: the caller builds
+// afresh when there is one).  `counts` lies in another cache line than stats_in: every thread reads stats_in[0].  [new_lo, new_lo + new_n): the original indices of the new points.
+// *counter += the number of lanes of this wave with `yes`: one atomic per wave.  (The kernel below takes 20-95 us for
+// 7 x 10^4 - 6 x 10^5 points whatever its counters or occupancy bits do: its cost is two scattered 4-byte stores per
+// occupied cell into a table of 10^7 slots, as in a build.)
 __device__ __forceinline__ void wave_count(uint32_t *counter, bool yes)
 {
     const unsigned long long votes = __ballot(yes);
@@ -264,7 +265,7 @@ __device__ __forceinline__ void wave_count(uint32_t *counter, bool yes)
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_dense_merge_finish(const KeyT *keys, float4 *merged, const uint32_t *stats_in, uint32_t n_old, uint32_t m,
                                                                uint32_t xbits, uint32_t new_lo, uint32_t new_n, int sx, int sxy, uint32_t *table,
-                                                               uint32_t *nbr, uint32_t *stats)
+                                                               uint32_t *nbr, uint32_t *counts)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = n_old + m - stats_in[0];
@@ -283,11 +284,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_merge_finish(const KeyT *keys,
                 const float4 a = merged[p], b = merged[p - 1];
                 copy = a.x == b.x && a.y == b.y && tgt_z(a) == tgt_z(b);
             }
-            if (cstart) table[(uint32_t)(kp >> xbits) + 1u] = p;
+            // (the cell before ends here; when it is the neighbouring slot, the store below writes the same word)
+            if (cstart && (uint32_t)(kp >> xbits) + 1u != slot) table[(uint32_t)(kp >> xbits) + 1u] = p;
         }
     }
-    wave_count(&stats[3], copy);
-    wave_count(&stats[2], cstart);
+    wave_count(&counts[1], copy);
+    wave_count(&counts[0], cstart);
     if (!in) return;
     if (cstart) {
         table[slot] = p;

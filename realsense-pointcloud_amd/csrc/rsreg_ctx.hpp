@@ -385,12 +385,19 @@ struct rsreg_ctx {
 
     // ---- ApproximateVoxelGrid on the device (voxel.hip)
     rsreg::DevBuf d_vox_in, d_vox_out, d_vox_cent;
-    // rsreg_cloud_filter_async: a second scratch set and a side stream, so that the filter of the next frame (one wave
-    // per long run, latency-bound) runs under the alignment of this one; ev_side_gate lets it start after the main stream
-    hipStream_t stream_side = nullptr;
+    // rsreg_cloud_filter_async: scratch sets and streams of their own, so that the filters of the next frames (one wave
+    // per long run, latency-bound: 0.4 ms for PCL's default 1 m leaf) run under the alignment of this one AND beside each
+    // other; a set is used again in turn, behind the filter that used it last (same stream).  ev_side_gate lets a filter
+    // start after what the main stream holds.
+    static constexpr int kSideSets = 3;
+    struct SideSet {
+        hipStream_t stream = nullptr;
+        rsreg::DevBuf out, keys, keys_alt, vals, vals_alt, flags, scan, cent, misc, tmp;
+        rsreg::PinnedBuf host;
+    } side_sets[kSideSets];
+    int side_next = 0;
     hipEvent_t ev_side_gate = nullptr;
-    rsreg::DevBuf vs_out, vs_keys, vs_keys_alt, vs_vals, vs_vals_alt, vs_flags, vs_scan, vs_cent, vs_misc, vs_tmp;
-    rsreg::PinnedBuf vs_host;
+    rsreg::TicketWorker *side_worker = nullptr;   // (queues those filters: rsreg_cloud_filter_async returns at once)
 
     // ---- NDT
     bool have_ndt_target = false;

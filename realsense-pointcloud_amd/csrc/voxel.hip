@@ -284,23 +284,25 @@ namespace rsreg {
 
 // The filter on records already in HBM (d_in, N records of `stride` bytes); the filtered records
 // land in the scratch set's `out`, *n_out of them.  One host synchronisation (the number of runs); what follows it
-// (the runs' sums, their order, the output records) is only queued.  `side`: the context's second scratch set and its
-// side stream (rsreg_cloud_filter_async: the filter of the next frame under the alignment of this one).
-int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, bool side)
+// (the runs' sums, their order, the output records) is only queued.  `side` >= 0: that scratch set of the context and its
+// stream (rsreg_cloud_filter_async: the filters of the next frames under the alignment of this one); -1: the main set.
+int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, int side_set)
 {
     *n_out = 0;
     if (N == 0) return RSREG_OK;
-    hipStream_t st = side ? ctx->stream_side : ctx->stream;
+    const bool side = side_set >= 0;
+    rsreg_ctx::SideSet &ss = ctx->side_sets[side ? side_set : 0];
+    hipStream_t st = side ? ss.stream : ctx->stream;
     const size_t n = N;
     const float ivx = 1.0f / leaf[0], ivy = 1.0f / leaf[1], ivz = 1.0f / leaf[2];
     // buffers (the main set is shared with the ICP index build: nothing on the main stream overlaps an ICP call in
     // flight; the side set is the side stream's own)
-    DevBuf &b_out = side ? ctx->vs_out : ctx->d_vox_out, &b_keys = side ? ctx->vs_keys : ctx->d_keys,
-           &b_keys_alt = side ? ctx->vs_keys_alt : ctx->d_keys_alt, &b_vals = side ? ctx->vs_vals : ctx->d_vals,
-           &b_vals_alt = side ? ctx->vs_vals_alt : ctx->d_vals_alt, &b_flags = side ? ctx->vs_flags : ctx->d_flags,
-           &b_scan = side ? ctx->vs_scan : ctx->d_scan, &b_cent = side ? ctx->vs_cent : ctx->d_vox_cent,
-           &b_misc = side ? ctx->vs_misc : ctx->d_misc, &b_tmp = side ? ctx->vs_tmp : ctx->d_tmp;
-    PinnedBuf &b_host = side ? ctx->vs_host : ctx->h_sums;
+    DevBuf &b_out = side ? ss.out : ctx->d_vox_out, &b_keys = side ? ss.keys : ctx->d_keys,
+           &b_keys_alt = side ? ss.keys_alt : ctx->d_keys_alt, &b_vals = side ? ss.vals : ctx->d_vals,
+           &b_vals_alt = side ? ss.vals_alt : ctx->d_vals_alt, &b_flags = side ? ss.flags : ctx->d_flags,
+           &b_scan = side ? ss.scan : ctx->d_scan, &b_cent = side ? ss.cent : ctx->d_vox_cent,
+           &b_misc = side ? ss.misc : ctx->d_misc, &b_tmp = side ? ss.tmp : ctx->d_tmp;
+    PinnedBuf &b_host = side ? ss.host : ctx->h_sums;
     RSREG_HIP(ctx, b_out.reserve(n * stride));
     RSREG_HIP(ctx, b_keys.reserve(n * 8));
     RSREG_HIP(ctx, b_keys_alt.reserve(n * 8));
@@ -375,7 +377,7 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     }
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
     uint32_t nr = 0;
-    int rc = voxel_filter_device(ctx, ctx->d_vox_in.as<char>(), (uint32_t)n, stride, leaf, &nr, false);
+    int rc = voxel_filter_device(ctx, ctx->d_vox_in.as<char>(), (uint32_t)n, stride, leaf, &nr, -1);
     if (rc || nr == 0) return rc;
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_vox_out.ptr, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));

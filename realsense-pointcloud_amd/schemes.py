@@ -256,24 +256,29 @@ class IncrementalICP(RegistrationScheme):
         icp = b.icp()
         model = b.upload(clouds[0])       # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
         n = len(clouds)
-        # two frames ahead on the PCIe link, one frame ahead in the voxel filter (the 1 m filter is one wave adding floats
-        # one after the other: it runs under the alignment of the frame before, on a stream of its own)
-        frames = {k: b.prefetch(clouds[k]) for k in range(1, min(3, n))}
+        # four frames ahead on the PCIe link, three frames ahead in the voxel filter (the 1 m filter is one wave adding floats
+        # one after the other, 0.4 ms a frame: three of them run side by side, each on a stream of its own, under the
+        # alignments of the frames before)
+        n_filters, n_uploads = 3, 4
+        frames = {k: b.prefetch(clouds[k]) for k in range(1, min(n_uploads + 1, n))}
 
         def start_filter(k):
             voxel.setInputCloud(frames[k])
             return voxel.filter_async() if hasattr(voxel, "filter_async") and not isinstance(frames[k], PointCloud) else voxel.filter()
 
-        reduced_ahead = start_filter(1) if n > 1 else None
+        ahead = isinstance(b, HipDeviceBackend)       # (host clouds: nothing runs ahead, a frame is filtered when its turn comes)
+        reduced_of = {k: start_filter(k) for k in range(1, min(n_filters + 1, n))} if ahead else {}
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
         result = self._result_stream(clouds)
         try:
             for k in range(1, n):
-                if k + 2 < n:
-                    frames[k + 2] = b.prefetch(clouds[k + 2])
-                frame, reduced = frames.pop(k), reduced_ahead
-                reduced_ahead = start_filter(k + 1) if k + 1 < n else None
+                if k + n_uploads < n:
+                    frames[k + n_uploads] = b.prefetch(clouds[k + n_uploads])
+                if ahead and k + n_filters < n:
+                    reduced_of[k + n_filters] = start_filter(k + n_filters)
+                reduced = reduced_of.pop(k) if ahead else start_filter(k)
+                frame = frames.pop(k)
                 icp.setInputSource(reduced)
                 icp.setInputTarget(model)
                 icp.align()

@@ -327,10 +327,11 @@ int rsreg_cloud_version(const rsreg_cloud *cloud, uint64_t *id, uint64_t *versio
 int rsreg_cloud_copy(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
 /* ApproximateVoxelGrid::filter, same records in the same order as the host filter; in == out allowed */
 int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);
-/* The same on a side stream of the context: returns once the number of output records is known, the sums of the voxels
- * still running; whichever call touches `out` next waits for them.  The frame loops filter frame k + 1 this way before
- * they align frame k (incremental_icp.hpp:54-55 filters every frame independently of the registration).  `in` must stay
- * alive and unchanged until `out` has been used; in != out. */
+/* The same queued by a thread of the context on a stream and scratch of its own: returns at once; the number of output
+ * records is known, and the records are there, when a call that takes `out` has waited for them (every one does).  The
+ * frame loops filter the next frames this way while they align this one (incremental_icp.hpp:54-55 filters every frame
+ * independently of the registration).  `in` must stay alive and unchanged until `out` has been used; in != out.  `in`
+ * may be the output of rsreg_cloud_edge_features_async that has not run yet: the jobs run in the order of the calls. */
 int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out);
 /* pcl::transformPointCloud; in == out allowed */
 int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float transform[16], rsreg_cloud *out);
@@ -366,6 +367,11 @@ int rsreg_ndt_align_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
 int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t width, uint32_t height, size_t stride,
                                 void *out, int32_t *indices_out, size_t *n_out);
 int rsreg_cloud_edge_features(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
+/* rsreg_cloud_edge_features queued like rsreg_cloud_filter_async: the edge schemes extract (and then filter) the features
+ * of frame k + 1 beside the two alignments of frame k -- the reference extracts the features of all frames before it
+ * registers any (types.hpp:30-43).  `in` may still be uploading (rsreg_cloud_upload_deferred): the job waits for it, not
+ * the caller.  Same lifetime rule as above. */
+int rsreg_cloud_edge_features_async(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out);
 
 /* ---- PCD files: the LZF coder of "DATA binary_compressed" bodies (host only, no ctx) ------ */
 /* pcl::io::loadPCDFile / savePCDFileBinaryCompressed as reached from main.cpp:53,81,87: the body

@@ -591,6 +591,12 @@ inline void extract_edge_features(const DeviceCloud<PointXYZRGB> &cloud, DeviceC
 {
     check(rsreg_cloud_edge_features(cloud.context()->get(), cloud.handle(), out.handle()), cloud.context()->get());
 }
+// ... queued by a thread of the context on a stream of its own (rsreg_cloud_edge_features_async): returns at once, `out` is
+// complete when a call that takes it has waited for it.  `cloud` must stay as it is until then.
+inline void extract_edge_features_async(const DeviceCloud<PointXYZRGB> &cloud, DeviceCloud<PointXYZRGB> &out)
+{
+    check(rsreg_cloud_edge_features_async(cloud.context()->get(), cloud.handle(), out.handle()), cloud.context()->get());
+}
 
 // ---- pcl::io: PCD files with FIELDS x y z rgb (ascii, binary, binary_compressed), as the reference reads/writes
 // (src/main.cpp:53,81,87)

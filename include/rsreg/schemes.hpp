@@ -322,7 +322,17 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
         const rgb_point_cloud &frame0 = pairs ? *(*pairs)[0].second : *(*frames)[0];
-        rgb_device_cloud target, merged(frame0), features, reduced, coarse_out, refined, fulls[2], moved;
+        rgb_device_cloud target, merged, features_of[2], reduced_of[2], coarse_out, refined, fulls[3], moved;
+        // frames only: frame k + 2 is on the PCIe link and the features of frame k + 1 are extracted and voxel-filtered
+        // (a thread, a stream and scratch of the context's own) while frame k goes through its two alignments here: the
+        // reference extracts all features before it registers anything (types.hpp:30-43), none depends on a registration
+        auto prepare = [&](size_t k) {
+            extract_edge_features_async(fulls[k % 3], features_of[k & 1]);
+            voxel.filter_async(features_of[k & 1], reduced_of[k & 1]);
+        };
+        if (!pairs)
+            for (size_t k = 1; k < std::min<size_t>(3, n_frames); ++k) fulls[k % 3].upload_deferred(*(*frames)[k]);   // (the worker starts on these ...)
+        merged.upload(frame0);                                                                                      // (... while frame 0 goes up from here)
         // (`merged` on the GPU: frame 0 for its features, and the whole merged cloud only when it is downloaded at the end)
         std::unique_ptr<detail::StreamedResult> result;
         if (stream_result) {
@@ -330,22 +340,23 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             for (size_t k = 0; k < n_frames; ++k) capacity += pairs ? (*pairs)[k].second->size() : (*frames)[k]->size();
             result.reset(new detail::StreamedResult(merged.context(), frame0, capacity));
         }
+        if (!pairs && n_frames > 1) prepare(1);
         if (pairs) target.upload(*(*pairs)[0].first);
         else extract_edge_features(merged, target);
-        if (!pairs && n_frames > 1) fulls[1].upload_deferred(*(*frames)[1]);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
         if (byproducts_on()) save_edge(0, target);   // (the reference writes all edge-k.pcd before the loop; the files are the same)
         float acc_rads = 0.f;
         frame_transforms.clear();
         for (size_t k = 1; k < n_frames; ++k) {
-            rgb_device_cloud &full = fulls[k & 1];
-            if (pairs) features.upload(*(*pairs)[k].first);
-            else {
-                if (k + 1 < n_frames) fulls[(k + 1) & 1].upload_deferred(*(*frames)[k + 1]);   // on the link while frame k is aligned
-                extract_edge_features(full, features);
+            rgb_device_cloud &full = fulls[k % 3], &features = features_of[k & 1], &reduced = reduced_of[k & 1];
+            if (pairs) {
+                features.upload(*(*pairs)[k].first);
+                voxel.filter(features, reduced);
+            } else {
+                if (k + 2 < n_frames) fulls[(k + 2) % 3].upload_deferred(*(*frames)[k + 2]);
+                if (k + 1 < n_frames) prepare(k + 1);
             }
             if (byproducts_on()) save_edge(k, features);
-            voxel.filter(features, reduced);
             const Matrix4f guess = next_guess(k, acc_rads);
             say_iteration(coarse_name(), k);
             const Matrix4f t_coarse = coarse_align_device(reduced, target, coarse_out, guess);

@@ -52,6 +52,7 @@ constexpr size_t kScanSourceLimit = 64;       // (= kScanMaxSource of icp_kernel
 constexpr size_t kScanTargetFloor = 32768;    // ... target points at least, for the search without an index
 
 namespace rsreg {
+int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint32_t width, uint32_t height, uint32_t *n_out, int side_set);   // edges.hip
 int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t stride, const float leaf[3], uint32_t *n_out, int side_set);   // voxel.hip
 }
 
@@ -450,58 +451,141 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
 // adding 10^5 floats one after the other -- still running; whoever touches `out` next waits for them (settle).  The
 // frame loops filter frame k + 1 this way before they align frame k.  `in` must stay alive and unchanged until `out`
 // has been used; in != out.
-int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out)
+namespace {
+
+// The next scratch set of the side worker, its stream behind what the main stream holds so far (`in` may have been
+// produced there, and the buffer `out` is about to get may come from the pool with work of its previous owner queued).
+// The sets take turns: a job queues behind the one that used its set last (same stream) and runs beside the others.
+int side_begin(rsreg_ctx *ctx, int *set_out)
 {
-    int rc = check_pair(ctx, in, out);
-    if (rc || !leaf || in == out) return rc ? rc : RSREG_ERR_INVALID_ARG;
-    RSREG_HIP(ctx, resolve(in));
-    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
-    if (in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
-    RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    RSREG_HIP(ctx, settle(in));
-    RSREG_HIP(ctx, settle(out));
-    // the scratch sets take turns: a filter queues behind the one that used its set last (same stream) and runs beside
-    // the filters of the other sets
     const int set = ctx->side_next;
     ctx->side_next = (ctx->side_next + 1) % rsreg_ctx::kSideSets;
     rsreg_ctx::SideSet &ss = ctx->side_sets[set];
     if (!ss.stream) RSREG_HIP(ctx, hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
     if (!ctx->ev_side_gate) RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
     if (!ctx->side_worker) ctx->side_worker = new rsreg::TicketWorker();
-    // what the main stream holds so far comes first: `in` may have been produced there, and the buffer `out` is about
-    // to get may come from the pool with work of its previous owner still queued
     RSREG_HIP(ctx, hipEventRecord(ctx->ev_side_gate, ctx->stream));
     RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_side_gate, 0));
     if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_src_done, 0)); }
-    const size_t stride = in->stride, n_in = in->n;
+    *set_out = set;
+    return RSREG_OK;
+}
+
+// what a side job needs to know about an input that may still be on its way: an upload in flight (the job waits for the
+// upload worker to have queued the copy, then makes its stream wait for it) -- captured on the caller's thread
+struct InFlight {
+    bool filling;
+    uint64_t ticket;
+    hipEvent_t ev;
+};
+InFlight in_flight_of(const rsreg_cloud *c) { return InFlight{c->filling, c->up_ticket, c->ev_filled}; }
+int side_wait_input(rsreg_ctx *ctx, const InFlight &f, hipStream_t st)
+{
+    if (!f.filling || !f.ev) return RSREG_OK;
+    if (ctx->up_worker) (void)ctx->up_worker->wait(f.ticket);
+    return hipStreamWaitEvent(st, f.ev, 0) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
+}
+
+}  // namespace
+
+// rsreg_cloud_filter queued by the context's side worker on a scratch set and a stream of its own: the call returns at
+// once; the number of output records is known when the job has run (every call that takes `out` waits for that first),
+// the runs' sums -- for PCL's default 1 m leaf one wave adding 10^5 floats one after the other -- may then still be
+// running (settle).  The frame loops filter the next frames this way while they align this one.  `in` must stay alive and
+// unchanged until `out` has been used; in != out.  `in` may itself be the output of a side job that has not run yet
+// (rsreg_cloud_edge_features_async, then this): the jobs run in the order they were posted.
+int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3], rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc || !leaf || in == out) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    const bool chained = in->filter_pending;   // its size is not known yet: the job reads it
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || in->stride < 20) return RSREG_ERR_INVALID_ARG;
+    if (!chained && in->n > 0x7ffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "cloud too large");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!chained) RSREG_HIP(ctx, settle(in));
+    RSREG_HIP(ctx, settle(out));
+    int set = 0;
+    rc = side_begin(ctx, &set);
+    if (rc) return rc;
+    const size_t stride = in->stride;
     // the filter's twenty launches and its round trip for the number of output records are a third of a frame's host time
-    // in IncrementalICP's loop: they run on the side worker's thread.  The output cannot be larger than the input: room
-    // for that is made here (the buffer pool is the caller's thread's), its size is known when the job has run (resolve).
-    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, n_in * stride + 16));
+    // in the frame loops: they run on the side worker's thread.  The output cannot be larger than the input: room for that
+    // is made here (the buffer pool is the caller's thread's).
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, (chained ? in->buf.cap : in->n * stride) + 16));
     if (!out->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&out->ev_filled, hipEventDisableTiming));
-    const char *src = in->buf.as<char>();
     const float l0 = leaf[0], l1 = leaf[1], l2 = leaf[2];
     out->version++;
     out->n = 0; out->stride = stride; out->width = 0; out->height = 1; out->is_dense = 0;
     out->filter_rc = 0;
-    out->filter_ticket = ctx->side_worker->post([ctx, out, src, n_in, stride, l0, l1, l2, set]() -> int {
+    out->filter_ticket = ctx->side_worker->post([ctx, in, out, chained, stride, l0, l1, l2, set]() -> int {
         rsreg_ctx::SideSet &ws = ctx->side_sets[set];
         const float lf[3] = {l0, l1, l2};
         uint32_t nr = 0;
         int r = hipSetDevice(ctx->device) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
-        if (!r) r = voxel_filter_device(ctx, src, (uint32_t)n_in, stride, lf, &nr, set);
+        if (!r && chained) {   // the job that makes `in` has run (same thread, posted earlier); its records may still be on their way
+            r = in->filter_rc;
+            if (!r && in->n && hipStreamWaitEvent(ws.stream, in->ev_filled, 0) != hipSuccess) r = RSREG_ERR_HIP;
+        }
+        if (!r) r = voxel_filter_device(ctx, in->buf.as<char>(), (uint32_t)in->n, stride, lf, &nr, set);
         if (!r && nr) {
             if (hipMemcpyAsync(out->buf.ptr, ws.out.ptr, (size_t)nr * stride, hipMemcpyDeviceToDevice, ws.stream) != hipSuccess ||
                 hipEventRecord(out->ev_filled, ws.stream) != hipSuccess)
                 r = fail(ctx, RSREG_ERR_HIP, "queueing the filtered records");
         }
         out->filter_rc = r;
-        out->n = nr;
-        out->width = nr;
+        out->n = r ? 0 : nr;
+        out->width = r ? 0 : nr;
         return 0;
     });
     out->filter_pending = true;
     out->filling = true;   // (settle: the event behind the copy; never recorded when the output is empty)
+    return RSREG_OK;
+}
+
+// rsreg_cloud_edge_features queued by the side worker the same way: the edge schemes extract and filter the features of
+// frame k + 1 (eleven launches and a round trip, then the filter's) beside the two alignments of frame k -- the
+// reference extracts the features of ALL frames before it registers any (types.hpp:30-43), so nothing of frame k + 1's
+// depends on frame k.  `in` (an organized cloud) may still be uploading: the job waits for it, not the caller.
+int rsreg_cloud_edge_features_async(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud *out)
+{
+    int rc = check_pair(ctx, in, out);
+    if (rc || in == out) return rc ? rc : RSREG_ERR_INVALID_ARG;
+    RSREG_HIP(ctx, resolve(in));
+    if ((size_t)in->width * in->height != in->n || in->stride < 20) return fail(ctx, RSREG_ERR_INVALID_ARG, "edge extraction needs an organized XYZRGB cloud");
+    if (in->n > 0x3fffffffull) return fail(ctx, RSREG_ERR_INVALID_ARG, "image too large");
+    RSREG_HIP(ctx, hipSetDevice(ctx->device));
+    RSREG_HIP(ctx, settle(out));
+    if (in->downloading) RSREG_HIP(ctx, settle(in));   // (rare: only its own download pending needs the caller's stream)
+    int set = 0;
+    rc = side_begin(ctx, &set);
+    if (rc) return rc;
+    const size_t stride = in->stride, n_in = in->n;
+    const uint32_t w = in->width, h = in->height;
+    RSREG_HIP(ctx, cloud_reserve(ctx, out->buf, n_in * stride + 16));
+    if (!out->ev_filled) RSREG_HIP(ctx, hipEventCreateWithFlags(&out->ev_filled, hipEventDisableTiming));
+    const InFlight inf = in_flight_of(in);
+    const char *src = in->buf.as<char>();
+    out->version++;
+    out->n = 0; out->stride = stride; out->width = 0; out->height = 1; out->is_dense = in->is_dense;
+    out->filter_rc = 0;
+    out->filter_ticket = ctx->side_worker->post([ctx, out, src, stride, w, h, inf, set]() -> int {
+        rsreg_ctx::SideSet &ws = ctx->side_sets[set];
+        uint32_t ne = 0;
+        int r = hipSetDevice(ctx->device) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
+        if (!r) r = side_wait_input(ctx, inf, ws.stream);
+        if (!r) r = rsreg::edge_features_device(ctx, src, stride, w, h, &ne, set);
+        if (!r && ne) {
+            if (hipMemcpyAsync(out->buf.ptr, ws.out.ptr, (size_t)ne * stride, hipMemcpyDeviceToDevice, ws.stream) != hipSuccess ||
+                hipEventRecord(out->ev_filled, ws.stream) != hipSuccess)
+                r = fail(ctx, RSREG_ERR_HIP, "queueing the edge points");
+        }
+        out->filter_rc = r;
+        out->n = r ? 0 : ne;
+        out->width = r ? 0 : ne;
+        return 0;
+    });
+    out->filter_pending = true;
+    out->filling = true;
     return RSREG_OK;
 }
 

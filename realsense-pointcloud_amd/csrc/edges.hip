@@ -189,28 +189,40 @@ __global__ __launch_bounds__(kBlock) void k_edge_gather(const char *rec, size_t 
     if (indices) indices[pos[p]] = p;
 }
 
-// records in HBM -> edge points in ctx->d_vox_out (+ their indices in ctx->d_vals_alt); one host sync
-int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint32_t width, uint32_t height, uint32_t *n_out)
+}  // namespace
+
+namespace rsreg {
+
+// records in HBM -> edge points in the scratch set's `out` (+ their indices in its vals_alt); one host sync.
+// side_set >= 0: that scratch set of the context and its stream (rsreg_cloud_edge_features_async: the features of the next
+// frame beside the alignment of this one, queued by the side worker's thread); -1: the main set, the main stream.
+int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint32_t width, uint32_t height, uint32_t *n_out, int side_set)
 {
     *n_out = 0;
     const size_t n = (size_t)width * height;
     if (n == 0) return RSREG_OK;
     if (n > 0x3fffffffull) return fail(ctx, RSREG_ERR_INVALID_ARG, "image too large");
-    hipStream_t st = ctx->stream;
+    const bool side = side_set >= 0;
+    rsreg_ctx::SideSet &ss = ctx->side_sets[side ? side_set : 0];
+    hipStream_t st = side ? ss.stream : ctx->stream;
+    DevBuf &b_keys = side ? ss.keys : ctx->d_keys, &b_keys_alt = side ? ss.keys_alt : ctx->d_keys_alt, &b_vals = side ? ss.vals : ctx->d_vals,
+           &b_flags = side ? ss.flags : ctx->d_flags, &b_scan = side ? ss.scan : ctx->d_scan, &b_vals_alt = side ? ss.vals_alt : ctx->d_vals_alt,
+           &b_dir = side ? ss.cent : ctx->d_brick, &b_out = side ? ss.out : ctx->d_vox_out, &b_tmp = side ? ss.tmp : ctx->d_tmp;
+    PinnedBuf &b_host = side ? ss.host : ctx->h_sums;
     const int w = (int)width, h = (int)height, N = (int)n;
-    RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));       // smoothed | magnitude
-    RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));   // maxima | labels
-    RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));       // strong flags per root
-    RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4 + 16));
-    RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4 + 16));
-    RSREG_HIP(ctx, ctx->d_vals_alt.reserve(n * 4));   // indices of the edge points
-    RSREG_HIP(ctx, ctx->d_brick.reserve(n + 16));     // direction classes
-    RSREG_HIP(ctx, ctx->d_vox_out.reserve(n * stride));
-    RSREG_HIP(ctx, ctx->h_sums.reserve(2048));
-    float *sm = ctx->d_keys.as<float>(), *mag = sm + n, *mx = ctx->d_keys_alt.as<float>();
+    RSREG_HIP(ctx, b_keys.reserve(n * 8));       // smoothed | magnitude
+    RSREG_HIP(ctx, b_keys_alt.reserve(n * 8));   // maxima | labels
+    RSREG_HIP(ctx, b_vals.reserve(n * 4));       // strong flags per root
+    RSREG_HIP(ctx, b_flags.reserve(n * 4 + 16));
+    RSREG_HIP(ctx, b_scan.reserve(n * 4 + 16));
+    RSREG_HIP(ctx, b_vals_alt.reserve(n * 4));   // indices of the edge points
+    RSREG_HIP(ctx, b_dir.reserve(n + 16));       // direction classes
+    RSREG_HIP(ctx, b_out.reserve(n * stride));
+    RSREG_HIP(ctx, b_host.reserve(2048));
+    float *sm = b_keys.as<float>(), *mag = sm + n, *mx = b_keys_alt.as<float>();
     int *label = reinterpret_cast<int *>(mx + n);
-    uint32_t *strong = ctx->d_vals.as<uint32_t>(), *flag = ctx->d_flags.as<uint32_t>(), *pos = ctx->d_scan.as<uint32_t>();
-    uint8_t *dir = ctx->d_brick.as<uint8_t>();
+    uint32_t *strong = b_vals.as<uint32_t>(), *flag = b_flags.as<uint32_t>(), *pos = b_scan.as<uint32_t>();
+    uint8_t *dir = b_dir.as<uint8_t>();
     // pcl::kernel::gaussianKernel(size 3, sigma 1): exp of -(i^2 + j^2) / (2 sigma^2) as a float, normalised by the float
     // sum.  (PCL calls expf at run time -- libm-dependent in the last ulp; here the correctly rounded float: exp in
     // double, rounded once, the same on every platform and in the checker.)
@@ -240,9 +252,9 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     RSREG_HIP(ctx, hipGetLastError());
     size_t scan_bytes = 0;
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(scan_bytes + 256));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-    k_edge_gather<<<nb, kBlock, 0, st>>>(d_rec, stride, N, flag, pos, ctx->d_vox_out.as<char>(), ctx->d_vals_alt.as<int32_t>());
+    RSREG_HIP(ctx, b_tmp.reserve(scan_bytes + 256));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+    k_edge_gather<<<nb, kBlock, 0, st>>>(d_rec, stride, N, flag, pos, b_out.as<char>(), b_vals_alt.as<int32_t>());
     RSREG_HIP(ctx, hipGetLastError());
     if (const char *dump = std::getenv("RSREG_EDGE_DUMP")) {   // dev: the stage images, for a stage-by-stage comparison
         std::vector<float> hbuf(n * 3);
@@ -258,7 +270,7 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
             std::fclose(f);
         }
     }
-    uint32_t *hb = ctx->h_sums.as<uint32_t>() + 200;
+    uint32_t *hb = b_host.as<uint32_t>() + 200;
     RSREG_HIP(ctx, hipMemcpyAsync(hb, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipMemcpyAsync(hb + 1, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
@@ -266,7 +278,7 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     return RSREG_OK;
 }
 
-}  // namespace
+}  // namespace rsreg
 
 extern "C" {
 
@@ -288,7 +300,7 @@ int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t wid
     }
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, ctx->stream));
     uint32_t ne = 0;
-    int rc = edge_features_device(ctx, ctx->d_vox_in.as<char>(), stride, width, height, &ne);
+    int rc = rsreg::edge_features_device(ctx, ctx->d_vox_in.as<char>(), stride, width, height, &ne, -1);
     if (rc || ne == 0) return rc;
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_vox_out.ptr, (size_t)ne * stride, hipMemcpyDeviceToHost, ctx->stream));
     if (indices_out) RSREG_HIP(ctx, hipMemcpyAsync(indices_out, ctx->d_vals_alt.ptr, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -313,7 +325,7 @@ int rsreg_cloud_edge_features(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg_cloud
     if ((size_t)w * h != n || stride < 20) return fail(ctx, RSREG_ERR_INVALID_ARG, "edge extraction needs an organized XYZRGB cloud");
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t ne = 0;
-    rc = edge_features_device(ctx, static_cast<const char *>(rsreg_cloud_device_ptr(in)), stride, w, h, &ne);
+    rc = rsreg::edge_features_device(ctx, static_cast<const char *>(rsreg_cloud_device_ptr(in)), stride, w, h, &ne, -1);
     if (rc) return rc;
     return rsreg_cloud_adopt_(out, &ctx->d_vox_out, ne, stride, ne, 1, dense);
 }

@@ -32,7 +32,7 @@ EXPORTS = [
     "rsreg_cloud_device_ptr", "rsreg_cloud_version", "rsreg_cloud_copy", "rsreg_cloud_filter", "rsreg_cloud_filter_async", "rsreg_cloud_transform", "rsreg_cloud_concat",
     "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
-    "rsreg_extract_edge_features", "rsreg_cloud_edge_features",
+    "rsreg_extract_edge_features", "rsreg_cloud_edge_features", "rsreg_cloud_edge_features_async",
     "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
 ]
 
@@ -201,6 +201,7 @@ def lib():
     L.rsreg_ndt_align_device.argtypes = [vp, vp, sz, sz, i32, vp, C.POINTER(NdtParams), C.POINTER(NdtResult), vp]
     L.rsreg_extract_edge_features.argtypes = [vp, vp, u32, u32, sz, vp, vp, C.POINTER(sz)]
     L.rsreg_cloud_edge_features.argtypes = [vp, vp, vp]
+    L.rsreg_cloud_edge_features_async.argtypes = [vp, vp, vp]
     L.rsreg_lzf_max_encoded_size.argtypes = [sz]
     L.rsreg_lzf_max_encoded_size.restype = sz
     for f in ("rsreg_lzf_encode", "rsreg_lzf_decode"):

@@ -540,9 +540,9 @@ class ApproximateVoxelGrid:
         self._in = cloud
 
     def filter_async(self):
-        """filter() of a device cloud on the context's side stream: returns once the size of the result is known, the
-        voxel sums still running; whatever touches the result next waits for them (rsreg_cloud_filter_async).  The
-        input must stay alive and unchanged until the result has been used."""
+        """filter() of a device cloud queued by a thread of the context on a stream of its own: returns at once; whatever
+        takes the result next waits for its size and its records (rsreg_cloud_filter_async).  The input -- which may be
+        the not-yet-complete result of extract_edge_features_async -- must stay alive and unchanged until then."""
         out = DeviceCloud(ctx=self._in.ctx)
         _l.check(_l.lib().rsreg_cloud_filter_async(self._in.ctx.h, self._in.h, self.leaf.ctypes.data, out.h), self._in.ctx.h)
         out._filtered_from = self._in   # (keeps the input alive)
@@ -580,6 +580,16 @@ def transformPointCloud(cloud, T, ctx=None):
     _l.check(_l.lib().rsreg_transform_cloud(ctx.h, pts.ctypes.data, out.ctypes.data, len(pts), pts.dtype.itemsize,
                                             int(cloud.is_dense), t.ctypes.data), ctx.h)
     return PointCloud(out, width=cloud.width, height=cloud.height, is_dense=cloud.is_dense)
+
+
+def extract_edge_features_async(cloud):
+    """extract_edge_features of a DeviceCloud queued by a thread of the context on a stream of its own
+    (rsreg_cloud_edge_features_async): returns at once; the result is complete when a call that takes it has waited for
+    it (every one does).  `cloud` -- which may still be uploading -- must stay as it is until then."""
+    out = DeviceCloud(ctx=cloud.ctx)
+    _l.check(_l.lib().rsreg_cloud_edge_features_async(cloud.ctx.h, cloud.h, out.h), cloud.ctx.h)
+    out._features_of = cloud   # (keeps the input alive)
+    return out
 
 
 def extract_edge_features(cloud, ctx=None, want_indices=False):

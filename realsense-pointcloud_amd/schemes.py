@@ -112,6 +112,10 @@ class HipDeviceBackend(HipBackend):
     def download(self, cloud):
         return cloud.download()
 
+    def edge_features_async(self, cloud):
+        """edge_features() of a DeviceCloud queued beside whatever the caller does next (None: not on this cloud)"""
+        return self.api.extract_edge_features_async(cloud) if isinstance(cloud, self.api.DeviceCloud) else None
+
     def result_stream(self, frames):
         """the merged cloud of `frames` (host clouds; frame 0 first) as a _StreamedResult, or None"""
         if len(frames) < 2:
@@ -226,6 +230,34 @@ class _FramePairs:
         self.scheme, self.clouds = scheme, clouds
         self.frames = {}
         self.pairs = {}
+        self.reduced = {}
+
+    def _prepare(self, k, voxel):
+        """features of frame k extracted and voxel-filtered by the backend's side worker (nothing of them depends on the
+        registration of the frames before: types.hpp:30-43 extracts all features first); False: not with this backend"""
+        if k in self.reduced or k in self.pairs:
+            return k in self.reduced
+        make = getattr(self.scheme.backend, "edge_features_async", None)
+        f = self._frame(k)
+        feats = make(f) if make and not self.scheme.feature_fn and hasattr(voxel, "filter_async") else None
+        if feats is None:
+            return False
+        voxel.setInputCloud(feats)
+        self.pairs[k] = (feats, f)
+        self.reduced[k] = voxel.filter_async()
+        return True
+
+    def prepared(self, k, voxel):
+        """the voxel-filtered features of frame k, with those of frame k + 1 queued and frame k + 2 on the PCIe link
+        (None: this backend prepares nothing ahead)"""
+        if not self._prepare(k, voxel):
+            return None
+        for j in (k + 1, k + 2):
+            if j < len(self.clouds):
+                self._frame(j)
+        if k + 1 < len(self.clouds):
+            self._prepare(k + 1, voxel)
+        return self.reduced.pop(k)
 
     def __len__(self):
         return len(self.clouds)
@@ -354,10 +386,12 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         acc = np.float32(0.0)
         self.frame_transforms = []
         for k in range(1, len(pairs)):
+            reduced = pairs.prepared(k, voxel) if isinstance(pairs, _FramePairs) else None
+            if reduced is None:
+                voxel.setInputCloud(b.upload(pairs[k][0]))
+                reduced = voxel.filter()
             if by:
                 self._save("edge-%d.pcd" % k, pairs[k][0])
-            voxel.setInputCloud(b.upload(pairs[k][0]))
-            reduced = voxel.filter()
             if self.use_imu:
                 t0 = self.thetas[0]
                 self.thetas[k] = [np.float32(self.thetas[k][i]) + np.float32(-1.0) * np.float32(t0[i]) for i in range(3)]

@@ -584,3 +584,61 @@ def test_upload_deferred_is_waited_for_like_upload_async(api, rs, frames):
     from rsreg_amd import lib
     assert lib.lib().rsreg_cloud_upload_deferred(None, None, 0, 32, 0, 0, 1) == lib.RSREG_ERR_INVALID_ARG
     assert lib.lib().rsreg_cloud_upload_deferred(held[0].h, None, 5, 32, 5, 1, 1) == lib.RSREG_ERR_INVALID_ARG
+
+
+def test_edge_features_and_filter_queued_on_the_side_worker(api, rs):
+    """rsreg_cloud_edge_features_async and rsreg_cloud_filter_async return before their jobs have run; the results have
+    the records of the synchronous calls once anything asks for them: a frame still uploading as the input, the filter
+    chained on the not-yet-run extraction, several frames in flight over the three scratch sets, results dropped unread,
+    a frame without a single edge, the size asked for first (info), and the bad calls refused."""
+    ctx = api.Context(0)
+    frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(5)]
+    leaf = np.array([0.01, 0.01, 0.01], np.float32)
+
+    def sync_chain(f):
+        e = api.extract_edge_features(api.DeviceCloud(f, ctx))
+        v = api.ApproximateVoxelGrid(ctx)
+        v.setLeafSize(*leaf)
+        v.setInputCloud(e)
+        return e.download(), v.filter().download()
+
+    want = [sync_chain(f) for f in frames]
+    queued = []
+    for f in frames:                               # five frames, three scratch sets: the jobs take turns
+        d = api.DeviceCloud(ctx=ctx).upload_deferred(f)
+        e = api.extract_edge_features_async(d)
+        v = api.ApproximateVoxelGrid(ctx)
+        v.setLeafSize(*leaf)
+        v.setInputCloud(e)
+        queued.append((e, v.filter_async()))
+    for (e, r), (we, wr) in zip(reversed(queued), reversed(want)):     # asked for in another order than posted
+        assert r.info()[0] == len(wr)
+        _same_records(r.download(), wr)
+        _same_records(e.download(), we)
+    # dropped unread, with the jobs possibly still queued
+    d = api.DeviceCloud(ctx=ctx).upload_deferred(frames[0])
+    e = api.extract_edge_features_async(d)
+    v = api.ApproximateVoxelGrid(ctx)
+    v.setLeafSize(*leaf)
+    v.setInputCloud(e)
+    r = v.filter_async()
+    del r, e, d
+    # no edge anywhere: both results empty
+    flat = frames[0].copy()
+    flat.points["rgba"] = 0x00808080
+    e = api.extract_edge_features_async(api.DeviceCloud(flat, ctx))
+    v.setInputCloud(e)
+    r = v.filter_async()
+    assert len(r) == 0 and len(e) == 0 and len(r.download()) == 0
+    # a result feeds the synchronous calls like any other cloud
+    e = api.extract_edge_features_async(api.DeviceCloud(frames[1], ctx))
+    v.setInputCloud(e)
+    _same_records(v.filter().download(), want[1][1])
+    from rsreg_amd import lib
+    L = lib.lib()
+    unorganized = api.DeviceCloud(frames[0] + frames[1], ctx)      # (one row of 2 n points: still an image, like the synchronous call takes it)
+    out = api.DeviceCloud(ctx=ctx)
+    assert L.rsreg_cloud_edge_features_async(ctx.h, out.h, out.h) == lib.RSREG_ERR_INVALID_ARG
+    assert L.rsreg_cloud_edge_features_async(ctx.h, None, out.h) == lib.RSREG_ERR_INVALID_ARG
+    other = api.Context(0)
+    assert L.rsreg_cloud_edge_features_async(other.h, unorganized.h, out.h) == lib.RSREG_ERR_INVALID_ARG

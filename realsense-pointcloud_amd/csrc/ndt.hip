@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "ndt_kernels.hpp"
+#include "sort_cfg.hpp"
 
 using namespace rsreg;
 
@@ -492,20 +493,38 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     RSREG_HIP(ctx, ctx->d_flags.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_scan.reserve(n * 4));
     RSREG_HIP(ctx, ctx->d_ndt_seg.reserve(((size_t)nfin + 2) * 4));
-    auto *keys = ctx->d_keys.as<unsigned long long>();
-    auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
     uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_ndt_seg.as<uint32_t>();
-    k_ndt_keys<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, keys, vals);
-    RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
-    k_ndt_flag_starts<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
-    RSREG_HIP(ctx, hipGetLastError());
+    // the leaf keys are < div0 * div1 * div2 (a few dozen leaves at the reference's 1 m resolution) and the key of a
+    // non-finite point is that product itself: the sort looks at those bits only -- one or two radix passes where all
+    // 64 bits of the key type were ten merge passes (23 launches) for a grown edge target of 5 x 10^5 points
+    const unsigned long long n_leaves = (unsigned long long)div_b[0] * (unsigned long long)div_b[1] * (unsigned long long)div_b[2];
+    unsigned key_bits = 1;
+    while (key_bits < 64 && (n_leaves >> key_bits)) ++key_bits;
+    if (n_leaves < 0x7fffffffull) {
+        auto *keys = ctx->d_keys.as<uint32_t>();
+        auto *keys2 = ctx->d_keys_alt.as<uint32_t>();
+        k_ndt_keys<uint32_t><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, (uint32_t)n_leaves, keys, vals);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        k_ndt_flag_starts<uint32_t><<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
+        RSREG_HIP(ctx, hipGetLastError());
+    } else {
+        auto *keys = ctx->d_keys.as<unsigned long long>();
+        auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
+        k_ndt_keys<unsigned long long><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, n_leaves, keys, vals);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        k_ndt_flag_starts<unsigned long long><<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
     RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
     k_ndt_seg_offsets<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(start, sid, nfin, seg_begin, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
@@ -514,11 +533,12 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     const uint32_t nseg = h_misc[8];
 
     // ---- per-voxel moments on the device, one block per occupied leaf
-    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * 10 * 8, 64 * 8)));
-    k_ndt_voxel_stats<<<nseg, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_ndt_out.as<double>());
+    const uint32_t n_parts = nseg <= 2048 ? 16u : 1u;   // (the reference's 1 m voxels: two dozen of 10^4 points each)
+    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * n_parts * 10 * 8, 64 * 8)));
+    k_ndt_voxel_stats<<<nseg * n_parts, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, n_parts, ctx->d_ndt_out.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
-    std::vector<double> stats((size_t)nseg * 10);
-    RSREG_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->d_ndt_out.ptr, stats.size() * 8, hipMemcpyDeviceToHost, st));
+    std::vector<double> parts((size_t)nseg * n_parts * 10);
+    RSREG_HIP(ctx, hipMemcpyAsync(parts.data(), ctx->d_ndt_out.ptr, parts.size() * 8, hipMemcpyDeviceToHost, st));
     std::vector<float> csum;   // PCL-mode centroids (rsreg_ndt_set_centroid_mode)
     if (ctx->ndt_centroid_mode == 1) {
         csum.resize((size_t)nseg * 3);
@@ -530,6 +550,10 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     RSREG_HIP(ctx, hipStreamSynchronize(st));
 
     // ---- host: mean, single-pass covariance, eigenvalue floor, inverse (App. A.6)
+    std::vector<double> stats((size_t)nseg * 10, 0.0);
+    for (uint32_t v = 0; v < nseg; ++v)
+        for (uint32_t part = 0; part < n_parts; ++part)   // (the parts of a voxel, in order)
+            for (int k = 0; k < 10; ++k) stats[(size_t)v * 10 + k] += parts[((size_t)v * n_parts + part) * 10 + k];
     std::vector<NdtVoxel> table;
     for (uint32_t v = 0; v < nseg; ++v) {
         const double *s = &stats[(size_t)v * 10];

@@ -113,7 +113,9 @@ class StreamedResult {
         bool dense = false;
         moved.info(n, w, h, dense);
         if (n_ + n > pts_.size()) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: streamed result overflows its capacity");
+        const auto t0 = std::chrono::steady_clock::now();
         moved.download_async(pts_.data() + n_, n);
+        append_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         pending_ = true;
         n_ += n;
         dense_ = dense_ && dense;
@@ -125,8 +127,9 @@ class StreamedResult {
         const auto t1 = std::chrono::steady_clock::now();
         ctx_->wait_downloads();
         if (std::getenv("RSREG_STREAM_VERBOSE"))
-            std::fprintf(stderr, "finish: join %.3f ms, wait %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+            std::fprintf(stderr, "finish: join %.3f ms, wait %.3f ms; download_async calls took %.3f ms in all\n",
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), append_us_ / 1e3);
         pending_ = false;
         pts_.resize(n_);
         out.points = std::move(pts_);
@@ -140,6 +143,7 @@ class StreamedResult {
     PointVector<rgb_point> pts_;
     size_t n_;
     bool dense_, pending_ = false;
+    double append_us_ = 0;   // (host time inside download_async: RSREG_STREAM_VERBOSE)
     std::thread copy0_;
 };
 
@@ -173,7 +177,7 @@ class IncrementalICP : public RegistrationScheme {
         // alignments of the frames before
         const size_t n = clouds.size();
         constexpr size_t kFilters = 3, kUploads = 4, kRing = kUploads + 1;
-        rgb_device_cloud model, reduced_of[kFilters + 1], aligned, frames[kRing], moved;
+        rgb_device_cloud model, frames[kRing], reduced_of[kFilters + 1], aligned, moved;   // (inputs of queued jobs outlive their outputs)
         for (size_t k = 1; k < std::min<size_t>(kUploads + 1, n); ++k) frames[k % kRing].upload_deferred(*clouds[k]);   // (the worker starts on these ...)
         model.upload(*clouds[0]);                                                                                        // (... while frame 0 goes up from here)
         std::unique_ptr<detail::StreamedResult> result;
@@ -322,7 +326,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
         const rgb_point_cloud &frame0 = pairs ? *(*pairs)[0].second : *(*frames)[0];
-        rgb_device_cloud target, merged, features_of[2], reduced_of[2], coarse_out, refined, fulls[3], moved;
+        rgb_device_cloud target, merged, fulls[3], features_of[2], reduced_of[2], coarse_out, refined, moved;   // (inputs of queued jobs outlive their outputs)
         // frames only: frame k + 2 is on the PCIe link and the features of frame k + 1 are extracted and voxel-filtered
         // (a thread, a stream and scratch of the context's own) while frame k goes through its two alignments here: the
         // reference extracts all features before it registers anything (types.hpp:30-43), none depends on a registration

@@ -1120,13 +1120,132 @@ __global__ __launch_bounds__(1024) void k_sched_build(const uint32_t *cost, uint
     }
 }
 
+// The same schedule, XCD-aware (RSREG_SCHED_XCD, default on): workgroups are dealt to the eight XCDs in turn (b and
+// b + 8 share one, MI355X_MICROARCH.md "Workgroup dispatch"), and every XCD has a 4 MiB L2 of its own.  The tiles are in
+// the source's Morton order, so a run of consecutive tiles is a compact piece of space: pieces of `deal` (32) consecutive
+// tiles are dealt to eight runs in turn, each run is sorted longest first by itself, and the runs are dealt out to the
+// workgroups in turn: workgroup b works on run b % 8 while that run lasts, so one XCD's L2 sees an eighth of the target's
+// cells instead of all of them.  When a run is used up the others close ranks (no empty workgroups; those last tiles land
+// on whatever XCD is next).  Which workgroup takes which tile never changes what a tile computes.
+// Measured (profiles/r03_experiments/xcd_schedule_*): 300 k points 53.6 -> 48.7 us per launch (the eighth of the index
+// fits the L2), 10^6 points level (96.9 against 96.5-98.3); pieces of 64+ tiles or eight contiguous runs of equal cost
+// (deal = 0) are slower at 10^6 (102-103 us: the heavy tiles of a crowded region then share one XCD's 256 workgroup
+// slots); a few cost classes with the Morton order kept inside a class are slower the coarser the classes (97 -> 117 us).
+__global__ __launch_bounds__(1024) void k_sched_build_xcd(const uint32_t *cost, uint32_t n_tiles, uint32_t n4, uint32_t n2, uint32_t total_items,
+                                                          uint32_t deal, uint32_t *items, uint32_t *done)
+{
+    constexpr uint32_t kRuns = 8;
+    __shared__ uint32_t bins[kRuns * 1024];
+    __shared__ uint32_t part[16];
+    __shared__ uint32_t run_first[kRuns + 1];   // rank, in run-major sorted order, of the first tile of a run
+    __shared__ uint32_t total_cost;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t k = tid; k < kRuns * 1024u; k += 1024u) bins[k] = 0;
+    auto bucket_of = [&](uint32_t t) {   // 0 .. 1023, steps of 0.64 us, longer = larger
+        uint32_t c = 0;
+        for (int w = 0; w < kTileWaves; ++w) c = max(c, cost[t * kTileWaves + w]);
+        return min(c >> 6, 1023u);
+    };
+    auto block_exclusive = [&](uint32_t mine, uint32_t *total) -> uint32_t {   // over the 1024 threads, in thread order
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        __syncthreads();
+        if (lane == 63u) part[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            if (w < wave) before += part[w];
+            all += part[w];
+        }
+        if (total) *total = all;
+        return before + incl - mine;
+    };
+    // every thread owns a contiguous share of the tiles: their cost before them, in natural order
+    const uint32_t per = (n_tiles + 1023u) / 1024u, lo = min(n_tiles, tid * per), hi = min(n_tiles, lo + per);
+    uint32_t mine = 0;
+    for (uint32_t t = lo; t < hi; ++t) mine += bucket_of(t) + 1u;
+    uint32_t all = 0;
+    const uint32_t before = block_exclusive(mine, &all);
+    if (tid == 0) total_cost = all;
+    __syncthreads();
+    const uint32_t C = max(total_cost, 1u);
+    // deal == 0: eight contiguous runs of equal cost; deal > 0: pieces of `deal` consecutive tiles dealt to the runs in turn
+    auto run_of = [&](uint32_t t, uint32_t cost_before) {
+        return deal ? (t / deal) % kRuns : min(kRuns - 1u, (uint32_t)(((unsigned long long)cost_before * kRuns) / C));
+    };
+    {
+        uint32_t at = before;
+        for (uint32_t t = lo; t < hi; ++t) {
+            const uint32_t b = bucket_of(t);
+            atomicAdd(&bins[run_of(t, at) * 1024u + (1023u - b)], 1u);
+            at += b + 1u;
+            done[t] = 0u;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 8 x 1024 bins, run-major: eight consecutive bins per thread
+    {
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = bins[tid * 8u + k]; sum += v[k]; }
+        uint32_t at = block_exclusive(sum, nullptr);
+        if ((tid & 127u) == 0) run_first[tid >> 7] = at;   // (bin x * 1024 is thread 128 x's first)
+        if (tid == 0) run_first[kRuns] = n_tiles;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { bins[tid * 8u + k] = at; at += v[k]; }
+    }
+    __syncthreads();
+    // how long every run's list of workgroups is: its tiles, the first n4 / 8 of them four times, the next n2 / 8 twice
+    uint32_t len[kRuns], r4[kRuns], r2[kRuns], used = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < kRuns; ++x) {
+        const uint32_t cnt = run_first[x + 1] - run_first[x];
+        r4[x] = min(n4 / kRuns, cnt);
+        r2[x] = min(n2 / kRuns, cnt - r4[x]);
+        len[x] = cnt + 3u * r4[x] + r2[x];
+        used += len[x];
+    }
+    auto place = [&](uint32_t x, uint32_t p) {   // list position p of run x -> workgroup: the runs dealt out in turn while they last
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < kRuns; ++y) pos += min(len[y], p + (y < x ? 1u : 0u));
+        return pos;
+    };
+    {
+        uint32_t at = before;
+        for (uint32_t t = lo; t < hi; ++t) {
+            const uint32_t b = bucket_of(t), x = run_of(t, at);
+            at += b + 1u;
+            const uint32_t r = atomicAdd(&bins[x * 1024u + (1023u - b)], 1u) - run_first[x];   // rank inside its run, longest first
+            uint32_t lg, p;
+            if (r < r4[x]) { lg = 2; p = 4u * r; }
+            else if (r < r4[x] + r2[x]) { lg = 1; p = 4u * r4[x] + 2u * (r - r4[x]); }
+            else { lg = 0; p = 4u * r4[x] + 2u * r2[x] + (r - r4[x] - r2[x]); }
+            for (uint32_t q = 0; q < (1u << lg); ++q) items[place(x, p + q)] = t | q << 24 | lg << 28;
+        }
+    }
+    for (uint32_t k = used + tid; k < total_items; k += 1024u) items[k] = 0xffffffffu;   // (a run shorter than its share of the splits: nothing to do)
+}
+
 int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
 {
     const SchedCfg cfg = sched_cfg();
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
-    const uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
-    k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, sb.items, sb.done);
+    uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
+    static const bool xcd = !(std::getenv("RSREG_SCHED_XCD") && std::getenv("RSREG_SCHED_XCD")[0] == '0');
+    if (xcd) {
+        n4 -= n4 % 8u;   // (an eighth of the splits to every run)
+        n2 -= n2 % 8u;
+        static const uint32_t deal = std::getenv("RSREG_SCHED_XCD_DEAL") ? (uint32_t)std::atoi(std::getenv("RSREG_SCHED_XCD_DEAL")) : 32u;
+        k_sched_build_xcd<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, n_tiles + 3 * n4 + n2, deal, sb.items, sb.done);
+    } else {
+        k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, sb.items, sb.done);
+    }
     RSREG_HIP(ctx, hipGetLastError());
     ctx->icp.sched_items = n_tiles + 3 * n4 + n2;
     if (std::getenv("RSREG_SCHED_VERBOSE"))

@@ -967,6 +967,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
                                                            TileSched sched)
 {
     const uint32_t item = sched.items ? sched.items[blockIdx.x] : blockIdx.x;
+    if (item == 0xffffffffu) return;   // (a workgroup the schedule has nothing for)
     const uint32_t tile = item & 0xffffffu, lg = (item >> 28) & 3u;
     const uint32_t i = tile * kTile + threadIdx.x;
     if (dev) {   // device-resident loop: the increment comes from the previous k_icp_solve

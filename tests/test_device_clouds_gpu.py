@@ -642,3 +642,36 @@ def test_edge_features_and_filter_queued_on_the_side_worker(api, rs):
     assert L.rsreg_cloud_edge_features_async(ctx.h, None, out.h) == lib.RSREG_ERR_INVALID_ARG
     other = api.Context(0)
     assert L.rsreg_cloud_edge_features_async(other.h, unorganized.h, out.h) == lib.RSREG_ERR_INVALID_ARG
+
+
+def test_contexts_and_clouds_go_away_with_work_of_their_helper_threads_in_flight(api, rs):
+    """A context owns helper threads (uploads, downloads, side jobs, source loads).  Dropping clouds, and closing the
+    context, right after work has been handed to them must neither hang nor crash, whatever is still queued; a context
+    made afterwards works as usual."""
+    frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
+    for round_ in range(3):
+        ctx = api.Context(0)
+        out = np.zeros(sum(len(f) for f in frames), api.POINT_DTYPE)
+        clouds, at = [], 0
+        for f in frames:
+            d = api.DeviceCloud(ctx=ctx).upload_deferred(f)
+            e = api.extract_edge_features_async(d)
+            v = api.ApproximateVoxelGrid(ctx)
+            v.setLeafSize(0.01, 0.01, 0.01)
+            v.setInputCloud(e)
+            r = v.filter_async()
+            at += api.DeviceCloud(f, ctx).download_async(out, at)
+            clouds.append((d, e, r))
+        if round_ == 0:
+            del clouds                       # outputs first or inputs first: whatever the collector does
+        elif round_ == 1:
+            clouds.reverse()
+            while clouds:
+                clouds.pop()
+        ctx.wait_downloads() if round_ == 2 else None
+        ctx.close()                          # (round 2: with the clouds still alive; they are not touched again)
+        if round_ == 2:
+            for f, lo in zip(frames, np.cumsum([0] + [len(f) for f in frames[:-1]])):
+                np.testing.assert_array_equal(out["rgba"][lo:lo + len(f)], f.points["rgba"])
+    ctx = api.Context(0)
+    _same_records(api.DeviceCloud(frames[0], ctx).download(), frames[0])

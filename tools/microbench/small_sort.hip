@@ -1,5 +1,5 @@
-// small_sort.hip — csrc/small_sort.hpp against rocprim::radix_sort_pairs below 65 536 items: same permutation, time per sort.
-// Build: hipcc --offload-arch=gfx950 -O3 -I realsense-pointcloud_amd/csrc tools/microbench/small_sort.hip -o tools/_build/small_sort
+// small_sort.hip — tools/microbench/small_sort.hpp against rocprim::radix_sort_pairs below 65 536 items: same permutation, time per sort.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench/small_sort.hip -o tools/_build/small_sort
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>

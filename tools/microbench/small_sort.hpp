@@ -1,4 +1,6 @@
-// small_sort.hpp — a stable sort of at most 65 536 (key, value) pairs in TWO launches.
+// small_sort.hpp — a stable sort of at most 65 536 (key, value) pairs in TWO launches.  AN EXPERIMENT, not part of the library:
+// same permutation as rocprim::radix_sort_pairs, but 64 us against rocPRIM's 41 us for 5 x 10^4 pairs as written
+// (small_sort.hip, small_sort_parts.hip: the 4096-item block sort alone takes 25 us, the placement 30-40 us).
 //
 // The frame loops of the edge schemes sort five clouds of 30-50 k points per frame (the source of each alignment by its
 // Morton key, the voxel filter's slots and runs, the new points of the grown target: icp_edge_based_registration.hpp:75-120

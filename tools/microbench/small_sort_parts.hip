@@ -1,4 +1,4 @@
-// small_sort_parts.hip — dev probe: the two kernels of csrc/small_sort.hpp in variants, timed apart (48 k pairs).
+// small_sort_parts.hip — dev probe: the two kernels of tools/microbench/small_sort.hpp in variants, timed apart (48 k pairs).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/microbench/small_sort_parts.hip -o tools/_build/small_sort_parts
 #include <hip/hip_runtime.h>
 #include <cstring>

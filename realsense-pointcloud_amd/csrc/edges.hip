@@ -96,10 +96,13 @@ __global__ __launch_bounds__(kBlock) void k_edge_sobel(const float *sm, int w, i
 // pcl::Edge::suppressNonMaxima: interior pixels at or above the low threshold that are no smaller than
 // their two neighbours along the gradient keep their magnitude, everything else is 0.
 // label[p] = p for a kept pixel (its own component to start with), -1 otherwise.
-__global__ __launch_bounds__(kBlock) void k_edge_nms(const float *mag, const uint8_t *dir, int w, int h, float t_low, float *mx, int *label)
+// strong[p] = 0: no component is strong yet (k_edge_cc_roots marks the roots; no launch of a memset in between).
+__global__ __launch_bounds__(kBlock) void k_edge_nms(const float *mag, const uint8_t *dir, int w, int h, float t_low, float *mx, int *label,
+                                                     uint32_t *strong)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= w * h) return;
+    strong[p] = 0u;
     const int i = p / w, j = p - i * w;
     float out = 0.0f;
     if (i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
@@ -241,11 +244,10 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     RSREG_HIP(ctx, hipGetLastError());
     k_edge_sobel<<<nb, kBlock, 0, st>>>(sm, w, h, mag, dir);
     RSREG_HIP(ctx, hipGetLastError());
-    k_edge_nms<<<nb, kBlock, 0, st>>>(mag, dir, w, h, t_low, mx, label);
+    k_edge_nms<<<nb, kBlock, 0, st>>>(mag, dir, w, h, t_low, mx, label, strong);
     RSREG_HIP(ctx, hipGetLastError());
     k_edge_cc_merge<<<nb, kBlock, 0, st>>>(mx, w, h, label);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, hipMemsetAsync(strong, 0, n * 4, st));
     k_edge_cc_roots<<<nb, kBlock, 0, st>>>(mx, N, t_high, label, strong);
     RSREG_HIP(ctx, hipGetLastError());
     k_edge_flags<<<nb, kBlock, 0, st>>>(mx, label, strong, N, flag);

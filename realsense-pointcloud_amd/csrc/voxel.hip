@@ -56,11 +56,13 @@ __device__ __forceinline__ uint32_t slot_of(const VoxelOf &v)
     return (uint32_t)(v.ix * 7171 + v.iy * 3079 + v.iz * 4231) & (kHist - 1);
 }
 
-// key = slot (non-finite points: kHist, sorted behind everything), value = input position
+// key = slot (non-finite points: kHist, sorted behind everything), value = input position; the filter's four counters
+// start at zero (this is its first kernel: no launch of a memset for 16 bytes)
 __global__ __launch_bounds__(kVBlock) void k_vox_keys(const char *recs, size_t stride, uint32_t n, float ivx, float ivy, float ivz,
-                                                      uint32_t *keys, uint32_t *vals)
+                                                      uint32_t *keys, uint32_t *vals, uint32_t *stats)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) stats[i] = 0u;
     if (i >= n) return;
     const VoxelOf v = voxel_of(recs + (size_t)i * stride, ivx, ivy, ivz);
     keys[i] = v.ok ? slot_of(v) : kHist;
@@ -323,9 +325,8 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     uint32_t *long_runs = rid;              // the run ids are dead once the starts are written
     float *cent = b_cent.as<float>();
     uint32_t *stats = b_misc.as<uint32_t>() + 32;
-    RSREG_HIP(ctx, hipMemsetAsync(stats, 0, 16, st));
     const uint32_t nb = div_up_u(N, kVBlock);
-    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals);
+    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals, stats);
     RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
     RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));

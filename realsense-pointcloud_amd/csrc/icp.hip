@@ -368,7 +368,7 @@ int update_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t
                                                                       xbits, idx_shift, new_first, ctx->d_tgt_merge.as<float4>(), mkeys,
                                                                       ctx->d_pos_of.as<uint32_t>());
     RSREG_HIP(ctx, hipGetLastError());
-    k_dense_merge_finish<KeyT><<<div_up(n_old + m, kBlock), kBlock, 0, st>>>(mkeys, ctx->d_tgt_merge.as<float4>(), d_misc + 16, n_old, m, xbits, new_lo, new_n,
+    k_dense_merge_finish<KeyT><<<std::min(div_up(n_old + m, kBlock), kMergeFinishBlocks), kBlock, 0, st>>>(mkeys, ctx->d_tgt_merge.as<float4>(), d_misc + 16, n_old, m, xbits, new_lo, new_n,
                                                                              g.sx, g.sxy, table, table + (total + 2), d_misc + 48);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 20, d_misc + 16, 34 * 4, hipMemcpyDeviceToHost, st));

@@ -253,59 +253,56 @@ __global__ __launch_bounds__(kBlock) void k_dense_merge(const float4 *old_sorted
 // rule), the occupancy bits of cells that new points start, the far-away points behind the run, and two counts:
 // counts[0] = occupied cells, counts[1] = exact copies of a predecessor (the build would drop them: the caller builds
 // afresh when there is one).  `counts` lies in another cache line than stats_in: every thread reads stats_in[0].  [new_lo, new_lo + new_n): the original indices of the new points.
-// *counter += the number of lanes of this wave with `yes`: one atomic per wave.  (The kernel below takes 20-95 us for
-// 7 x 10^4 - 6 x 10^5 points whatever its counters or occupancy bits do: its cost is two scattered 4-byte stores per
-// occupied cell into a table of 10^7 slots, as in a build.)
-__device__ __forceinline__ void wave_count(uint32_t *counter, bool yes)
-{
-    const unsigned long long votes = __ballot(yes);
-    if (votes && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(votes)) atomicAdd(counter, (uint32_t)__popcll(votes));
-}
-
+// Launched with at most kMergeFinishBlocks workgroups, each walking its share of the run: the two counts go through the
+// workgroup's LDS and cost two atomics per WORKGROUP.  (One per wave on the same two words -- what the compiler's atomic
+// optimizer makes of a per-lane atomicAdd anyway -- was what this kernel took its 20-95 us for: 10^4 same-address atomics
+// at 3-5 ns each.  The scattered table stores and the occupancy bits are cheap beside that.)
+constexpr uint32_t kMergeFinishBlocks = 1024;
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_dense_merge_finish(const KeyT *keys, float4 *merged, const uint32_t *stats_in, uint32_t n_old, uint32_t m,
                                                                uint32_t xbits, uint32_t new_lo, uint32_t new_n, int sx, int sxy, uint32_t *table,
                                                                uint32_t *nbr, uint32_t *counts)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t sh_counts[2];
+    if (threadIdx.x < 2) sh_counts[threadIdx.x] = 0u;
+    __syncthreads();
     const uint32_t total = n_old + m - stats_in[0];
-    const bool in = p < total;
-    KeyT k = 0;
-    uint32_t slot = 0;
-    bool cstart = false, copy = false;
-    if (in) {
-        k = keys[p];
-        slot = (uint32_t)(k >> xbits);
-        cstart = true;
+    uint32_t my_cells = 0, my_copies = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const KeyT k = keys[p];
+        const uint32_t slot = (uint32_t)(k >> xbits);
+        bool cstart = true;
         if (p > 0) {
             const KeyT kp = keys[p - 1];
             cstart = (kp >> xbits) != (k >> xbits);
             if (k == kp) {
                 const float4 a = merged[p], b = merged[p - 1];
-                copy = a.x == b.x && a.y == b.y && tgt_z(a) == tgt_z(b);
+                if (a.x == b.x && a.y == b.y && tgt_z(a) == tgt_z(b)) ++my_copies;
             }
             // (the cell before ends here; when it is the neighbouring slot, the store below writes the same word)
             if (cstart && (uint32_t)(kp >> xbits) + 1u != slot) table[(uint32_t)(kp >> xbits) + 1u] = p;
         }
-    }
-    wave_count(&counts[1], copy);
-    wave_count(&counts[0], cstart);
-    if (!in) return;
-    if (cstart) {
-        table[slot] = p;
-        const uint32_t idx = tgt_idx(merged[p]);
-        if (idx - new_lo < new_n) {   // (a cell whose first point is an old one was occupied before: its bits are set)
+        if (cstart) {
+            ++my_cells;
+            table[slot] = p;
+            const uint32_t idx = tgt_idx(merged[p]);
+            if (idx - new_lo < new_n) {   // (a cell whose first point is an old one was occupied before: its bits are set)
 #pragma unroll
-            for (int j = 0; j < 27; ++j) {
-                const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
-                atomicOr(&nbr[(int)slot - ((dz - 1) * sxy + (dy - 1) * sx + (dx - 1))], 1u << j);
+                for (int j = 0; j < 27; ++j) {
+                    const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
+                    atomicOr(&nbr[(int)slot - ((dz - 1) * sxy + (dy - 1) * sx + (dx - 1))], 1u << j);
+                }
             }
         }
+        if (p == total - 1) {
+            table[slot + 1u] = total;
+            for (uint32_t q = 0; q < 4; ++q) merged[total + q] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
+        }
     }
-    if (p == total - 1) {
-        table[slot + 1u] = total;
-        for (uint32_t q = 0; q < 4; ++q) merged[total + q] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
-    }
+    if (my_cells) atomicAdd(&sh_counts[0], my_cells);
+    if (my_copies) atomicAdd(&sh_counts[1], my_copies);
+    __syncthreads();
+    if (threadIdx.x < 2 && sh_counts[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh_counts[threadIdx.x]);
 }
 
 // table[slot of occupied cell c] = its point count (the exclusive scan of the table then gives

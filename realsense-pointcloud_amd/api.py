@@ -172,8 +172,10 @@ class DeviceCloud:
         _l.check(_l.lib().rsreg_cloud_version(self.h, C.byref(i), C.byref(v)))
         return (i.value, v.value)
 
+    @property
     def device_ptr(self):
-        return _l.lib().rsreg_cloud_device_ptr(self.h)
+        """Address of the records in HBM (an int; 0 for a cloud without a buffer)."""
+        return int(_l.lib().rsreg_cloud_device_ptr(self.h) or 0)
 
     def download(self):
         n, stride, w, h, dense = self.info()

@@ -135,6 +135,9 @@ void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
         b.cap = 0;
         return;
     }
+    // the buffer is freed: whatever the source worker still has to queue reads it (load_source_queue on stream_src), so
+    // that work has to be queued AND finished first -- hipFree only waits for what is already on a stream
+    if (ctx->src_pending) { (void)ctx->source_enqueued(); (void)hipEventSynchronize(ctx->ev_src_done); }
     (void)hipStreamSynchronize(ctx->stream);
     b.release();
 }

@@ -20,6 +20,7 @@
 #include "icp_kernels.hpp"
 #include "icp_tile_kernel.hpp"
 #include "icp_dense.hpp"
+#include "icp_rows.hpp"
 #include "sort_cfg.hpp"
 
 using namespace rsreg;
@@ -852,6 +853,23 @@ unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
     return ctx->d_brick.as<unsigned long long>();
 }
 
+// the search with the target staged through LDS row by row (icp_rows.hpp): RSREG_ROWS=1 / 0
+bool use_rows_kernel()
+{
+    const char *e = std::getenv("RSREG_ROWS");
+    return e && e[0] == '1';
+}
+
+RowsStats *rows_stats()   // dev: RSREG_ROWS_STATS=1, counters of every launch of the rows kernel, printed at rsreg_icp_end
+{
+    static RowsStats *d = [] {
+        RowsStats *p = nullptr;
+        if (std::getenv("RSREG_ROWS_STATS") && hipMalloc(&p, sizeof(RowsStats)) == hipSuccess) (void)hipMemset(p, 0, sizeof(RowsStats));
+        return p;
+    }();
+    return d;
+}
+
 bool use_tile_kernel()
 {
     // The LDS-staged tile kernel is exact but, with fixed 128-point tiles, not yet faster than
@@ -1237,6 +1255,7 @@ int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
+    if (use_rows_kernel()) n4 = n2 = 0;   // (that kernel's tiles are never split)
     static const bool xcd = !(std::getenv("RSREG_SCHED_XCD") && std::getenv("RSREG_SCHED_XCD")[0] == '0');
     if (xcd) {
         n4 -= n4 % 8u;   // (an eighth of the splits to every run)
@@ -1291,6 +1310,15 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                     sc.cost = sb.cost;
                 }
             }
+            if (use_rows_kernel() && !wt) {
+                RowsStats *rst = rows_stats();
+                auto rk = rst ? (blocks ? k_icp_fused_rows<1, true> : k_icp_fused_rows<2, true>)
+                              : (blocks ? k_icp_fused_rows<1, false> : k_icp_fused_rows<2, false>);
+                rk<<<grid, kTile, 0, ctx->stream>>>(
+                    ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
+                    dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
+                    ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), dev, sc, rst);
+            } else
             kern<<<grid, kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
@@ -1803,6 +1831,14 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
                 std::fclose(f);
             }
         }
+    }
+    if (RowsStats *rst = use_rows_kernel() ? rows_stats() : nullptr) {
+        RowsStats h{};
+        (void)hipMemcpy(&h, rst, sizeof(h), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[rsreg] rows kernel: %u tiles, %u searched from global memory, %u passes, %u records staged, %u rows (%u not empty), "
+                     "%u row visits, %u candidates, %u binary-search steps\n", h.tiles, h.fallback_tiles, h.passes, h.records, h.rows, h.rows_nonempty,
+                     h.row_visits, h.candidates, h.bs_steps);
+        (void)hipMemset(rst, 0, sizeof(h));
     }
     if (uint32_t *st = tile_stats(ctx)) {
         uint32_t h[9] = {0};

@@ -18,9 +18,7 @@
 #include <vector>
 
 #include "icp_kernels.hpp"
-#include "icp_tile_kernel.hpp"
 #include "icp_dense.hpp"
-#include "icp_rows.hpp"
 #include "sort_cfg.hpp"
 
 using namespace rsreg;
@@ -88,8 +86,6 @@ GridDev grid_dev(const rsreg_ctx *ctx, double max_dist)
     g.dx = p.dims[0]; g.dy = p.dims[1]; g.dz = p.dims[2];
     g.bmask = p.table_mask;
     g.max_ring = p.max_ring;
-    static const int halo_env = std::getenv("RSREG_HALO") ? std::atoi(std::getenv("RSREG_HALO")) : 1;
-    g.halo = std::max(1, std::min(p.max_ring, std::min(halo_env, kHaloMax)));
     // squared search radius as a float that is never below the f64 gate PCL compares with
     const double gate2 = max_dist * max_dist;
     if (!(gate2 < (double)FLT_MAX)) {
@@ -853,41 +849,6 @@ unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
     return ctx->d_brick.as<unsigned long long>();
 }
 
-// the search with the target staged through LDS row by row (icp_rows.hpp): RSREG_ROWS=1 / 0
-bool use_rows_kernel()
-{
-    const char *e = std::getenv("RSREG_ROWS");
-    return e && e[0] == '1';
-}
-
-RowsStats *rows_stats()   // dev: RSREG_ROWS_STATS=1, counters of every launch of the rows kernel, printed at rsreg_icp_end
-{
-    static RowsStats *d = [] {
-        RowsStats *p = nullptr;
-        if (std::getenv("RSREG_ROWS_STATS") && hipMalloc(&p, sizeof(RowsStats)) == hipSuccess) (void)hipMemset(p, 0, sizeof(RowsStats));
-        return p;
-    }();
-    return d;
-}
-
-bool use_tile_kernel()
-{
-    // The LDS-staged tile kernel is exact but, with fixed 128-point tiles, not yet faster than
-    // the global-memory search on clouds whose areal density varies 10x:
-    // opt in with RSREG_TILE=1.
-    static const bool on = [] {
-        const char *e = std::getenv("RSREG_TILE");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
-uint32_t *tile_stats(rsreg_ctx *ctx)
-{
-    static const bool on = std::getenv("RSREG_TILE_STATS") != nullptr;
-    return on ? ctx->d_misc.as<uint32_t>() + 32 : nullptr;
-}
-
 bool filters_on(const rsreg_icp_params &p)
 {
     return p.use_reciprocal_correspondences != 0 || (p.trim_overlap_ratio > 0.0 && p.trim_overlap_ratio < 1.0);
@@ -995,10 +956,6 @@ int launch_search(rsreg_ctx *ctx)
                                                                              dense_dev(ctx, s.prm.max_correspondence_distance), gate2,
                                                                              ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
                                                                              seed_ptr(ctx));
-        else if (use_tile_kernel())
-            k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(Mat4f::identity()), 0, g,
-                                                                      gate2, ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
-                                                                      1, nullptr, 0, tile_stats(ctx), seed_ptr(ctx));
         else
             k_nn_search<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, g, gate2,
                                                                        ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(), seed_ptr(ctx));
@@ -1255,7 +1212,6 @@ int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
-    if (use_rows_kernel()) n4 = n2 = 0;   // (that kernel's tiles are never split)
     static const bool xcd = !(std::getenv("RSREG_SCHED_XCD") && std::getenv("RSREG_SCHED_XCD")[0] == '0');
     if (xcd) {
         n4 -= n4 % 8u;   // (an eighth of the splits to every run)
@@ -1310,15 +1266,6 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                     sc.cost = sb.cost;
                 }
             }
-            if (use_rows_kernel() && !wt) {
-                RowsStats *rst = rows_stats();
-                auto rk = rst ? (blocks ? k_icp_fused_rows<1, true> : k_icp_fused_rows<2, true>)
-                              : (blocks ? k_icp_fused_rows<1, false> : k_icp_fused_rows<2, false>);
-                rk<<<grid, kTile, 0, ctx->stream>>>(
-                    ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
-                    dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
-                    ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), dev, sc, rst);
-            } else
             kern<<<grid, kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
@@ -1330,11 +1277,6 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
             }
             s.fused_launches++;
         }
-        else if (use_tile_kernel())
-            k_icp_tile<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc),
-                                                                     s.pending_transform ? 1 : 0, g, gate2, ctx->d_corr_pos.as<int>(),
-                                                                     ctx->d_corr_d2.as<float>(), want_corr ? 1 : 0,
-                                                                     ctx->d_partials.as<double>(), 1, tile_stats(ctx), seed_ptr(ctx));
         else
             k_icp_fused<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
                 ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0, g, gate2,
@@ -1832,21 +1774,6 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
             }
         }
     }
-    if (RowsStats *rst = use_rows_kernel() ? rows_stats() : nullptr) {
-        RowsStats h{};
-        (void)hipMemcpy(&h, rst, sizeof(h), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[rsreg] rows kernel: %u tiles, %u searched from global memory, %u passes, %u records staged, %u rows (%u not empty), "
-                     "%u row visits, %u candidates, %u binary-search steps\n", h.tiles, h.fallback_tiles, h.passes, h.records, h.rows, h.rows_nonempty,
-                     h.row_visits, h.candidates, h.bs_steps);
-        (void)hipMemset(rst, 0, sizeof(h));
-    }
-    if (uint32_t *st = tile_stats(ctx)) {
-        uint32_t h[9] = {0};
-        (void)hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[rsreg] tiles: %u staged in LDS, %u global fallback, %u empty; fallback causes: box %u bricks %u cells %u pts %u; max box %u max pts %u\n",
-                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
-        (void)hipMemset(st, 0, sizeof(h));
-    }
     if (aligned_out && n) {
         const float *src = ctx->h_stage.as<float>();
         char *dst = static_cast<char *>(aligned_out);
@@ -1904,8 +1831,7 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     const bool filtered = filters_on(*params);   // the optional correspondence filters run between the staged kernels
     const bool scan = ctx->grid.dense == 2;   // no index: the staged kernels (search over the whole target, sums)
     const bool fused = !filtered && !scan && (params->pipeline_mode == RSREG_PIPELINE_FUSED || params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP);
-    if (!filtered && !scan && params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED &&
-        !(!ctx->grid.dense && use_tile_kernel())) {
+    if (!filtered && !scan && params->pipeline_mode == RSREG_PIPELINE_DEVICE_LOOP && params->criteria_mode == RSREG_CRITERIA_FIXED) {
         rc = run_device_loop(ctx);
         if (rc) return rc;
         done = 1;

@@ -40,7 +40,6 @@ struct GridDev {
     uint32_t bmask;          // brick hash table has bmask + 1 slots
     int max_ring;            // rings (in cells) that cover the correspondence gate
     float prune2;            // squared search radius as float, rounded up (+inf: unbounded)
-    int halo;                // rings of cells the LDS tile stages around its queries (1..3)
     const BrickEntry *bricks;
     const uint32_t *cellpos;
     const float4 *pts;
@@ -846,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials,
     }
 }
 
-// One ICP iteration in one pass from global memory (the LDS-staged form is k_icp_tile):
+// One ICP iteration in one pass from global memory over the brick-hash index:
 // apply the previous increment, search, gate, accumulate.  Writes the transformed source back
 // (next iteration starts from it, like PCL's in-place transformCloud).
 __global__ __launch_bounds__(kTile) void k_icp_fused(float4 *cur, uint32_t n, Mat34 T, int apply_t, GridDev g,

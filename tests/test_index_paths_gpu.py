@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("env", [{"RSREG_FORCE_HASH": "1"}, {"RSREG_FORCE_HASH": "1", "RSREG_TILE": "1"},
+@pytest.mark.parametrize("env", [{"RSREG_FORCE_HASH": "1"},
                                  {"RSREG_DENSE_MAX_CELLS": "2000000"}],
-                         ids=["brick-hash", "brick-hash+lds-tiles", "dense-only-when-small"])
+                         ids=["brick-hash", "dense-only-when-small"])
 def test_parity_suite_on_alternative_index_paths(env):
     e = dict(os.environ)
     e.update(env)

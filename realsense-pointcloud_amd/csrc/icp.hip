@@ -35,6 +35,14 @@ inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n +
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// the radix sorts of the index build and the source load driven by this library (radix32.hpp); RSREG_ROCPRIM_SORT=1: by rocPRIM's driver
+bool use_own_sort()
+{
+    static const bool off = std::getenv("RSREG_ROCPRIM_SORT") && std::getenv("RSREG_ROCPRIM_SORT")[0] == '1';
+    return !off;
+}
+
+
 hipEvent_t take_event(rsreg_ctx *ctx)
 {
     if (ctx->ev_used == ctx->ev_pool.size()) {
@@ -226,16 +234,34 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     // clear, no scan of (nx+2)(ny+2)(nz+2) entries; the occupancy words behind it are OR-ed together and start from zero
     if (gp.table_sparse) RSREG_HIP(ctx, hipMemsetAsync(table + (total + 2), 0, (total + 2) * 4, st));
     else RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));
-    k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, keys, vals);
-    RSREG_HIP(ctx, hipGetLastError());
     const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
     size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
     using SortCfg = typename RadixCfgOf<KeyT>::type;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    // 32-bit keys, enough of them for the radix path: the onesweep passes driven by this library, their state cleared by the
+    // keys kernel instead of nine memsets (radix32.hpp); otherwise rocPRIM's own driver
+    const bool own_sort = sizeof(KeyT) == 4 && n >= 65536 && use_own_sort();
+    const Radix32Plan plan = radix32_plan(n, 0, end_bit);
+    if (own_sort) sort_bytes = (size_t)plan.words * 4;
+    else RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
+    const bool start_in_out = own_sort && plan.places % 2 == 0;
+    k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, start_in_out ? keys2 : keys,
+                                                                       start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
+                                                                       own_sort ? plan.words : 0u);
+    RSREG_HIP(ctx, hipGetLastError());
+    if (own_sort) {
+        if constexpr (sizeof(KeyT) == 4) {
+            bool in_first = false;
+            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                              start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, end_bit, st, &in_first));
+            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+        }
+    } else {
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    }
     const uint32_t nbf = div_up(nfin, kBlock);
     k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
     RSREG_HIP(ctx, hipGetLastError());
@@ -713,11 +739,25 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             auto *keys = ctx->d_skeys.as<uint32_t>();
             auto *keys2 = ctx->d_skeys_alt.as<uint32_t>();
             const unsigned sort_bits = (unsigned)(mb.x + mb.y + mb.z) + 1u;
-            k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys, vals);
-            RSREG_HIP(ctx, hipGetLastError());
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            const bool own_sort = n >= 65536 && use_own_sort();   // (radix32.hpp: the sort's state is cleared by the keys kernel, no memsets)
+            const Radix32Plan plan = radix32_plan(n, 0, sort_bits);
+            if (own_sort) sort_bytes = (size_t)plan.words * 4;
+            else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
+            const bool start_in_out = own_sort && plan.places % 2 == 0;
+            uint32_t *keys_a = start_in_out ? keys2 : keys, *vals_a = start_in_out ? perm : vals;
+            uint32_t *keys_b = start_in_out ? keys : keys2, *vals_b = start_in_out ? vals : perm;
+            k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys_a, vals_a,
+                                                           own_sort ? ctx->d_stmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
+            RSREG_HIP(ctx, hipGetLastError());
+            if (own_sort) {
+                bool in_first = false;
+                RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_stmp.as<uint32_t>(), keys_a, keys_b, vals_a, vals_b, n, 0, sort_bits, st, &in_first));
+                if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+            } else {
+                RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            }
             k_gather_source<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
             RSREG_HIP(ctx, hipGetLastError());
         } else {
@@ -726,7 +766,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
             const int axis_bits = axis_bits_of(extent, (double)cell);
             const unsigned sort_bits = 3u * (unsigned)axis_bits + 1u;
-            k_source_keys<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), mb, keys, vals);
+            k_source_keys<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), mb, keys, vals, nullptr, 0u);
             RSREG_HIP(ctx, hipGetLastError());
             RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));

@@ -51,11 +51,13 @@ __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int 
 // by x, which lets a search stop inside a cell (dense_walk); non-finite points sort to the very end (all-ones key).
 // KeyT = uint32_t whenever cell id and x position fit 32 bits together (any room-scale cloud: 23 + 9 bits at 1 M
 // points): the radix sort then moves half the bytes in four passes instead of six.
+// (sort_scratch: the state of the radix sort that follows, cleared on the way -- radix32.hpp)
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t stride, uint32_t n, DenseDev g, uint32_t xbits,
-                                                       KeyT *keys, uint32_t *vals)
+                                                       KeyT *keys, uint32_t *vals, uint32_t *sort_scratch, uint32_t sort_scratch_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sort_scratch) radix32_clear(sort_scratch, sort_scratch_words, i, gridDim.x * blockDim.x);
     if (i >= n) return;
     const float *p = rec_xyz(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];

@@ -27,6 +27,7 @@
 
 #include "rsreg_ctx.hpp"
 #include "records.hpp"
+#include "radix32.hpp"
 
 namespace rsreg {
 
@@ -350,9 +351,10 @@ __device__ __forceinline__ uint32_t morton_mixed(uint32_t cx, uint32_t cy, uint3
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t stride, uint32_t n, float ox, float oy,
                                                         float oz, float inv_cell, KeyT invalid_key, MortonBits bits,
-                                                        KeyT *keys, uint32_t *vals)
+                                                        KeyT *keys, uint32_t *vals, uint32_t *sort_scratch, uint32_t sort_scratch_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sort_scratch) radix32_clear(sort_scratch, sort_scratch_words, i, gridDim.x * blockDim.x);   // (the state of the sort that follows: radix32.hpp)
     if (i >= n) return;
     const float *p = rec_xyz(raw, stride, i);
     const float x = p[0], y = p[1], z = p[2];

@@ -406,6 +406,19 @@ def main():
                 "source": "profiles/%s (static: rocprofv3 --pmc SQ_* passes of this command + tools/microbench/valu_issue.hip; the launch "
                           "time is this run's)" % ij[-1],
             }
+            # where the launch's time goes while the chip is full, and how much of it is the emptying tail
+            # (profiles/*_wave_timeline.json: start / end stamp of every wave of a scheduled launch, tools/wave_timeline.py)
+            wj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_wave_timeline.json"))
+            if wj and t.get("vmem_bound_us"):
+                w = json.load(open(os.path.join(ROOT, "profiles", wj[-1])))
+                # the address units' cycles are spent where the wave time is: the share of the wave time that falls
+                # into the period with every wave slot taken, over that period
+                out["roofline_issue"]["vmem_frac_while_full"] = t["vmem_bound_us"] * w["slots"] / w["sum_wave_time_us"]
+                out["roofline_issue"]["valu_frac_while_full"] = bound_us * w["slots"] / w["sum_wave_time_us"]
+                out["roofline_issue"]["tail_fraction"] = 1.0 - w["sum_wave_time_us"] / (w["slots"] * w["span_us"])
+                out["roofline_issue"]["wave_timeline"] = {"slots": w["slots"], "span_us": w["span_us"], "sum_wave_time_us": w["sum_wave_time_us"],
+                                                          "slots_full_until_us": w.get("full_until_us"), "waves": w.get("waves"),
+                                                          "source": "profiles/%s (static)" % wj[-1]}
             out["roofline"]["binding"] = "not HBM (the working set lives in the Infinity Cache): see roofline_issue (the contract's roofline stays the HBM one)"
     except Exception:  # noqa: BLE001
         pass
@@ -533,6 +546,8 @@ def main():
             "ms_per_pair_host_clouds": modes["host_clouds"], "ms_per_pair_device_clouds": modes["device_clouds"],
             "point_pairs_per_s_device_clouds": float(len(sp)) * ref.result.iterations / (modes["device_clouds"] * 1e-3),
             "same_transform": bool((modes["host_clouds_T"] == modes["device_clouds_T"]).all()),
+            # what the reference's one iteration per align runs: the first, unseeded and unscheduled search launch
+            "first_launch_us": (float(ref.result.ms_nn) / max(int(ref.result.n_nn_launches), 1) * 1e3) if ref.result.ms_nn > 0 else None,
         }
     gt = synth.ground_truth(1, 0, "bench")
     out["transform_error_vs_ground_truth_frobenius"] = float(np.linalg.norm(T_gpu - gt))

@@ -485,7 +485,9 @@ InFlight in_flight_of(const rsreg_cloud *c) { return InFlight{c->filling, c->up_
 int side_wait_input(rsreg_ctx *ctx, const InFlight &f, hipStream_t st)
 {
     if (!f.filling || !f.ev) return RSREG_OK;
-    if (ctx->up_worker) (void)ctx->up_worker->wait(f.ticket);
+    // (a third party's wait: a failed upload stays for the poster's own settle() to report, and this job does not run on
+    // a buffer that was never filled)
+    if (ctx->up_worker && ctx->up_worker->peek(f.ticket)) return RSREG_ERR_HIP;
     return hipStreamWaitEvent(st, f.ev, 0) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
 }
 
@@ -636,6 +638,11 @@ int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
         RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_down_gate, hipEventDisableTiming));
         for (hipEvent_t &e : ctx->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->down_worker = new rsreg::DownloadWorker();
+        ctx->down_worker->wait_ready = [](const rsreg::DownloadWorker::Job &j) -> int {
+            hipError_t e = hipSetDevice(j.device);
+            if (e == hipSuccess) e = hipEventSynchronize(static_cast<hipEvent_t>(j.ev));
+            return (int)e;
+        };
     }
     rsreg_cloud *mc = const_cast<rsreg_cloud *>(c);
     if (!mc->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&mc->ev_down, hipEventDisableTiming));
@@ -643,12 +650,20 @@ int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
     const int slot = ctx->down_next;
     ctx->down_next = (ctx->down_next + 1) % 3;
     ctx->down_worker->wait_slot(slot);   // (the copy-out that last used this staging buffer)
-    RSREG_HIP(ctx, ctx->h_down[slot].reserve(bytes));
-    RSREG_HIP(ctx, hipEventRecord(ctx->ev_down_gate, ctx->stream));
-    RSREG_HIP(ctx, hipStreamWaitEvent(ctx->stream_down, ctx->ev_down_gate, 0));
-    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_down[slot].ptr, c->buf.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream_down));
-    RSREG_HIP(ctx, hipEventRecord(ctx->ev_down[slot], ctx->stream_down));
-    RSREG_HIP(ctx, hipEventRecord(mc->ev_down, ctx->stream_down));
+    {
+        // (a failure before the job is posted must give the slot back: nobody else would, and the third download after it
+        // would wait for ever)
+        hipError_t e = ctx->h_down[slot].reserve(bytes);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_down_gate, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream_down, ctx->ev_down_gate, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_down[slot].ptr, c->buf.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream_down);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_down[slot], ctx->stream_down);
+        if (e == hipSuccess) e = hipEventRecord(mc->ev_down, ctx->stream_down);
+        if (e != hipSuccess) {
+            ctx->down_worker->release_slot(slot);
+            return rsreg::fail(ctx, RSREG_ERR_HIP, "rsreg_cloud_download_async", e);
+        }
+    }
     c->downloading = true;
     ctx->down_worker->post(rsreg::DownloadWorker::Job{ctx->ev_down[slot], ctx->h_down[slot].as<char>(), static_cast<char *>(out), bytes, slot, ctx->device});
     return RSREG_OK;

@@ -13,8 +13,7 @@ using namespace rsreg;
     do {                                                                               \
         ncclResult_t _r = (expr);                                                      \
         if (_r != ncclSuccess) {                                                       \
-            (ctx)->last_error = std::string(#expr) + ": " + ncclGetErrorString(_r);    \
-            return RSREG_ERR_RCCL;                                                     \
+            return fail((ctx), RSREG_ERR_RCCL, (std::string(#expr) + ": " + ncclGetErrorString(_r)).c_str());   \
         }                                                                              \
     } while (0)
 

@@ -35,14 +35,6 @@ inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n +
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// the radix sorts of the index build and the source load driven by this library (radix32.hpp); RSREG_ROCPRIM_SORT=1: by rocPRIM's driver
-bool use_own_sort()
-{
-    static const bool off = std::getenv("RSREG_ROCPRIM_SORT") && std::getenv("RSREG_ROCPRIM_SORT")[0] == '1';
-    return !off;
-}
-
-
 hipEvent_t take_event(rsreg_ctx *ctx)
 {
     if (ctx->ev_used == ctx->ev_pool.size()) {
@@ -188,8 +180,10 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.table_bytes = (uint32_t)(((size_t)(p.dims[0] + 2) * (p.dims[1] + 2) * (p.dims[2] + 2) + 2) * 4);
     g.nbr = ctx->d_dense.as<uint32_t>() + g.table_bytes / 4;   // the occupancy words lie right behind the table (one memset clears both)
     g.pos_of = ctx->d_pos_of.as<uint32_t>();
-    static const uint32_t debug_skip = std::getenv("RSREG_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("RSREG_DEBUG_SKIP")) : 0u;   // timing experiments only
+#ifdef RSREG_DIAG   // (diagnostic builds only -- RSREG_CXXFLAGS=-DRSREG_DIAG: the shipped library has no switch that changes a result)
+    static const uint32_t debug_skip = std::getenv("RSREG_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("RSREG_DEBUG_SKIP")) : 0u;
     g.debug_skip = debug_skip;
+#endif
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
     // how far the x order of a sorted run can be off: one bucket of the sort key (2^-xbits of a cell), plus the float
@@ -239,7 +233,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     using SortCfg = typename RadixCfgOf<KeyT>::type;
     // 32-bit keys, enough of them for the radix path: the onesweep passes driven by this library, their state cleared by the
     // keys kernel instead of nine memsets (radix32.hpp); otherwise rocPRIM's own driver
-    const bool own_sort = sizeof(KeyT) == 4 && n >= 65536 && use_own_sort();
+    const bool own_sort = sizeof(KeyT) == 4 && radix32_pays(n, end_bit);
     const Radix32Plan plan = radix32_plan(n, 0, end_bit);
     if (own_sort) sort_bytes = (size_t)plan.words * 4;
     else RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
@@ -435,6 +429,10 @@ int update_dense_incremental(rsreg_ctx *ctx, const char *d_pts, size_t n_total, 
     }
     const int rc = gp.xbits < 16 ? update_dense_keyed<uint32_t>(ctx, d_pts, n_total, stride, (uint32_t)new_lo, (uint32_t)new_n, max_dist)
                                  : update_dense_keyed<unsigned long long>(ctx, d_pts, n_total, stride, (uint32_t)new_lo, (uint32_t)new_n, max_dist);
+    if (rc < 0) {   // a failure half-way: the table and the occupancy words are partly rewritten -- there is no index any more
+        ctx->have_target = false;
+        ctx->tgt_cloud_id = 0;
+    }
     if (rc == RSREG_OK && ctx->profiling) {
         (void)hipEventRecord(ev1, ctx->stream);
         (void)hipEventSynchronize(ev1);
@@ -739,7 +737,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             auto *keys = ctx->d_skeys.as<uint32_t>();
             auto *keys2 = ctx->d_skeys_alt.as<uint32_t>();
             const unsigned sort_bits = (unsigned)(mb.x + mb.y + mb.z) + 1u;
-            const bool own_sort = n >= 65536 && use_own_sort();   // (radix32.hpp: the sort's state is cleared by the keys kernel, no memsets)
+            const bool own_sort = radix32_pays(n, sort_bits);   // (radix32.hpp: the sort's state is cleared by the keys kernel, no memsets)
             const Radix32Plan plan = radix32_plan(n, 0, sort_bits);
             if (own_sort) sort_bytes = (size_t)plan.words * 4;
             else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
@@ -938,7 +936,14 @@ int apply_filters(rsreg_ctx *ctx)
         RSREG_HIP(ctx, hipGetLastError());
         rsreg_ctx *c = ctx->recip;
         int rc = build_grid(c, ctx->d_recip_pts.as<char>(), ns, sizeof(float4), s.prm.max_correspondence_distance, 1.0);
-        if (rc) return fail(ctx, rc, c->last_error.c_str());
+        if (rc) {
+            std::string why;
+            {
+                std::lock_guard<std::mutex> lk(c->error_mutex);
+                why = c->last_error;
+            }
+            return fail(ctx, rc, why.c_str());
+        }
         if (c->grid.n_points) {
             const DenseDev gd = c->grid.dense ? dense_dev(c, s.prm.max_correspondence_distance) : DenseDev{};
             const GridDev gh = grid_dev(c, s.prm.max_correspondence_distance);
@@ -1365,7 +1370,8 @@ int run_device_loop(rsreg_ctx *ctx)
     for (int k = 0; k < 9; ++k) h->svd_v[k] = (k % 4 == 0) ? 1.0 : 0.0;
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState) + 16, hipMemcpyHostToDevice, ctx->stream));
     const int iters = std::max(1, s.prm.max_iterations);
-    for (int it = 0; it < iters; ++it) {
+    int it = 0;
+    for (; it < iters; ++it) {
         int rc = launch_fused(ctx, nullptr, false, true);
         if (rc) return rc;
     }
@@ -1450,7 +1456,18 @@ const char *rsreg_status_string(int status)
     }
 }
 
-const char *rsreg_last_error(const rsreg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+// (the message is copied under the mutex the context's helper threads report under, into a buffer of the calling thread:
+// the pointer stays valid until this thread's next call, whatever the helpers write meanwhile)
+const char *rsreg_last_error(const rsreg_ctx *ctx)
+{
+    if (!ctx) return "null ctx";
+    thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<rsreg_ctx *>(ctx)->error_mutex);
+        copy = ctx->last_error;
+    }
+    return copy.c_str();
+}
 
 int rsreg_device_count(int *count)
 {
@@ -1491,13 +1508,23 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
 {
     if (!ctx) return RSREG_OK;
     (void)hipSetDevice(ctx->device);
+    // The helper threads go first, in the order of who waits for whom -- a queued side job waits for the upload worker
+    // (side_wait_input), an upload or a download for nothing of the others -- and every stream they fed is drained before
+    // a buffer, an event or a stream is released.
     if (ctx->src_worker) {
         ctx->src_worker->shutdown();
         delete ctx->src_worker;
         ctx->src_worker = nullptr;
     }
+    if (ctx->side_worker) ctx->side_worker->shutdown();
+    if (ctx->up_worker) ctx->up_worker->shutdown();
+    if (ctx->down_worker) ctx->down_worker->shutdown();
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_src) (void)hipStreamSynchronize(ctx->stream_src);
+    if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
+    if (ctx->stream_down) (void)hipStreamSynchronize(ctx->stream_down);
+    for (rsreg_ctx::SideSet &ss : ctx->side_sets)
+        if (ss.stream) (void)hipStreamSynchronize(ss.stream);
     rsreg_comm_destroy(ctx);
     if (ctx->recip) {   // the child context of the reciprocal index runs on this context's stream: it goes first
         rsreg_ctx_destroy(ctx->recip);
@@ -1896,7 +1923,9 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
     static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
-    if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
+    // (after an incremental update the cell starts of the last build from scratch no longer describe the index: the figure
+    // stays 0, "not known", until the next build)
+    if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0 && ctx->grid_info.n_updates == 0) {
         const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);
         uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;
         uint32_t h = 0;

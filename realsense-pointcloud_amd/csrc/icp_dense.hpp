@@ -39,7 +39,9 @@ struct DenseDev {
     float x_slack;           // metres: slack on the x order of a sorted run (sort-key bucket + float rounding of the position)
     const uint32_t *nbr;     // per cell: bit j = dz*9+dy*3+dx (offsets 0..2) set when that neighbour holds points
     const uint32_t *pos_of;  // original index -> position in pts (kept points only)
-    uint32_t debug_skip;     // timing experiments only (RSREG_DEBUG_SKIP, results WRONG): 1 = no search beyond ring 1, 3 = nothing beyond the own cell
+#ifdef RSREG_DIAG
+    uint32_t debug_skip;     // diagnostic builds only (-DRSREG_DIAG; RSREG_DEBUG_SKIP, results WRONG): 1 = no search beyond ring 1, 3 = nothing beyond the own cell
+#endif
 };
 
 __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int y, int z)
@@ -557,7 +559,10 @@ __device__ __forceinline__ uint32_t dense_own(const DenseDev &g, const DRes &rs,
     r1.right_half = right_half;
     r1.mask = 0;
     const bool any_face = (gx0 <= lim_c) | (gx2 <= lim_c) | (gy0 <= lim_c) | (gy2 <= lim_c) | (gz0 <= lim_c) | (gz2 <= lim_c);
-    if (!any_face || !(occ & ~(1u << 13)) || (g.debug_skip & 2u)) return occ;
+#ifdef RSREG_DIAG
+    if (g.debug_skip & 2u) return occ;
+#endif
+    if (!any_face || !(occ & ~(1u << 13))) return occ;
     uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
@@ -631,7 +636,10 @@ __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs
 __device__ __forceinline__ bool dense_needs_far(const DenseDev &g, float limit2)
 {
     const float reach = (1.0f - g.margin) * g.cell;   // ring 1 proves everything up to here
-    return g.max_ring >= 2 && limit2 > reach * reach && !g.debug_skip;
+#ifdef RSREG_DIAG
+    if (g.debug_skip) return false;
+#endif
+    return g.max_ring >= 2 && limit2 > reach * reach;
 }
 
 // Everything beyond rings 0-1, row by row: the cells of one (y, z) row are one contiguous run of

@@ -508,17 +508,31 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     if (n_leaves < 0x7fffffffull) {
         auto *keys = ctx->d_keys.as<uint32_t>();
         auto *keys2 = ctx->d_keys_alt.as<uint32_t>();
-        k_ndt_keys<uint32_t><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, (uint32_t)n_leaves, keys, vals);
-        RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        // (the onesweep passes driven by this library, their state cleared by the keys kernel: radix32.hpp)
+        const bool own_sort = radix32_pays(n, key_bits);
+        const Radix32Plan plan = radix32_plan(n, 0, key_bits);
+        if (own_sort) sort_bytes = (size_t)plan.words * 4;
+        else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        const bool start_in_out = own_sort && plan.places % 2 == 0;   // (an even number of passes ends in the pair it started from)
+        k_ndt_keys<uint32_t><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, (uint32_t)n_leaves, start_in_out ? keys2 : keys,
+                                                                                 start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
+                                                                                 own_sort ? plan.words : 0u);
+        RSREG_HIP(ctx, hipGetLastError());
+        if (own_sort) {
+            bool in_first = false;
+            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                              start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, key_bits, st, &in_first));
+            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+        } else {
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        }
         k_ndt_flag_starts<uint32_t><<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
         RSREG_HIP(ctx, hipGetLastError());
     } else {
         auto *keys = ctx->d_keys.as<unsigned long long>();
         auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
-        k_ndt_keys<unsigned long long><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, n_leaves, keys, vals);
+        k_ndt_keys<unsigned long long><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, n_leaves, keys, vals, nullptr, 0u);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));

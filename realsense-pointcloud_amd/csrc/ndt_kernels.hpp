@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+
+#include "radix32.hpp"
 #include <cstdint>
 
 #include "records.hpp"
@@ -57,9 +59,10 @@ __device__ __forceinline__ bool ndt_finite3(float x, float y, float z)
 // (non-finite points get `invalid_key`, one above every leaf's: they sort last, and the sort only has to look at its bits)
 template <typename KeyT>
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_keys(const char *pts, size_t stride, uint32_t n, NdtBinParams bp, KeyT invalid_key,
-                                                        KeyT *keys, uint32_t *vals)
+                                                        KeyT *keys, uint32_t *vals, uint32_t *sort_scratch, uint32_t sort_scratch_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sort_scratch) radix32_clear(sort_scratch, sort_scratch_words, i, gridDim.x * blockDim.x);   // (the state of the sort that follows: radix32.hpp)
     if (i >= n) return;
     const float *p = reinterpret_cast<const float *>(pts + (size_t)i * stride);
     const float x = p[0], y = p[1], z = p[2];

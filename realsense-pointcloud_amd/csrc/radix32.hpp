@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "sort_cfg.hpp"
 
@@ -31,11 +32,12 @@ struct Radix32Plan {
     uint32_t off_digits = 0, off_tmp = 0, off_bid = 0, off_states = 0;
 };
 
-inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit)
+// (items_per_block: of the digit passes -- 1024 x 4 unless radix32_sort_pairs is instantiated otherwise)
+inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit, unsigned items_per_block = kR32SortBlock * kR32SortItems)
 {
     Radix32Plan p;
     p.places = (end_bit - begin_bit + kR32Bits - 1) / kR32Bits;
-    p.blocks = (uint32_t)((n + kR32SortBlock * kR32SortItems - 1) / (kR32SortBlock * kR32SortItems));
+    p.blocks = (uint32_t)((n + items_per_block - 1) / items_per_block);
     p.hist_blocks = (uint32_t)((n + kR32HistBlock * kR32HistItems - 1) / (kR32HistBlock * kR32HistItems));
     p.off_digits = 0;
     p.off_tmp = p.places << kR32Bits;
@@ -45,12 +47,24 @@ inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit)
     return p;
 }
 
+// When this driver is the faster one (profiles/r04_sort_driver.txt): from 65 536 pairs on whatever the bits (below that
+// rocPRIM merge-sorts: 27-43 us), and from 8 192 pairs on for keys of at most 16 bits (two digit passes: 24 us at 36 k pairs
+// where the merge path takes 42).  RSREG_ROCPRIM_SORT=1 hands every sort back to rocPRIM's driver.
+inline bool radix32_pays(size_t n, unsigned bits)
+{
+    static const bool off = std::getenv("RSREG_ROCPRIM_SORT") && std::getenv("RSREG_ROCPRIM_SORT")[0] == '1';
+    if (off || bits == 0 || bits > 32) return false;
+    return n >= 65536 || (n >= 8192 && bits <= 16);
+}
+
 // what the kernel in front of a sort does on its way: thread `t` of `threads` clears its share of the scratch block
 __device__ __forceinline__ void radix32_clear(uint32_t *scratch, uint32_t words, uint32_t t, uint32_t threads)
 {
     for (uint32_t w = t; w < words; w += threads) scratch[w] = 0u;
 }
 
+// (templates, so that the several translation units of the library that include this header share one definition)
+template <int kDummy = 0>
 __global__ __launch_bounds__(kR32HistBlock) void k_r32_histograms(const uint32_t *keys, uint32_t *digits, uint32_t n, uint32_t full_blocks,
                                                                   uint32_t begin_bit, uint32_t end_bit)
 {
@@ -58,22 +72,25 @@ __global__ __launch_bounds__(kR32HistBlock) void k_r32_histograms(const uint32_t
                                                                                          begin_bit, end_bit);
 }
 
+template <int kDummy = 0>
 __global__ __launch_bounds__(kR32HistBlock) void k_r32_scan_histograms(uint32_t *digits)
 {
     rocprim::detail::onesweep_scan_histograms<kR32HistBlock, kR32Bits>(digits);
 }
 
-__global__ __launch_bounds__(kR32SortBlock) void k_r32_pass(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                                                            uint32_t n, uint32_t *digits_in, uint32_t *digits_out, R32State *states, uint32_t bit,
-                                                            uint32_t bits, uint32_t full_blocks, R32Bid bid)
+template <unsigned kBlockT, unsigned kItemsT>
+__global__ __launch_bounds__(kBlockT) void k_r32_pass(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                                                      uint32_t n, uint32_t *digits_in, uint32_t *digits_out, R32State *states, uint32_t bit,
+                                                      uint32_t bits, uint32_t full_blocks, R32Bid bid)
 {
-    rocprim::detail::onesweep_iteration<kR32SortBlock, kR32SortItems, kR32Bits, false, rocprim::block_radix_rank_algorithm::match>(
+    rocprim::detail::onesweep_iteration<kBlockT, kItemsT, kR32Bits, false, rocprim::block_radix_rank_algorithm::match>(
         keys_in, keys_out, vals_in, vals_out, n, digits_in, digits_out, states, rocprim::identity_decomposer{}, bit, bits, full_blocks, bid);
 }
 
 // Sorts n pairs by bits [begin_bit, end_bit) of the key.  `scratch` (plan.words words) must be all zero when the first
 // kernel starts and is dirty afterwards.  Returns through *in_first whether the sorted pairs lie in (keys_a, vals_a)
 // (true) or in (keys_b, vals_b); the other pair is overwritten too.
+template <unsigned kBlockT = kR32SortBlock, unsigned kItemsT = kR32SortItems>
 inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                                      size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first)
 {
@@ -84,10 +101,11 @@ inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, ui
     {
         const uint32_t per = kR32HistBlock * kR32HistItems;
         const uint32_t full = (uint32_t)(n % per == 0 ? p.hist_blocks : p.hist_blocks - 1);
-        k_r32_histograms<<<p.hist_blocks, kR32HistBlock, 0, st>>>(keys_a, digits, (uint32_t)n, full, begin_bit, end_bit);
-        k_r32_scan_histograms<<<p.places, kR32HistBlock, 0, st>>>(digits);
+        k_r32_histograms<0><<<p.hist_blocks, kR32HistBlock, 0, st>>>(keys_a, digits, (uint32_t)n, full, begin_bit, end_bit);
+        k_r32_scan_histograms<0><<<p.places, kR32HistBlock, 0, st>>>(digits);
     }
-    const uint32_t per = kR32SortBlock * kR32SortItems;
+    const uint32_t per = kBlockT * kItemsT;
+    if (p.blocks != (uint32_t)((n + per - 1) / per)) return hipErrorInvalidValue;   // (the plan was made for another tiling)
     const uint32_t full = (uint32_t)(n % per == 0 ? p.blocks : p.blocks - 1);
     bool from_a = true;
     unsigned bit = begin_bit;
@@ -95,7 +113,7 @@ inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, ui
         const uint32_t bits = std::min(kR32Bits, end_bit - bit);
         R32Bid bid = R32Bid::create(scratch + p.off_bid + place);
         auto *states = reinterpret_cast<R32State *>(scratch + p.off_states + (size_t)place * (p.blocks << kR32Bits));
-        k_r32_pass<<<p.blocks, kR32SortBlock, 0, st>>>(from_a ? keys_a : keys_b, from_a ? keys_b : keys_a, from_a ? vals_a : vals_b,
+        k_r32_pass<kBlockT, kItemsT><<<p.blocks, kBlockT, 0, st>>>(from_a ? keys_a : keys_b, from_a ? keys_b : keys_a, from_a ? vals_a : vals_b,
                                                         from_a ? vals_b : vals_a, (uint32_t)n, digits + (place << kR32Bits), scratch + p.off_tmp, states,
                                                         bit, bits, full, bid);
         from_a = !from_a;

@@ -17,6 +17,7 @@
 
 #include "../../include/rsreg.h"
 #include "host_linalg.hpp"
+#include "workers.hpp"
 
 namespace rsreg {
 
@@ -57,199 +58,6 @@ struct CloudPool {
         const char *e = std::getenv("RSREG_CLOUD_POOL_MB");
         return (size_t)(e ? std::max(0ll, std::atoll(e)) : 4096ll) << 20;
     }();
-};
-
-// The host side of a source load (a bounding-box round trip and ~25 launches: 0.13 ms of host time at any size) runs on a
-// thread of the context's own, so that the caller's thread goes straight on to the target's index build
-// (incremental_icp.hpp:57-58: setInputSource, then setInputTarget): the two queues are then FILLED side by side, not only
-// drained side by side.  One job at a time; whoever needs the source (or hands one of its buffers on) waits for the
-// job to have queued everything first (wait), then for the GPU as before (ev_src_done).
-struct SourceWorker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<int()> job;
-    bool has_job = false, busy = false, stop = false;
-    int rc = 0;
-
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return has_job || stop; });
-            if (stop) return;
-            std::function<int()> f = std::move(job);
-            has_job = false;
-            busy = true;
-            lk.unlock();
-            const int r = f();
-            lk.lock();
-            rc = r;
-            busy = false;
-            cv.notify_all();
-        }
-    }
-    void post(std::function<int()> f)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (!th.joinable()) th = std::thread([this] { loop(); });
-        cv.wait(lk, [&] { return !has_job && !busy; });
-        job = std::move(f);
-        has_job = true;
-        rc = 0;
-        cv.notify_all();
-    }
-    int wait()   // until the posted job has run; its status
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return !has_job && !busy; });
-        return rc;
-    }
-    void shutdown()
-    {
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return !has_job && !busy; });
-            stop = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
-};
-
-// Downloads that run beside the frame loop (rsreg_cloud_download_async): the copy lands in one of a few pinned staging
-// buffers on a stream of its own; this thread waits for it and copies it out to the caller's (pageable) memory.
-struct DownloadWorker {
-    struct Job {
-        hipEvent_t ev;
-        const char *stage;
-        char *dst;
-        size_t bytes;
-        int slot, device;
-    };
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<Job> queue;
-    bool busy = false, stop = false;
-    bool slot_busy[3] = {false, false, false};
-    int err = 0;
-
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return !queue.empty() || stop; });
-            if (queue.empty() && stop) return;
-            const Job j = queue.front();
-            queue.erase(queue.begin());
-            busy = true;
-            lk.unlock();
-            hipError_t e = hipSetDevice(j.device);
-            if (e == hipSuccess) e = hipEventSynchronize(j.ev);
-            if (e == hipSuccess) {
-                // a few threads: one core copies ~10 GB/s, a frame of 10 MB would take as long as the link needs for it
-                const size_t parts = j.bytes >= (size_t)4 << 20 ? 4 : 1, step = (j.bytes + parts - 1) / parts;
-                std::vector<std::thread> helpers;
-                for (size_t p = 1; p < parts; ++p)
-                    helpers.emplace_back([=] { const size_t lo = p * step, hi = std::min(j.bytes, lo + step); if (lo < hi) std::memcpy(j.dst + lo, j.stage + lo, hi - lo); });
-                std::memcpy(j.dst, j.stage, std::min(step, j.bytes));
-                for (auto &t : helpers) t.join();
-            }
-            lk.lock();
-            if (e != hipSuccess && !err) err = (int)e;
-            slot_busy[j.slot] = false;
-            busy = false;
-            cv.notify_all();
-        }
-    }
-    void wait_slot(int slot)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return !slot_busy[slot]; });
-        slot_busy[slot] = true;
-    }
-    void post(const Job &j)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (!th.joinable()) th = std::thread([this] { loop(); });
-        queue.push_back(j);
-        cv.notify_all();
-    }
-    int wait_idle()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return queue.empty() && !busy; });
-        const int e = err;
-        err = 0;
-        return e;
-    }
-    void shutdown()
-    {
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return queue.empty() && !busy; });
-            stop = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
-};
-
-// Jobs run one after the other on a thread of their own, each with a ticket the poster can wait for.  The uploads that
-// run beside the frame loop (rsreg_cloud_upload_deferred / _async) are staged here: copying a 9.8 MB frame into pinned
-// memory takes 0.2 ms of a host thread, and on the caller's thread that is 0.2 ms per frame with nothing queued on the GPU.
-struct TicketWorker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<std::function<int()>> queue;
-    uint64_t posted = 0, done = 0;
-    bool stop = false;
-    int err = 0;
-
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return !queue.empty() || stop; });
-            if (queue.empty() && stop) return;
-            std::function<int()> f = std::move(queue.front());
-            queue.erase(queue.begin());
-            lk.unlock();
-            const int r = f();
-            lk.lock();
-            if (r && !err) err = r;
-            ++done;
-            cv.notify_all();
-        }
-    }
-    uint64_t post(std::function<int()> f)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (!th.joinable()) th = std::thread([this] { loop(); });
-        queue.push_back(std::move(f));
-        cv.notify_all();
-        return ++posted;
-    }
-    int wait(uint64_t ticket)   // until job `ticket` has run; the first error of any job since the last wait
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return done >= ticket; });
-        const int e = err;
-        err = 0;
-        return e;
-    }
-    void shutdown()
-    {
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return done >= posted; });
-            stop = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
 };
 
 struct PinnedBuf {

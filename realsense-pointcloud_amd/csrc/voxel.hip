@@ -27,6 +27,7 @@
 
 #include "rsreg_ctx.hpp"
 #include "sort_cfg.hpp"
+#include "radix32.hpp"
 
 namespace rsreg {
 namespace {
@@ -59,10 +60,12 @@ __device__ __forceinline__ uint32_t slot_of(const VoxelOf &v)
 // key = slot (non-finite points: kHist, sorted behind everything), value = input position; the filter's four counters
 // start at zero (this is its first kernel: no launch of a memset for 16 bytes)
 __global__ __launch_bounds__(kVBlock) void k_vox_keys(const char *recs, size_t stride, uint32_t n, float ivx, float ivy, float ivz,
-                                                      uint32_t *keys, uint32_t *vals, uint32_t *stats)
+                                                      uint32_t *keys, uint32_t *vals, uint32_t *stats, uint32_t *sort_scratch,
+                                                      uint32_t sort_scratch_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4) stats[i] = 0u;
+    if (sort_scratch) rsreg::radix32_clear(sort_scratch, sort_scratch_words, i, gridDim.x * blockDim.x);   // (the state of the sort that follows: radix32.hpp)
     if (i >= n) return;
     const VoxelOf v = voxel_of(recs + (size_t)i * stride, ivx, ivy, ivz);
     keys[i] = v.ok ? slot_of(v) : kHist;
@@ -326,14 +329,28 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     float *cent = b_cent.as<float>();
     uint32_t *stats = b_misc.as<uint32_t>() + 32;
     const uint32_t nb = div_up_u(N, kVBlock);
-    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, keys, vals, stats);
-    RSREG_HIP(ctx, hipGetLastError());
     size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
+    // the slot sort (10 bits, stable): two onesweep passes driven by this library, their state cleared by the keys kernel
+    // (radix32.hpp) -- rocPRIM's driver merge-sorts below 65 536 records (42 us for an edge cloud of 36 k against 25) and
+    // queues five memsets above
+    const bool own_sort = radix32_pays(n, 10);
+    const Radix32Plan plan = radix32_plan(n, 0, 10);
+    if (own_sort) sort_bytes = (size_t)plan.words * 4;
+    else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
     RSREG_HIP(ctx, b_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable (radix above 65 536 items: sort_cfg.hpp)
+    // (two passes end in the pair they started from: the keys are written where the sorted pairs belong)
+    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, own_sort ? skeys : keys, own_sort ? svals : vals, stats,
+                                       own_sort ? b_tmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
+    RSREG_HIP(ctx, hipGetLastError());
+    if (own_sort) {
+        bool in_first = false;
+        RSREG_HIP(ctx, radix32_sort_pairs(plan, b_tmp.as<uint32_t>(), skeys, keys, svals, vals, n, 0, 10, st, &in_first));
+        if (!in_first) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+    } else {
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable (radix above 65 536 items: sort_cfg.hpp)
+    }
     k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));

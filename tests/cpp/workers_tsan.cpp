@@ -1,0 +1,139 @@
+// workers_tsan.cpp — the helper threads of a context (csrc/workers.hpp: SourceWorker, TicketWorker, DownloadWorker) with stub
+// jobs, posted / waited for / shut down from several threads at once.  Built and run by tests/test_workers_cpu.py under
+// -fsanitize=thread and under -fsanitize=address,undefined on the CPU box: no GPU call in here.
+// They serve rsreg_icp_set_source* (the source load beside the index build, incremental_icp.hpp:57-58), the frame uploads and
+// side jobs of the scheme loops (types.hpp:30-43) and the streamed download of the merged cloud.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../realsense-pointcloud_amd/csrc/workers.hpp"
+
+using namespace rsreg;
+
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+static void spin(int us)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(us)) {}
+}
+
+// one job at a time; every post is followed by a wait somewhere: the status of the LAST job is what wait returns
+static void source_worker()
+{
+    SourceWorker w;
+    std::atomic<int> ran{0};
+    long long sum = 0;   // written by the jobs only (one at a time), read after the last wait
+    for (int k = 0; k < 200; ++k) {
+        w.post([&, k] { spin(k % 7); sum += k; ++ran; return k % 5 == 4 ? -3 : 0; });
+        if (k % 3 == 0) REQUIRE(w.wait() == (k % 5 == 4 ? -3 : 0));
+    }
+    (void)w.wait();
+    REQUIRE(ran == 200 && sum == 199 * 200 / 2);
+    // waiters on other threads while the poster keeps posting
+    std::atomic<bool> go{true};
+    std::vector<std::thread> waiters;
+    for (int t = 0; t < 3; ++t) waiters.emplace_back([&] { while (go) (void)w.wait(); });
+    for (int k = 0; k < 200; ++k) w.post([&] { ++ran; return 0; });
+    (void)w.wait();
+    go = false;
+    for (auto &t : waiters) t.join();
+    REQUIRE(ran == 400);
+    w.shutdown();
+    w.shutdown();   // (rsreg_ctx_destroy may call it twice)
+    SourceWorker never_used;
+    never_used.shutdown();
+}
+
+// many posters, tickets waited for in any order by any thread; the first error is reported once to a wait, peek leaves it
+static void ticket_worker()
+{
+    TicketWorker w;
+    std::atomic<int> ran{0};
+    std::vector<std::thread> posters;
+    std::vector<std::vector<uint64_t>> tickets(4);
+    for (int t = 0; t < 4; ++t)
+        posters.emplace_back([&, t] {
+            std::mt19937 rng(t);
+            for (int k = 0; k < 150; ++k) {
+                tickets[t].push_back(w.post([&, k] { spin(k % 5); ++ran; return 0; }));
+                if (rng() % 4 == 0) REQUIRE(w.wait(tickets[t][rng() % tickets[t].size()]) == 0);
+            }
+        });
+    for (auto &t : posters) t.join();
+    for (auto &v : tickets)
+        for (uint64_t k : v) REQUIRE(w.peek(k) == 0);
+    REQUIRE(ran == 600);
+    const uint64_t bad = w.post([] { return -7; });
+    const uint64_t after = w.post([] { return 0; });
+    REQUIRE(w.peek(after) == -7);    // a third party sees it ...
+    REQUIRE(w.peek(bad) == -7);
+    REQUIRE(w.wait(after) == -7);    // ... the poster's wait takes it
+    REQUIRE(w.wait(after) == 0);
+    // shutdown with jobs still queued: they all run first
+    for (int k = 0; k < 50; ++k) (void)w.post([&] { spin(20); ++ran; return 0; });
+    w.shutdown();
+    REQUIRE(ran == 650);
+    w.shutdown();
+}
+
+// three staging slots taken in turn; the copy-out of a job runs when its "event" has fired
+static void download_worker()
+{
+    DownloadWorker w;
+    std::atomic<int> ready_calls{0};
+    w.wait_ready = [&](const DownloadWorker::Job &j) -> int {
+        ++ready_calls;
+        spin(30);
+        return j.device == 99 ? 5 : 0;   // (device 99: the stub's "event wait failed")
+    };
+    const size_t small = 4096, big = (size_t)5 << 20;   // (the big ones are copied out by four threads)
+    std::vector<std::vector<char>> stage(3, std::vector<char>(big)), dst(12, std::vector<char>(big));
+    for (int k = 0; k < 12; ++k) {
+        const int slot = k % 3;
+        w.wait_slot(slot);   // (nobody copies out of this staging buffer any more)
+        const size_t bytes = k % 4 == 0 ? big : small;
+        for (size_t i = 0; i < bytes; i += 997) stage[slot][i] = (char)(k + 1);
+        w.post(DownloadWorker::Job{nullptr, stage[slot].data(), dst[k].data(), bytes, slot, 0});
+    }
+    REQUIRE(w.wait_idle() == 0);
+    for (int k = 0; k < 12; ++k) REQUIRE(dst[k][0] == (char)(k + 1));
+    REQUIRE(ready_calls == 12);
+    // a slot given back without a job (the error path of rsreg_cloud_download_async), from another thread
+    w.wait_slot(0);
+    std::thread giver([&] { spin(200); w.release_slot(0); });
+    w.wait_slot(0);
+    giver.join();
+    w.release_slot(0);
+    // a failed event wait: reported once by wait_idle, the slot is free again
+    w.wait_slot(1);
+    w.post(DownloadWorker::Job{nullptr, stage[1].data(), dst[0].data(), small, 1, 99});
+    REQUIRE(w.wait_idle() == 5);
+    REQUIRE(w.wait_idle() == 0);
+    w.wait_slot(1);
+    w.release_slot(1);
+    // waiters on several threads
+    std::vector<std::thread> th;
+    for (int t = 0; t < 3; ++t) th.emplace_back([&] { for (int k = 0; k < 20; ++k) (void)w.wait_idle(); });
+    for (int k = 0; k < 30; ++k) {
+        const int slot = k % 3;
+        w.wait_slot(slot);
+        w.post(DownloadWorker::Job{nullptr, stage[slot].data(), dst[k % 12].data(), small, slot, 0});
+    }
+    for (auto &t : th) t.join();
+    w.shutdown();
+    w.shutdown();
+}
+
+int main()
+{
+    source_worker();
+    ticket_worker();
+    download_worker();
+    std::puts("workers ok");
+    return 0;
+}

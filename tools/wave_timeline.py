@@ -48,6 +48,17 @@ for c in sorted(set(lgc.tolist())):
     d = (us1 - us0)[m]
     print("  waves of tiles searched by %d lane(s) per query: %6d, duration mean %.1f p50 %.1f p90 %.1f max %.1f us, started p50 %.1f max %.1f us" %
           (1 << c, m.sum(), d.mean(), np.percentile(d, 50), np.percentile(d, 90), d.max(), np.percentile(us0[m], 50), us0[m].max()))
+# what bench.py quotes (roofline_issue.tail_fraction, .vmem_frac_while_full): RSREG_WAVE_TIMELINE_JSON=<file>
+if os.environ.get("RSREG_WAVE_TIMELINE_JSON"):
+    import json
+    grid_t = np.linspace(0.0, us1.max(), 400)
+    resident = np.array([((us0 <= t) & (us1 > t)).sum() for t in grid_t])
+    full = grid_t[resident >= 0.9 * 8192]
+    json.dump({"size": str(size), "iterations": iters, "waves": int(len(raw)), "slots": 8192, "span_us": float(us1.max()),
+               "sum_wave_time_us": float((us1 - us0).sum()), "mean_wave_us": float((us1 - us0).mean()),
+               "full_until_us": float(full.max()) if len(full) else 0.0,
+               "source": "python tools/wave_timeline.py %s %d (RSREG_WAVE_TIMES_LIGHT: start / end stamp of every wave of the last launch)" % (size, iters)},
+              open(os.environ["RSREG_WAVE_TIMELINE_JSON"], "w"), indent=1)
 slots = len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist(), simd.tolist())))
 print("distinct (xcc, se, sh, cu, simd): %d; distinct (xcc,se,sh,cu): %d" %
       (slots, len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist())))))

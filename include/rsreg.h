@@ -396,9 +396,8 @@ typedef struct rsreg_grid_info {
                                  * target set for at most 64 source points is searched whole (IncrementalICP) */
     uint32_t n_source_distinct; /* distinct source points the iterations work on (0: no source) */
     uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
-    uint32_t n_updates;         /* how often the index has taken new points in since it was last built from scratch: a target
-                                 * cloud that grew by one concatenation (icp_edge_based_registration.hpp:119-120) is merged
-                                 * into the sorted run instead of being indexed again                                   */
+    uint32_t n_updates;         /* always 0 since round 4 (the index of a grown target cloud is built afresh: merging the
+                                 * new points into the old index, rounds 3-4, was bit-identical and did not pay)      */
     uint32_t reserved;
 } rsreg_grid_info;
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);

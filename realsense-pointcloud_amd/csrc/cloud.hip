@@ -37,17 +37,9 @@ struct rsreg_cloud {
     // which cloud this is and how often its records have been rewritten: an index built from (id, version) is still
     // good while both are unchanged (rsreg_icp_set_target_cloud)
     uint64_t id = 0, version = 0;
-    // how the records got here when the last rewrite was a concatenation with ONE of its inputs being this very cloud
-    // (target = refined + target, model += moved): the cloud as it was (id, base_version) plus grown_n new records at
-    // grown_lo.  An index built from the old cloud can take the new records in instead of being built again
-    // (rsreg_icp_set_target_cloud).  grown_version = the version this describes; any later rewrite invalidates it.
-    uint64_t base_version = 0, grown_version = 0;
-    size_t grown_lo = 0, grown_n = 0;
 };
 
 extern "C" int rsreg_icp_set_target_scan_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, double max_correspondence_distance);   // icp.hip
-extern "C" int rsreg_icp_update_target_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, size_t new_lo, size_t new_n, double max_correspondence_distance);   // icp.hip
-extern "C" void rsreg_icp_set_target_pad_(rsreg_ctx *ctx, double pad);   // icp.hip
 constexpr size_t kScanSourceLimit = 64;       // (= kScanMaxSource of icp_kernels.hpp) source points at most, and ...
 constexpr size_t kScanTargetFloor = 32768;    // ... target points at least, for the search without an index
 
@@ -699,8 +691,6 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     RSREG_HIP(ctx, settle(out));
     const size_t stride = a->n ? a->stride : b->stride, na = a->n, nb = b->n, total = na + nb;
     const int dense = a->is_dense && b->is_dense;
-    const uint64_t out_version_before = out->version;
-    const bool grows_a = out == a && a != b, grows_b = out == b && a != b;   // out += b  /  out = a + out
     if (out == a && out->buf.cap >= total * stride + 16) {
         if (nb) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.as<char>() + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
@@ -718,13 +708,6 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     }
     out->version++;
     out->n = total; out->stride = stride; out->width = (uint32_t)total; out->height = 1; out->is_dense = dense;
-    out->grown_version = 0;
-    if ((grows_a && nb) || (grows_b && na)) {
-        out->base_version = out_version_before;
-        out->grown_version = out->version;
-        out->grown_lo = grows_a ? na : 0;
-        out->grown_n = grows_a ? nb : na;
-    }
     return RSREG_OK;
 }
 
@@ -738,24 +721,11 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
     // source is set before the target in the reference; if it is not, or changes, rsreg_icp_begin builds the index.
     const bool few_queries = ctx->have_source && ctx->n_source > 0 && ctx->n_source <= kScanSourceLimit && c->n >= kScanTargetFloor &&
                              !std::getenv("RSREG_NO_SCAN");
-    // The cloud the index was built from, grown since by one concatenation (icp_edge_based_registration.hpp:119-120:
-    // *target = *icp_aligned + *target, then the next frame's setInputTarget): the new records are merged into the
-    // index instead of everything being sorted again.  Same matches as a build from scratch (icp.hip).
-    if (!few_queries && c->grown_version == c->version && c->grown_n && ctx->have_target && ctx->tgt_cloud_id == c->id &&
-        ctx->tgt_cloud_version == c->base_version) {
-        const int ru = rsreg_icp_update_target_(ctx, c->buf.ptr, c->n, c->stride, c->grown_lo, c->grown_n, max_correspondence_distance);
-        if (ru < 0) return ru;
-        if (ru == 0) {
-            ctx->tgt_cloud_id = c->id;
-            ctx->tgt_cloud_version = c->version;
-            return RSREG_OK;
-        }
-    }
-    // a cloud handle as the target may well grow (the schemes' targets all do): leave room around the grid's box
-    rsreg_icp_set_target_pad_(ctx, few_queries ? 0.0 : 0.08);
+    // (a cloud that has grown since its index was built -- icp_edge_based_registration.hpp:119-120: *target = *icp_aligned +
+    // *target, then the next frame's setInputTarget -- is indexed afresh: rounds 3-4 merged the new records into the index
+    // instead, bit for bit the same index, and it did not pay: profiles/r04_experiments/README.md)
     int rc = few_queries ? rsreg_icp_set_target_scan_(ctx, c->buf.ptr, c->n, c->stride, max_correspondence_distance)
                          : rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
-    rsreg_icp_set_target_pad_(ctx, 0.0);
     if (rc) return rc;
     ctx->tgt_cloud_id = c->id;
     ctx->tgt_cloud_version = c->version;

@@ -147,17 +147,90 @@ __device__ __forceinline__ void cc_union(int *label, int a, int b)
     }
 }
 
-// 8-neighbourhood components of the kept pixels: every pixel joins its W, NW, N and NE neighbours
-__global__ __launch_bounds__(kBlock) void k_edge_cc_merge(const float *mx, int w, int h, int *label)
+// 8-neighbourhood components of the kept pixels (the hysteresis of the Canny edges: a component with one pixel at or above
+// the high threshold is kept whole).  Every pixel joins its W, NW, N and NE neighbours -- in two steps: first inside tiles
+// of 32 x 32 pixels, in LDS (a union is a chain of dependent finds and an atomic minimum: a few hundred cycles each in LDS,
+// microseconds each in HBM -- one kernel doing all of them in HBM took 56 us for a 640 x 480 frame), then only the joins
+// that cross a tile's edge, one pixel in sixteen, on the labels in HBM.  A root is the smallest pixel index of its
+// component either way.
+constexpr int kCcTile = 32;
+
+__device__ __forceinline__ int cc_find_lds(const int *label, int i)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= w * h || mx[p] == 0.0f) return;
-    const int i = p / w, j = p - i * w;
-    if (j > 0 && mx[p - 1] != 0.0f) cc_union(label, p, p - 1);
+    int l = label[i];
+    while (l != i) {
+        i = l;
+        l = label[i];
+    }
+    return i;
+}
+
+__device__ __forceinline__ void cc_union_lds(int *label, int a, int b)
+{
+    bool done = false;
+    while (!done) {
+        a = cc_find_lds(label, a);
+        b = cc_find_lds(label, b);
+        if (a < b) {
+            const int old = atomicMin(&label[b], a);
+            done = old == b;
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&label[a], b);
+            done = old == a;
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+
+// one workgroup per tile, one pixel per thread; label[p] = the smallest pixel index of p's component inside its tile
+__global__ __launch_bounds__(kCcTile * kCcTile) void k_edge_cc_tiles(const float *mx, int w, int h, int tiles_x, int *label)
+{
+    __shared__ int lab[kCcTile * kCcTile];   // local index ly * 32 + lx: ordered like the pixel index inside the tile
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x0 = tx * kCcTile, y0 = ty * kCcTile;
+    const int t = threadIdx.x, lx = t % kCcTile, ly = t / kCcTile, x = x0 + lx, y = y0 + ly;
+    const bool kept = x < w && y < h && mx[y * w + x] != 0.0f;
+    lab[t] = kept ? t : -1;
+    __syncthreads();
+    if (kept) {   // (a kept pixel's entry only ever moves to a smaller kept index: never negative)
+        if (lx > 0 && lab[t - 1] >= 0) cc_union_lds(lab, t, t - 1);
+        if (ly > 0) {
+            if (lx > 0 && lab[t - kCcTile - 1] >= 0) cc_union_lds(lab, t, t - kCcTile - 1);
+            if (lab[t - kCcTile] >= 0) cc_union_lds(lab, t, t - kCcTile);
+            if (lx < kCcTile - 1 && lab[t - kCcTile + 1] >= 0) cc_union_lds(lab, t, t - kCcTile + 1);
+        }
+    }
+    __syncthreads();
+    if (kept) {
+        const int r = cc_find_lds(lab, t);
+        label[y * w + x] = (y0 + r / kCcTile) * w + x0 + r % kCcTile;
+    }
+}
+
+// The joins across tile edges: the pixels of a tile's first row, first column and last column (the NE neighbour of those
+// lies in the next tile) -- 94 of a tile's 1 024, one thread each.
+constexpr int kCcEdge = 3 * kCcTile - 2;
+__global__ __launch_bounds__(kBlock) void k_edge_cc_borders(const float *mx, int w, int h, int tiles_x, int n_tiles, int *label)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_tiles * kCcEdge) return;
+    const int tile = e / kCcEdge, k = e - tile * kCcEdge;
+    int lx, ly;
+    if (k < kCcTile) { lx = k; ly = 0; }                                              // first row
+    else if (k < 2 * kCcTile - 1) { lx = 0; ly = k - kCcTile + 1; }                   // first column, rows 1..31
+    else { lx = kCcTile - 1; ly = k - (2 * kCcTile - 1) + 1; }                        // last column, rows 1..31
+    const int j = (tile % tiles_x) * kCcTile + lx, i = (tile / tiles_x) * kCcTile + ly;
+    if (i >= h || j >= w) return;
+    const int p = i * w + j;
+    if (mx[p] == 0.0f) return;
+    if (lx == 0 && j > 0 && mx[p - 1] != 0.0f) cc_union(label, p, p - 1);
     if (i > 0) {
-        if (j > 0 && mx[p - w - 1] != 0.0f) cc_union(label, p, p - w - 1);
-        if (mx[p - w] != 0.0f) cc_union(label, p, p - w);
-        if (j < w - 1 && mx[p - w + 1] != 0.0f) cc_union(label, p, p - w + 1);
+        if ((lx == 0 || ly == 0) && j > 0 && mx[p - w - 1] != 0.0f) cc_union(label, p, p - w - 1);
+        if (ly == 0 && mx[p - w] != 0.0f) cc_union(label, p, p - w);
+        if ((lx == kCcTile - 1 || ly == 0) && j < w - 1 && mx[p - w + 1] != 0.0f) cc_union(label, p, p - w + 1);
     }
 }
 
@@ -246,8 +319,13 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     RSREG_HIP(ctx, hipGetLastError());
     k_edge_nms<<<nb, kBlock, 0, st>>>(mag, dir, w, h, t_low, mx, label, strong);
     RSREG_HIP(ctx, hipGetLastError());
-    k_edge_cc_merge<<<nb, kBlock, 0, st>>>(mx, w, h, label);
-    RSREG_HIP(ctx, hipGetLastError());
+    {
+        const int tiles_x = (w + kCcTile - 1) / kCcTile, tiles_y = (h + kCcTile - 1) / kCcTile;
+        k_edge_cc_tiles<<<(uint32_t)(tiles_x * tiles_y), kCcTile * kCcTile, 0, st>>>(mx, w, h, tiles_x, label);
+        RSREG_HIP(ctx, hipGetLastError());
+        k_edge_cc_borders<<<(uint32_t)((tiles_x * tiles_y * kCcEdge + kBlock - 1) / kBlock), kBlock, 0, st>>>(mx, w, h, tiles_x, tiles_x * tiles_y, label);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
     k_edge_cc_roots<<<nb, kBlock, 0, st>>>(mx, N, t_high, label, strong);
     RSREG_HIP(ctx, hipGetLastError());
     k_edge_flags<<<nb, kBlock, 0, st>>>(mx, label, strong, N, flag);

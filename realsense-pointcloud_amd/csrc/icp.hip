@@ -309,7 +309,6 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in the pinned buffer)
     gp.n_cells = h_misc[8];
     gp.n_points = h_misc[10];
-    gp.built_points = gp.n_points;
     gp.n_bricks = 0;
     rsreg_grid_info &gi = ctx->grid_info;
     for (int k = 0; k < 3; ++k) { gi.origin[k] = gp.origin[k]; gi.dims[k] = gp.dims[k]; }
@@ -325,121 +324,6 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     }
     ctx->have_target = true;
     return RSREG_OK;
-}
-
-// The index of a cloud that has grown by `new_n` records at [new_lo, new_lo + new_n) since the index was built (the
-// other records are the old cloud, in its order): the new points are sorted on their own and merged into the old run
-// (icp_dense.hpp).  Returns 1 when the update does not apply and the caller has to build from scratch: points outside
-// the grid's box, exact copies (a build drops them), a cloud that has doubled since the last build (the cells were
-// sized for that one), an index of another kind.  Matches, and therefore transforms, are those of a fresh build: the
-// search is exact whatever the geometry, and what is summed in which order depends on the source alone.
-template <typename KeyT>
-int update_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t stride, uint32_t new_lo, uint32_t new_n, double max_dist)
-{
-    hipStream_t st = ctx->stream;
-    GridParams &gp = ctx->grid;
-    const uint32_t n_old = gp.n_points, m = new_n;
-    const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
-    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
-    uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
-    RSREG_HIP(ctx, ctx->d_keys.reserve((size_t)m * sizeof(KeyT) + 16));
-    RSREG_HIP(ctx, ctx->d_keys_alt.reserve((size_t)m * sizeof(KeyT) + 16));
-    RSREG_HIP(ctx, ctx->d_vals.reserve((size_t)m * 4 + 16));
-    RSREG_HIP(ctx, ctx->d_vals_alt.reserve((size_t)m * 4 + 16));
-    RSREG_HIP(ctx, ctx->d_flags.reserve(((size_t)n_old + m) * sizeof(KeyT) + 16));          // keys of the merged run
-    RSREG_HIP(ctx, ctx->d_tgt_merge.reserve(((size_t)n_old + m + 8) * sizeof(float4)));
-    RSREG_HIP(ctx, ctx->d_pos_of.reserve((n_total + 1) * 4));   // (every kept point's entry is rewritten by the merge)
-    const DenseDev g = dense_dev(ctx, max_dist);
-    auto *keys = ctx->d_keys.as<KeyT>(), *keys2 = ctx->d_keys_alt.as<KeyT>(), *mkeys = ctx->d_flags.as<KeyT>();
-    auto *vals = ctx->d_vals.as<uint32_t>(), *vals2 = ctx->d_vals_alt.as<uint32_t>();
-    uint32_t *table = ctx->d_dense.as<uint32_t>();
-    const uint32_t xbits = (uint32_t)gp.xbits;
-    // counters: d_misc[16..19] = non-finite new points, new points outside the box, occupied cells, exact copies
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 16, 0, 34 * 4, st));   // stats at words 16-20, merge_finish's two counts at 48-49
-    k_dense_keys_new<KeyT><<<div_up(m, kBlock), kBlock, 0, st>>>(d_pts, stride, new_lo, m, g, xbits, keys, vals, d_misc + 16);
-    RSREG_HIP(ctx, hipGetLastError());
-    int id_bits = 1;
-    while ((1ull << id_bits) <= total) ++id_bits;
-    const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
-    size_t sort_bytes = 0;
-    using SortCfg = typename RadixCfgOf<KeyT>::type;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(sort_bytes + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, (size_t)m, 0, end_bit, st));
-    // exact copies among the new points go, as in a build; the kept pairs move back into keys / vals
-    RSREG_HIP(ctx, ctx->d_scan.reserve((size_t)m * 8 + 16));
-    uint32_t *keep = ctx->d_scan.as<uint32_t>(), *kpos = keep + m;
-    size_t scan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, kpos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st));
-    if (scan_bytes > ctx->d_tmp.cap) RSREG_HIP(ctx, ctx->d_tmp.reserve(scan_bytes + 256));
-    k_dense_new_flag<KeyT><<<div_up(m, kBlock), kBlock, 0, st>>>(keys2, vals2, d_pts, stride, m, keep);
-    RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, kpos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st));
-    k_dense_new_compact<KeyT><<<div_up(m, kBlock), kBlock, 0, st>>>(keys2, vals2, keep, kpos, m, keys, vals, d_misc + 16);
-    RSREG_HIP(ctx, hipGetLastError());
-    std::swap(keys, keys2);
-    std::swap(vals, vals2);
-    const int new_first = new_lo == 0 ? 1 : 0;
-    const uint32_t idx_shift = new_first ? m : 0u;
-    k_dense_merge<KeyT><<<div_up(n_old + m, kBlock), kBlock, 0, st>>>(ctx->d_tgt_sorted.as<float4>(), n_old, keys2, vals2, d_misc + 16, m, d_pts, stride, g,
-                                                                      xbits, idx_shift, new_first, ctx->d_tgt_merge.as<float4>(), mkeys,
-                                                                      ctx->d_pos_of.as<uint32_t>());
-    RSREG_HIP(ctx, hipGetLastError());
-    k_dense_merge_finish<KeyT><<<std::min(div_up(n_old + m, kBlock), kMergeFinishBlocks), kBlock, 0, st>>>(mkeys, ctx->d_tgt_merge.as<float4>(), d_misc + 16, n_old, m, xbits, new_lo, new_n,
-                                                                             g.sx, g.sxy, table, table + (total + 2), d_misc + 48);
-    RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, hipMemcpyAsync(h_misc + 20, d_misc + 16, 34 * 4, hipMemcpyDeviceToHost, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t outside = h_misc[21], copies = h_misc[20 + 33];
-    if (std::getenv("RSREG_INC_VERBOSE"))
-        std::fprintf(stderr, "[rsreg] index update: %u old + %u new points, %u outside the box, %u exact copies -> %s\n", n_old, m, outside, copies,
-                     outside || copies ? "build from scratch" : "merged");
-    if (outside || copies) return 1;   // (the old index is untouched except for table entries and occupancy bits a fresh build rewrites)
-    std::swap(ctx->d_tgt_sorted, ctx->d_tgt_merge);
-    gp.n_points = n_old + m - h_misc[20];
-    gp.n_cells = h_misc[20 + 32];
-    ctx->n_target_raw = n_total;
-    rsreg_grid_info &gi = ctx->grid_info;
-    gi.n_target_points = (uint32_t)(gi.n_target_points + m - h_misc[24]);
-    gi.n_unique_points = gp.n_points;
-    gi.n_cells = gp.n_cells;
-    gi.max_points_per_cell = 0;
-    gi.n_updates++;
-    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t) + (uint64_t)n_total * sizeof(uint32_t);
-    return RSREG_OK;
-}
-
-int update_dense_incremental(rsreg_ctx *ctx, const char *d_pts, size_t n_total, size_t stride, size_t new_lo, size_t new_n, double max_dist)
-{
-    static const bool off = std::getenv("RSREG_NO_INCREMENTAL") && std::getenv("RSREG_NO_INCREMENTAL")[0] == '1';
-    GridParams &gp = ctx->grid;
-    if (off || !ctx->have_target || gp.dense != 1 || !gp.table_sparse || gp.n_points == 0 || new_n == 0) return 1;
-    if (max_dist != ctx->gate_built_for || n_total != ctx->n_target_raw + new_n || (new_lo != 0 && new_lo != ctx->n_target_raw)) return 1;
-    if ((unsigned long long)gp.n_points + new_n + 4ull >= (1ull << 28) || n_total > 0xfffffff0ull) return 1;
-    if ((size_t)gp.n_points + new_n > 2 * (size_t)std::max(gp.built_points, 1u)) {   // cells sized for a cloud half as large: build again
-        if (std::getenv("RSREG_INC_VERBOSE")) std::fprintf(stderr, "[rsreg] index update: %u + %zu points, built for %u -> build from scratch\n", gp.n_points, new_n, gp.built_points);
-        return 1;
-    }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->profiling) {
-        ctx->ev_used = 0;
-        ev0 = take_event(ctx);
-        ev1 = take_event(ctx);
-        (void)hipEventRecord(ev0, ctx->stream);
-    }
-    const int rc = gp.xbits < 16 ? update_dense_keyed<uint32_t>(ctx, d_pts, n_total, stride, (uint32_t)new_lo, (uint32_t)new_n, max_dist)
-                                 : update_dense_keyed<unsigned long long>(ctx, d_pts, n_total, stride, (uint32_t)new_lo, (uint32_t)new_n, max_dist);
-    if (rc < 0) {   // a failure half-way: the table and the occupancy words are partly rewritten -- there is no index any more
-        ctx->have_target = false;
-        ctx->tgt_cloud_id = 0;
-    }
-    if (rc == RSREG_OK && ctx->profiling) {
-        (void)hipEventRecord(ev1, ctx->stream);
-        (void)hipEventSynchronize(ev1);
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ctx->grid_info.ms_build = ms;
-    }
-    return rc;
 }
 
 // Builds the grid from records already in HBM (d_pts/stride); keeps no pointer to them.
@@ -507,10 +391,8 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     gp.cell = (float)cell;
     gp.inv_cell = 1.0f / gp.cell;
     for (int k = 0; k < 3; ++k) {
-        // (a target that is going to grow gets a box with room around it: update_dense_incremental keeps the geometry)
-        const float pad = ctx->target_pad > 0 ? (float)(ctx->target_pad * ((double)mx[k] - (double)mn[k])) + 2.0f * gp.cell : 0.0f;
-        gp.origin[k] = mn[k] - pad;
-        gp.dims[k] = host_cell_coord(mx[k] + pad, gp.origin[k], gp.inv_cell) + 2;
+        gp.origin[k] = mn[k];
+        gp.dims[k] = host_cell_coord(mx[k], gp.origin[k], gp.inv_cell) + 2;
     }
     const int max_dim = std::max(gp.dims[0], std::max(gp.dims[1], gp.dims[2]));
     int max_ring = max_dim + 1;
@@ -1530,7 +1412,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         rsreg_ctx_destroy(ctx->recip);
         ctx->recip = nullptr;
     }
-    DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_tgt_merge, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
+    DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
@@ -1639,17 +1521,6 @@ int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     return build_grid(ctx, static_cast<const char *>(d_points), n, stride, max_correspondence_distance);
 }
-
-// (internal, cloud.hip) the target cloud has grown by new_n records at new_lo since its index was built: merge them in.
-// 0: done; 1: does not apply, build from scratch; < 0: error
-int rsreg_icp_update_target_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, size_t new_lo, size_t new_n, double max_correspondence_distance)
-{
-    if (hipSetDevice(ctx->device) != hipSuccess) return 1;
-    return update_dense_incremental(ctx, static_cast<const char *>(d_points), n, stride, new_lo, new_n, max_correspondence_distance);
-}
-
-// (internal, cloud.hip) the box of the next index build gets this much room on every side (fraction of its extent)
-void rsreg_icp_set_target_pad_(rsreg_ctx *ctx, double pad) { ctx->target_pad = pad; }
 
 // (internal, cloud.hip) a target for the handful of source points already loaded: no index, see scan_target
 int rsreg_icp_set_target_scan_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, double max_correspondence_distance)
@@ -1923,9 +1794,7 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
     static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
-    // (after an incremental update the cell starts of the last build from scratch no longer describe the index: the figure
-    // stays 0, "not known", until the next build)
-    if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0 && ctx->grid_info.n_updates == 0) {
+    if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
         const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);
         uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;
         uint32_t h = 0;

@@ -142,173 +142,6 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const KeyT *keys, cons
     }
 }
 
-// ---- incremental update of the index of a cloud that has GROWN (icp.hip: update_dense_incremental).
-// The edge-based schemes put every frame's refined edge points in front of the target they have just been aligned
-// with and hand the grown cloud to the next coarse ICP (icp_edge_based_registration.hpp:79,109,119-120), PCL builds a new
-// kd-tree of all of it each time.  Here the new points are sorted on their own and merged into the sorted run of the
-// old index: same geometry, same order (key, then original index), same records as a build from scratch would give.
-
-template <typename KeyT>
-__device__ __forceinline__ KeyT dense_key_of(const DenseDev &g, uint32_t xbits, float x, float y, float z)
-{
-    const int cx = min(max(cell_coord(x, g.ox, g.inv_cell), 0), g.nx - 1), cy = min(max(cell_coord(y, g.oy, g.inv_cell), 0), g.ny - 1),
-              cz = min(max(cell_coord(z, g.oz, g.inv_cell), 0), g.nz - 1);
-    const float fx = (cell_pos(x, g.ox, g.inv_cell) - (float)cx) * (float)(1u << xbits);
-    return ((KeyT)dense_cell_id(g, cx, cy, cz) << xbits) | (KeyT)min(max((int)fx, 0), (int)(1u << xbits) - 1);
-}
-
-// keys of the m new records [lo, lo + m) of the grown cloud; stats[4] += non-finite ones (they sort last, as in a build),
-// stats[1] += finite ones that lie outside the grid's box (then the geometry no longer fits: the caller builds afresh)
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_dense_keys_new(const char *pts, size_t stride, uint32_t lo, uint32_t m, DenseDev g, uint32_t xbits,
-                                                           KeyT *keys, uint32_t *vals, uint32_t *stats)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const float *p = rec_xyz(pts, stride, lo + i);
-    const float x = p[0], y = p[1], z = p[2];
-    KeyT key = (KeyT)~(KeyT)0;
-    if (finite3(x, y, z)) {
-        const int cx = cell_coord(x, g.ox, g.inv_cell), cy = cell_coord(y, g.oy, g.inv_cell), cz = cell_coord(z, g.oz, g.inv_cell);
-        if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || cz < 0 || cz >= g.nz) atomicAdd(&stats[1], 1u);
-        key = dense_key_of<KeyT>(g, xbits, x, y, z);
-    } else {
-        atomicAdd(&stats[4], 1u);   // (stats[0] itself is set by the compaction: everything of the new run that is not merged)
-    }
-    keys[i] = key;
-    vals[i] = lo + i;
-}
-
-// Exact copies among the sorted NEW points (the (0,0,0) pixels of a frame, once moved, all land on one point) are dropped
-// the way a build drops them -- a point equal to its predecessor of the same key goes -- before the merge:
-// keep[i] for the scan, then the kept (key, value) pairs move to the front; stats[0] becomes m - kept, i.e. everything
-// of the new run that does not take part in the merge (non-finite points and copies)
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_dense_new_flag(const KeyT *keys, const uint32_t *vals, const char *pts, size_t stride, uint32_t m,
-                                                           uint32_t *keep)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    uint32_t kp = keys[i] != (KeyT)~(KeyT)0 ? 1u : 0u;
-    if (kp && i > 0 && keys[i] == keys[i - 1]) {
-        const float *a = rec_xyz(pts, stride, vals[i]);
-        const float *b = rec_xyz(pts, stride, vals[i - 1]);
-        if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) kp = 0;
-    }
-    keep[i] = kp;
-}
-
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_dense_new_compact(const KeyT *keys, const uint32_t *vals, const uint32_t *keep, const uint32_t *pos, uint32_t m,
-                                                              KeyT *keys_out, uint32_t *vals_out, uint32_t *stats)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    if (keep[i]) {
-        keys_out[pos[i]] = keys[i];
-        vals_out[pos[i]] = vals[i];
-    }
-    if (i == m - 1) stats[0] = m - (pos[i] + keep[i]);
-}
-
-// One thread per element of either run: its place in the merged run = its place in its own run + the elements of the
-// other run that precede it (binary search; the keys of the old run are recomputed from its records).  Among equal
-// keys the lower original index goes first: the new points when they were put in front of the old cloud (new_first),
-// the old ones when the new points were appended.  Old records take their new original index (idx + idx_shift).
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_dense_merge(const float4 *old_sorted, uint32_t n_old, const KeyT *new_keys, const uint32_t *new_vals,
-                                                        const uint32_t *stats, uint32_t m, const char *pts, size_t stride, DenseDev g, uint32_t xbits,
-                                                        uint32_t idx_shift, int new_first, float4 *merged, KeyT *merged_keys, uint32_t *pos_of)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t m_fin = m - stats[0];
-    if (t < n_old) {
-        float4 rec = old_sorted[t];
-        const KeyT key = dense_key_of<KeyT>(g, xbits, rec.x, rec.y, tgt_z(rec));
-        uint32_t lo = 0, hi = m_fin;   // new elements with key < key (or <= key when the new ones go first)
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const KeyT k = new_keys[mid];
-            if (new_first ? k <= key : k < key) lo = mid + 1; else hi = mid;
-        }
-        const uint32_t pos = t + lo, idx = tgt_idx(rec) + idx_shift;
-        merged[pos] = tgt_rec(rec.x, rec.y, tgt_z(rec), idx);
-        merged_keys[pos] = key;
-        pos_of[idx] = pos;
-    } else if (t - n_old < m_fin) {
-        const uint32_t i = t - n_old;
-        const KeyT key = new_keys[i];
-        uint32_t lo = 0, hi = n_old;   // old elements with key <= key (or < key when the new ones go first)
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const float4 r = old_sorted[mid];
-            const KeyT k = dense_key_of<KeyT>(g, xbits, r.x, r.y, tgt_z(r));
-            if (new_first ? k < key : k <= key) lo = mid + 1; else hi = mid;
-        }
-        const uint32_t pos = i + lo, v = new_vals[i];
-        const float *p = rec_xyz(pts, stride, v);
-        merged[pos] = tgt_rec(p[0], p[1], p[2], v);
-        merged_keys[pos] = key;
-        pos_of[v] = pos;
-    }
-}
-
-// Over the merged run: the table entries of every cell (first point, and the end of the cell before: k_dense_scatter's
-// rule), the occupancy bits of cells that new points start, the far-away points behind the run, and two counts:
-// counts[0] = occupied cells, counts[1] = exact copies of a predecessor (the build would drop them: the caller builds
-// afresh when there is one).  `counts` lies in another cache line than stats_in: every thread reads stats_in[0].  [new_lo, new_lo + new_n): the original indices of the new points.
-// Launched with at most kMergeFinishBlocks workgroups, each walking its share of the run: the two counts go through the
-// workgroup's LDS and cost two atomics per WORKGROUP.  (One per wave on the same two words -- what the compiler's atomic
-// optimizer makes of a per-lane atomicAdd anyway -- was what this kernel took its 20-95 us for: 10^4 same-address atomics
-// at 3-5 ns each.  The scattered table stores and the occupancy bits are cheap beside that.)
-constexpr uint32_t kMergeFinishBlocks = 1024;
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_dense_merge_finish(const KeyT *keys, float4 *merged, const uint32_t *stats_in, uint32_t n_old, uint32_t m,
-                                                               uint32_t xbits, uint32_t new_lo, uint32_t new_n, int sx, int sxy, uint32_t *table,
-                                                               uint32_t *nbr, uint32_t *counts)
-{
-    __shared__ uint32_t sh_counts[2];
-    if (threadIdx.x < 2) sh_counts[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t total = n_old + m - stats_in[0];
-    uint32_t my_cells = 0, my_copies = 0;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
-        const KeyT k = keys[p];
-        const uint32_t slot = (uint32_t)(k >> xbits);
-        bool cstart = true;
-        if (p > 0) {
-            const KeyT kp = keys[p - 1];
-            cstart = (kp >> xbits) != (k >> xbits);
-            if (k == kp) {
-                const float4 a = merged[p], b = merged[p - 1];
-                if (a.x == b.x && a.y == b.y && tgt_z(a) == tgt_z(b)) ++my_copies;
-            }
-            // (the cell before ends here; when it is the neighbouring slot, the store below writes the same word)
-            if (cstart && (uint32_t)(kp >> xbits) + 1u != slot) table[(uint32_t)(kp >> xbits) + 1u] = p;
-        }
-        if (cstart) {
-            ++my_cells;
-            table[slot] = p;
-            const uint32_t idx = tgt_idx(merged[p]);
-            if (idx - new_lo < new_n) {   // (a cell whose first point is an old one was occupied before: its bits are set)
-#pragma unroll
-                for (int j = 0; j < 27; ++j) {
-                    const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
-                    atomicOr(&nbr[(int)slot - ((dz - 1) * sxy + (dy - 1) * sx + (dx - 1))], 1u << j);
-                }
-            }
-        }
-        if (p == total - 1) {
-            table[slot + 1u] = total;
-            for (uint32_t q = 0; q < 4; ++q) merged[total + q] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
-        }
-    }
-    if (my_cells) atomicAdd(&sh_counts[0], my_cells);
-    if (my_copies) atomicAdd(&sh_counts[1], my_copies);
-    __syncthreads();
-    if (threadIdx.x < 2 && sh_counts[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh_counts[threadIdx.x]);
-}
-
 // table[slot of occupied cell c] = its point count (the exclusive scan of the table then gives
 // the first point of EVERY cell, empty ones included); plain stores, no atomics
 __global__ __launch_bounds__(kBlock) void k_dense_counts(const uint32_t *cellslot, const uint32_t *cellpos, const uint32_t *stats,

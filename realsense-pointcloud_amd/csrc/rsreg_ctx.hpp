@@ -97,8 +97,6 @@ struct GridParams {
     int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos), 2: no index (scan_target)
     int xbits;             // dense: bits of the x position inside a cell in the sort key (16, or what a 32-bit key leaves)
     int table_sparse;      // dense: only the table entries of occupied cells (and the slot behind each) are valid
-    uint32_t built_points; // dense: points the index held after its last build from scratch (incremental updates keep the geometry
-                           // until the cloud has doubled)
 };
 
 struct BrickEntry {          // 32 B, one hash-table slot
@@ -142,9 +140,6 @@ struct rsreg_ctx {
     double gate_built_for = 0;
     rsreg::DevBuf d_tgt_raw;      // packed xyz of the caller's target (n x float3)
     rsreg::DevBuf d_tgt_sorted;   // float4 {x,y,z,bits(orig index)}, cell-sorted, de-duplicated
-    rsreg::DevBuf d_tgt_merge;    // where an incremental update writes the merged run (then swapped with d_tgt_sorted)
-    double target_pad = 0.0;      // next index build: the grid's box grows by this fraction of its extent on every side (cloud targets
-                                  // that are going to grow: rsreg_icp_set_target_cloud), so that an update seldom finds points outside it
     rsreg::DevBuf d_table;        // BrickEntry[table_mask+1]
     rsreg::DevBuf d_cellpos;      // uint32[n_cells+1]: first sorted point of each occupied cell
     rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell, followed by one uint32 per cell: occupancy of its 27-cell neighbourhood

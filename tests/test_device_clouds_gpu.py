@@ -408,13 +408,13 @@ def test_device_cloud_rewritten_in_place_is_loaded_again(api, rs, frames):
     assert L.rsreg_cloud_edge_features(other_ctx.h, organized.h, out.h) == lib.RSREG_ERR_INVALID_ARG
 
 
-def test_grown_target_takes_the_new_points_into_its_index(api, rs, frames, monkeypatch):
+def test_grown_target_is_indexed_as_it_is_now(api, rs, frames):
     """The edge-based schemes put every frame's refined points in FRONT of the target they were aligned with and set
     the grown cloud as the next target (icp_edge_based_registration.hpp:79,109,119-120); PCL builds a new kd-tree each
-    time.  A cloud handle that grew by one concatenation since its index was built has the new records merged into the
-    sorted run instead (rsreg_grid_info.n_updates counts them).  Matches and transforms must be those of an index built
-    from scratch on the same records -- whichever way the cloud grew, and when the update cannot apply (points outside
-    the box, exact copies, a cloud that has doubled) the build from scratch happens by itself."""
+    time.  A cloud handle that has grown -- in front, behind, by points outside the old box, by exact copies -- must be
+    searched as the cloud it is now: matches and transforms those of a fresh context given the same records on the host.
+    (Rounds 3-4 merged the new records into the old index instead; it was bit-identical and did not pay,
+    profiles/r04_experiments/README.md: the index is built afresh, rsreg_grid_info.n_updates stays 0.)"""
     ctx = api.Context(0)
     prm = dict(max_iterations=3, criteria_mode=1, max_correspondence_distance=0.05)
     src = frames[2]
@@ -440,16 +440,17 @@ def test_grown_target_takes_the_new_points_into_its_index(api, rs, frames, monke
     icp.setInputSource(api.DeviceCloud(src, ctx))
     icp.setInputTarget(tgt)
     icp.align()
-    assert icp.grid_info().n_updates == 0
     host = frames[0]
-    def valid(c):   # (the (0,0,0) pixels of a frame all land on one point when moved: exact copies, which an update leaves to a build)
+
+    def valid(c):
         pts = np.ascontiguousarray(c.points[np.isfinite(c.points["x"]) & (c.points["z"] != 0)])
         return rs.PointCloud(pts, width=len(pts), height=1, is_dense=False)
 
+    far = api.transformPointCloud(valid(frames[1].crop(0, 0, 100, 40)), rs.synth.small_transform(0.0, (7.0, 0.0, 0.0)).astype(np.float32))
     steps = [("front", api.transformPointCloud(valid(frames[1].crop(0, 0, 250, 60)), rs.synth.small_transform(0.3, (0.004, 0.0, -0.003)).astype(np.float32))),
              ("back", api.transformPointCloud(valid(frames[1].crop(0, 100, 250, 50)), rs.synth.small_transform(-0.2, (0.0, 0.002, 0.001)).astype(np.float32))),
-             ("front", api.transformPointCloud(valid(frames[2].crop(30, 20, 150, 90)), rs.synth.small_transform(0.1, (0.001, 0.001, 0.0)).astype(np.float32)))]
-    for n_done, (where, new) in enumerate(steps, 1):
+             ("front", far), ("front", frames[0].crop(10, 10, 50, 50)), ("back", frames[1])]
+    for where, new in steps:
         d_new = api.DeviceCloud(new, ctx)
         if where == "front":
             tgt.prepend(d_new)
@@ -461,34 +462,23 @@ def test_grown_target_takes_the_new_points_into_its_index(api, rs, frames, monke
         i1, d1 = search(icp)
         icp.align()
         g = icp.grid_info()
-        assert g.n_updates == n_done, (where, g.n_updates)
         i0, d0, t0, g0 = fresh(host)
         np.testing.assert_array_equal(i1, i0)
         np.testing.assert_array_equal(d1, d0)
         assert icp.getFinalTransformation().tobytes() == t0
-        assert (g.n_unique_points, g.n_target_points) == (g0.n_unique_points, g0.n_target_points)   # (the cells differ: the update keeps the old geometry)
-    # what the update cannot take: points outside the box of the index, exact copies, a cloud that has doubled
-    far = api.transformPointCloud(valid(frames[1].crop(0, 0, 100, 40)), rs.synth.small_transform(0.0, (7.0, 0.0, 0.0)).astype(np.float32))
-    for new in (far, frames[0].crop(10, 10, 50, 50), frames[1], frames[2] + frames[1]):
-        tgt.prepend(api.DeviceCloud(new, ctx))
-        host = new + host
-        icp.setInputTarget(tgt)
-        i1, d1 = search(icp)
-        icp.align()
-        assert icp.grid_info().n_updates == 0            # built from scratch
-        i0, d0, t0, g0 = fresh(host)
-        np.testing.assert_array_equal(i1, i0)
-        np.testing.assert_array_equal(d1, d0)
-        assert icp.getFinalTransformation().tobytes() == t0
-    # and with the updates switched off the same clouds give the same bits (the switch is read once per process: checked
-    # through a cloud that was rewritten some other way -- a transform in place -- which must never be taken for growth)
+        assert (g.n_unique_points, g.n_target_points, g.n_cells, g.n_updates) == (g0.n_unique_points, g0.n_target_points, g0.n_cells, 0)
+    # a cloud rewritten in place (a transform) is indexed again too
     tgt2 = api.DeviceCloud(frames[0], ctx)
     icp.setInputTarget(tgt2)
     icp.align()
-    api._l.check(api._l.lib().rsreg_cloud_transform(ctx.h, tgt2.h, np.ascontiguousarray(np.eye(4, dtype=np.float32)).ctypes.data, tgt2.h), ctx.h)
+    api._l.check(api._l.lib().rsreg_cloud_transform(ctx.h, tgt2.h, api._colmajor(rs.synth.small_transform(0.2, (0.01, 0.0, 0.0)).astype(np.float32)).ctypes.data,
+                                                    tgt2.h), ctx.h)
     icp.setInputTarget(tgt2)
-    icp.align()
-    assert icp.grid_info().n_updates == 0
+    i1, d1 = search(icp)
+    moved = api.transformPointCloud(frames[0], rs.synth.small_transform(0.2, (0.01, 0.0, 0.0)).astype(np.float32))
+    i0, d0, _, _ = fresh(moved)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
 
 
 def test_download_async_lands_what_the_stream_had_when_it_was_asked(api, rs, frames):

@@ -162,16 +162,34 @@ __global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *cell
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
-// nbr[n] |= bit(offset of c seen from n) for the 27 cells n around every occupied cell c
+// nbr[n] |= bit(offset of c seen from n) for the 27 cells n around every occupied cell c.
+// Bit j = dz * 9 + dy * 3 + dx of a cell's word: its neighbour at (dx - 1, dy - 1, dz - 1) holds points.  The occupied cells
+// come in slot order, so the occupied neighbours of c in its own row are the threads next to it, and the three x offsets
+// of one (y, z) offset are put together before they are OR-ed in: the word of a cell is written, per (y, z) offset, by
+// the thread of that cell if it is occupied, else by the thread of the occupied cell to its left, else by the one to
+// its right -- 9 atomics per occupied cell inside a run of occupied cells, 27 for a lone one (it was 27 for all:
+// 3.9 M atomic ORs, 27 us, for the 10^6-point target of the bench).
 __global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, const uint32_t *stats, int sx, int sxy, uint32_t *nbr)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= stats[0]) return;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nc = stats[0];
+    if (c >= nc) return;
     const int slot = (int)cellslot[c];
+    const int sl1 = c >= 1 ? (int)cellslot[c - 1] : -9, sl2 = c >= 2 ? (int)cellslot[c - 2] : -9;
+    const int sr1 = c + 1 < nc ? (int)cellslot[c + 1] : -9, sr2 = c + 2 < nc ? (int)cellslot[c + 2] : -9;
+    const bool L = sl1 == slot - 1, L2 = sl1 == slot - 2 || sl2 == slot - 2;    // cells slot - 1, slot - 2 hold points
+    const bool R = sr1 == slot + 1, R2 = sr1 == slot + 2 || sr2 == slot + 2;    // cells slot + 1, slot + 2
+    // bits of the three x offsets as seen from: the cell itself (its left neighbour, itself, its right neighbour), the empty
+    // cell to its right (its left neighbour = this cell, its right neighbour = slot + 2), the empty cell to its left
+    const uint32_t own = (L ? 1u : 0u) | 2u | (R ? 4u : 0u), right = 1u | (R2 ? 4u : 0u), left = 4u;
+    const bool owns_right = !R, owns_left = !L && !L2;
 #pragma unroll
-    for (int j = 0; j < 27; ++j) {
-        const int dz = j / 9, dy = (j / 3) % 3, dx = j % 3;
-        atomicOr(&nbr[slot - ((dz - 1) * sxy + (dy - 1) * sx + (dx - 1))], 1u << j);
+    for (int r = 0; r < 9; ++r) {
+        const int dz = r / 3, dy = r % 3;   // the (y, z) offset, as seen from the cell whose word is written
+        const int row = slot - ((dz - 1) * sxy + (dy - 1) * sx);
+        const int sh = dz * 9 + dy * 3;
+        atomicOr(&nbr[row], own << sh);
+        if (owns_right) atomicOr(&nbr[row + 1], right << sh);
+        if (owns_left) atomicOr(&nbr[row - 1], left << sh);
     }
 }
 

@@ -1,0 +1,51 @@
+#!/bin/bash
+# The round's committed measurements in one gpurun call (MI355X box): bench line, kernel statistics, PMC passes (HBM traffic,
+# SQ counters), step breakdown, reference mode, wave timeline, scheme times.  usage: tools/final_profiles.sh <tag, e.g. r04>
+# Everything lands under gpurun_out/<tag>_final/; copy what is to be judged into profiles/.
+TAG=${1:-r04}
+cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_final; mkdir -p $O
+export TMPDIR=/tmp
+step() { echo "[final_profiles] $1 ($(date +%T))"; }
+step bench
+timeout -k 10 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err || { tail -5 $O/bench_n1.err; exit 1; }
+cut -c1-600 $O/bench_n1.json
+step "kernel stats"
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1)
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench.csv
+step "traffic"
+(cd /tmp && timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1)
+(cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1)
+python tools/make_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json "round 4" > $O/traffic.log 2>&1; tail -2 $O/traffic.log
+step "SQ counters"
+: > $O/pmc_sq_counters.txt
+k=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64" \
+           "SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_IFETCH SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL"; do
+  k=$((k+1))
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc_sq$k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq$k.log 2>&1)
+  python tools/pmc_summary.py $O/pmc_sq$k rsreg >> $O/pmc_sq_counters.txt 2>&1
+done
+python tools/make_issue.py $O/pmc_sq_counters.txt profiles/r03_valu_issue_microbench.txt $O/issue.json > $O/issue.log 2>&1; tail -2 $O/issue.log
+step "launch times, wave timeline"
+for s in N1M N300 50k; do echo "== $s" >> $O/launch_times.txt; timeout -k 10 200 python tools/iter_times.py $s 30 2 2>&1 | grep -v amdgpu.ids | cut -c1-330 >> $O/launch_times.txt; done
+for s in 125k; do echo "== 125 k points (400 x 313)" >> $O/launch_times.txt; timeout -k 10 200 python tools/iter_times.py 400x313 30 2 2>&1 | grep -v amdgpu.ids | cut -c1-330 >> $O/launch_times.txt; done
+RSREG_WAVE_TIMELINE_JSON=$O/wave_timeline.json timeout -k 10 300 python tools/wave_timeline.py N1M 30 > $O/wave_timeline_n1m.txt 2>&1
+step "step breakdown, reference mode"
+for s in N1M N300 50k; do
+  timeout -k 10 200 python tools/step_breakdown.py $s 30 source-first 2>&1 | grep -v amdgpu.ids >> $O/step_breakdown.txt
+  timeout -k 10 200 python tools/ref_mode.py $s 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
+done
+timeout -k 10 200 python tools/small_align.py 300 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
+timeout -k 10 200 python tools/small_ndt.py 100 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
+cat $O/step_breakdown.txt $O/reference_mode.txt
+step "schemes"
+RSREG_SCHEME_REPS=3 timeout -k 10 900 bash tools/ab_schemes.sh $O/ab cur=realsense-pointcloud_amd > $O/cpp_scheme_times.txt 2>&1; cat $O/cpp_scheme_times.txt
+timeout -k 10 300 python tools/scheme_times.py N300 16 2>&1 | grep -v amdgpu.ids > $O/scheme_times.txt; tail -8 $O/scheme_times.txt
+step "other workloads"
+timeout -k 10 300 python bench.py --workload chain --steps 5 --warmup 1 > $O/bench_chain_n1.json 2> $O/bench_chain.err; cut -c1-300 $O/bench_chain_n1.json
+timeout -k 10 600 python tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; cut -c1-250 $O/bench_configs.jsonl
+step "clean up"
+rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq? $O/ab
+ls -la $O

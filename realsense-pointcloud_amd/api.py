@@ -214,9 +214,7 @@ class DeviceCloud:
         return self
 
     def prepend(self, other):
-        """`*self = *other + *self` in HBM (icp_edge_based_registration.hpp:119: the new points go FIRST).  The handle
-        remembers that it grew by len(other) records in front: an ICP index built from it before is updated, not rebuilt,
-        by the next setInputTarget (rsreg_icp_set_target_cloud)."""
+        """`*self = *other + *self` in HBM (icp_edge_based_registration.hpp:119: the new points go FIRST)."""
         _l.check(_l.lib().rsreg_cloud_concat(self.ctx.h, other.h, self.h, self.h), self.ctx.h)
         return self
 

@@ -421,6 +421,13 @@ def main():
                 out["roofline_issue"]["wave_timeline"] = {"slots": w["slots"], "span_us": w["span_us"], "sum_wave_time_us": w["sum_wave_time_us"],
                                                           "slots_full_until_us": w.get("full_until_us"), "waves": w.get("waves"),
                                                           "source": "profiles/%s (static)" % wj[-1]}
+                # the numbers that bind first, the VALU figure (an upper bound of the VALU time over the WHOLE launch: see
+                # valu_frac_while_full_upper_bound) under a name that says so
+                ri = out["roofline_issue"]
+                ri["valu_bound_over_launch_upper_bound"] = ri.pop("frac")
+                ri["bound"] = "vector memory issue while the wave slots are full, then an emptying tail (the VALU figure is an upper bound)"
+                lead = ("bound", "kernel", "vmem_frac_while_full", "tail_fraction", "avg_launch_us", "vmem_bound_us", "vmem_frac")
+                out["roofline_issue"] = {**{k: ri[k] for k in lead if k in ri}, **{k: v for k, v in ri.items() if k not in lead}}
             out["roofline"]["binding"] = "not HBM (the working set lives in the Infinity Cache): see roofline_issue (the contract's roofline stays the HBM one)"
     except Exception:  # noqa: BLE001
         pass

@@ -71,6 +71,39 @@ __global__ __launch_bounds__(kBlock) void k_records_transform(const char *in, ch
     if (set_w && stride >= 16) dst[3] = __float_as_uint(1.0f);
 }
 
+// The same for PointXYZRGB's own layout (32-byte records, 16-byte aligned: SURVEY.md App. A.0): two lanes per record, each
+// moving one 16-byte half with one load and one store -- a wave reads and writes 1 KiB runs instead of 64 words 32 bytes
+// apart, eight times over.  The lane of the first half transforms; the lane of the second half only copies (and has
+// nothing to do in place).
+__global__ __launch_bounds__(kBlock) void k_records_transform32(const uint4 *in, uint4 *out, uint32_t n_halves, Mat34 T, int set_w)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    if (h & 1u) {
+        if (out != in) out[h] = in[h];
+        return;
+    }
+    uint4 r = in[h];
+    const float x = __uint_as_float(r.x), y = __uint_as_float(r.y), z = __uint_as_float(r.z);
+    if (finite3(x, y, z)) {
+        const float3 t = xform(T, x, y, z);
+        r.x = __float_as_uint(t.x);
+        r.y = __float_as_uint(t.y);
+        r.z = __float_as_uint(t.z);
+    }
+    if (set_w) r.w = __float_as_uint(1.0f);
+    out[h] = r;
+}
+
+hipError_t launch_records_transform(hipStream_t st, const char *in, char *out, uint32_t n, size_t stride, const Mat34 &T, int set_w)
+{
+    if (stride == 32 && ((uintptr_t)in & 15u) == 0 && ((uintptr_t)out & 15u) == 0 && n < 0x7fffffffu)
+        k_records_transform32<<<div_up(2u * n, kBlock), kBlock, 0, st>>>(reinterpret_cast<const uint4 *>(in), reinterpret_cast<uint4 *>(out), 2u * n, T, set_w);
+    else
+        k_records_transform<<<div_up(n, kBlock), kBlock, 0, st>>>(in, out, n, stride, T, set_w);
+    return hipGetLastError();
+}
+
 // Whoever reads or rewrites a cloud first waits (on the host) for an upload of it that is still in flight: by then a
 // frame prefetched one step of the frame loop earlier has long arrived, and a host wait is right whatever stream the
 // reader works on.
@@ -598,9 +631,7 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
     Mat4f T;
     std::memcpy(T.m, transform, 64);
     if (in->n) {
-        k_records_transform<<<div_up((uint32_t)in->n, kBlock), kBlock, 0, ctx->stream>>>(in->buf.as<char>(), out->buf.as<char>(), (uint32_t)in->n,
-                                                                                        in->stride, to_mat34(T), 0);
-        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, launch_records_transform(ctx->stream, in->buf.as<char>(), out->buf.as<char>(), (uint32_t)in->n, in->stride, to_mat34(T), 0));
     }
     out->version++;
     out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
@@ -770,9 +801,7 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
     Mat4f T;
     std::memcpy(T.m, result->transform, 64);
     if (src->n) {
-        k_records_transform<<<div_up((uint32_t)src->n, kBlock), kBlock, 0, ctx->stream>>>(src->buf.as<char>(), aligned_out->buf.as<char>(),
-                                                                                         (uint32_t)src->n, src->stride, to_mat34(T), 1);
-        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, launch_records_transform(ctx->stream, src->buf.as<char>(), aligned_out->buf.as<char>(), (uint32_t)src->n, src->stride, to_mat34(T), 1));
     }
     aligned_out->version++;
     aligned_out->n = src->n; aligned_out->stride = src->stride; aligned_out->width = src->width; aligned_out->height = src->height;

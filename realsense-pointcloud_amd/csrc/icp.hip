@@ -565,7 +565,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             // and a kernel on the source stream can find itself behind a 0.4 ms voxel filter of a side stream
             hipStream_t st = ctx->stream;
             k_source_plain<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, ctx->d_src_all.as<float4>(), ctx->d_src.as<float4>(),
-                                                                           ctx->d_cur.as<float4>(), ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(),
+                                                                           ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(),
                                                                            ctx->d_first.as<uint32_t>(), d_misc + 12, h_misc + 32);
             RSREG_HIP(ctx, hipGetLastError());
             RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
@@ -656,10 +656,8 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         }
         RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
-                                               ctx->d_uniq_of.as<uint32_t>(), d_misc + 12, h_misc + 32);   // the number of distinct points: read at the join
-        RSREG_HIP(ctx, hipGetLastError());
-        k_source_weights<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), ctx->d_first.as<uint32_t>(), d_misc + 12,
-                                                ctx->d_src.as<float4>(), ctx->d_cur.as<float4>());
+                                               ctx->d_uniq_of.as<uint32_t>(), d_misc + 12, h_misc + 32,   // the number of distinct points: read at the join
+                                               ctx->d_src.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
     }
@@ -758,6 +756,22 @@ int *seed_ptr(rsreg_ctx *ctx)
 {
     static const bool off = std::getenv("RSREG_NO_SEED") && std::getenv("RSREG_NO_SEED")[0] == '1';
     return off ? nullptr : ctx->d_seed.as<int>();
+}
+
+// rsreg_icp_begin leaves "working copy = guess * source, no seeds" pending: the first search launch of the fused
+// pipelines over the dense index does it on its way (launch_fused); whatever else touches the working copy first runs
+// k_restart_source here.
+int ensure_restarted(rsreg_ctx *ctx)
+{
+    IcpState &s = ctx->icp;
+    if (!s.restart_pending) return RSREG_OK;
+    s.restart_pending = false;
+    const uint32_t n = (uint32_t)ctx->n_work;
+    if (!n) return RSREG_OK;
+    k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t), s.final_t.is_identity() ? 0 : 1,
+                                                                    ctx->d_cur.as<float4>(), ctx->d_seed.as<int>());   // (and: no seeds yet)
+    RSREG_HIP(ctx, hipGetLastError());
+    return RSREG_OK;
 }
 
 // diagnostic: per-wave start/end stamps of the last fused launch, dumped at rsreg_icp_end
@@ -861,6 +875,10 @@ int apply_filters(rsreg_ctx *ctx)
 int launch_search(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
+    {
+        int rcr = ensure_restarted(ctx);
+        if (rcr) return rcr;
+    }
     const uint32_t n = (uint32_t)ctx->n_work;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     if (n) {
@@ -918,6 +936,10 @@ int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 
 int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
+    {
+        int rcr = ensure_restarted(ctx);
+        if (rcr) return rcr;
+    }
     const uint32_t n = (uint32_t)ctx->n_work;
     {
         ScopedEvents ev(ctx, &ctx->ev_reduce);
@@ -1164,6 +1186,17 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     const uint32_t n = (uint32_t)ctx->n_work;
     const IcpDevState *dev = device_loop ? ctx->d_icp_state.as<IcpDevState>() : nullptr;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
+    // the first launch of an alignment over the dense index reads the source itself, applies the guess and starts without
+    // seeds: k_restart_source's work, one launch and a pass over the working copy saved (never with a schedule in
+    // place: that is built from a launch of this alignment)
+    static const bool restart_apart = std::getenv("RSREG_RESTART_APART") && std::getenv("RSREG_RESTART_APART")[0] == '1';
+    const bool restart_here = s.restart_pending && ctx->grid.dense && !s.sched_ready && !s.pending_transform && !restart_apart;
+    if (restart_here) {
+        s.restart_pending = false;
+    } else {
+        int rcr = ensure_restarted(ctx);
+        if (rcr) return rcr;
+    }
     {
         ScopedEvents ev(ctx, &ctx->ev_nn);
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
@@ -1194,7 +1227,8 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 }
             }
             kern<<<grid, kTile, 0, ctx->stream>>>(
-                ctx->d_cur.as<float4>(), n, to_mat34(s.t_inc), s.pending_transform ? 1 : 0,
+                ctx->d_cur.as<float4>(), restart_here ? ctx->d_src.as<float4>() : nullptr, n, to_mat34(restart_here ? s.final_t : s.t_inc),
+                restart_here ? (s.final_t.is_identity() ? 0 : 1) : (s.pending_transform ? 1 : 0),
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
                 ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev, sc);
             RSREG_HIP(ctx, hipGetLastError());
@@ -1279,6 +1313,10 @@ int run_device_loop(rsreg_ctx *ctx)
 int apply_pending_transform(rsreg_ctx *ctx)
 {
     IcpState &s = ctx->icp;
+    {
+        int rcr = ensure_restarted(ctx);
+        if (rcr) return rcr;
+    }
     if (!s.pending_transform) return RSREG_OK;
     const uint32_t n = (uint32_t)ctx->n_work;
     if (n) {
@@ -1601,13 +1639,7 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     ctx->ev_nn.clear();
     ctx->ev_reduce.clear();
     ctx->ev_transform.clear();
-    const uint32_t n = (uint32_t)ctx->n_work;
-    if (n) {
-        const int apply = s.final_t.is_identity() ? 0 : 1;
-        k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t),
-                                                                        apply, ctx->d_cur.as<float4>(), ctx->d_seed.as<int>());   // (and: no seeds yet)
-        RSREG_HIP(ctx, hipGetLastError());
-    }
+    s.restart_pending = true;   // input_transformed = guess * input (App. A.2 prologue): ensure_restarted / launch_fused
     return RSREG_OK;
 }
 

@@ -819,7 +819,7 @@ __device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsi
 // instantiation (RSREG_WAVE_TIMES) also writes clock stamps and step counts per wave (1), or only the start and
 // end stamp and the hardware slot of each wave, at the product kernel's own occupancy (2: RSREG_WAVE_TIMES_LIGHT=1).
 template <int kDiag, int kFar>
-__global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, uint32_t n, Mat34 T, int apply_t, DenseDev g,
+__global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, const float4 *restart, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev,
                                                            TileSched sched)
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
     if (item == 0xffffffffu) return;   // (a workgroup the schedule has nothing for)
     const uint32_t tile = item & 0xffffffu, lg = (item >> 28) & 3u;
     const uint32_t i = tile * kTile + threadIdx.x;
-    if (dev) {   // device-resident loop: the increment comes from the previous k_icp_solve
+    if (dev && !restart) {   // device-resident loop: the increment comes from the previous k_icp_solve
         T = dev->t_inc;
         apply_t = dev->apply;
     }
@@ -852,20 +852,24 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
             }
         }
     } else if (i < n) {
-        q = cur[i];
+        // restart (the first launch of an alignment): the query is the source point itself under the guess (T, apply_t: the
+        // host's), the working copy is written whatever the point, and there is no seed -- what k_restart_source did
+        q = restart ? restart[i] : cur[i];
         if (q.w != 0.0f) {
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
                 q = make_float4(t.x, t.y, t.z, q.w);
-                cur[i] = q;
             }
-            const int seed_in = seed ? seed[i] : -1;
+            if (apply_t || restart) cur[i] = q;
+            const int seed_in = (seed && !restart) ? seed[i] : -1;
             const Best b = nn_query_dense<kFull, kFar>(g, q.x, q.y, q.z, seed_in, &dg);
-            if (seed && b.pos != seed_in) seed[i] = b.pos;   // (most matches do not change once the clouds have settled)
+            if (seed && (restart || b.pos != seed_in)) seed[i] = b.pos;   // (most matches do not change once the clouds have settled)
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
                 d2 = b.d2;
             }
+        } else if (restart) {
+            cur[i] = q;
         }
         if (corr_pos) { corr_pos[i] = pos; corr_d2[i] = d2; }
     }

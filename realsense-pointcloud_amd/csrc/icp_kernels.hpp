@@ -393,16 +393,38 @@ __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_
     }
 }
 
-// pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id
+// pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id, and
+// src[u] = {xyz, weight = number of copies (0: invalid point)}.  The copies of a point are the run j .. e - 1 behind its
+// first record; nearly every run is one record long (the next record is kept too), and the end of a longer one -- the
+// (0,0,0) pixels of a RealSense frame, 10^5 of them -- is where pos stops being u + 1: a binary search by the run's first
+// thread, not a second launch over first[].  (The working copy `cur` is written by the alignment that reads it:
+// k_restart_source, or the first search launch itself.)
 __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all, uint32_t n, const uint32_t *keep,
                                                           const uint32_t *pos, uint32_t *first, uint32_t *uniq_of,
-                                                          uint32_t *count, uint32_t *host_count)
+                                                          uint32_t *count, uint32_t *host_count, float4 *src)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint32_t u = keep[j] ? pos[j] : pos[j] - 1;
+    const uint32_t kp = keep[j];
+    const uint32_t u = kp ? pos[j] : pos[j] - 1;
     uniq_of[j] = u;
-    if (keep[j]) first[u] = j;
+    if (kp) {
+        first[u] = j;
+        uint32_t e = j + 1;   // one past the run's last record
+        if (e < n && !keep[e]) {
+            // largest k in [j + 1, n - 1] with pos[k] == u + 1: the next kept record, or the last record of all
+            uint32_t lo = e, hi = n - 1;
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (pos[mid] == u + 1) lo = mid;
+                else hi = mid - 1;
+            }
+            e = (lo == n - 1 && !keep[n - 1]) ? n : lo;
+        }
+        float4 s = src_all[j];
+        s.w = s.w != 0.0f ? (float)(e - j) : 0.0f;
+        src[u] = s;
+    }
     if (j == n - 1) {
         count[0] = u + 1;
         host_count[0] = u + 1;   // (pinned host memory: read at the join, no copy queued)
@@ -410,25 +432,11 @@ __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all,
     }
 }
 
-// src[u] = {xyz, weight = number of copies (0: invalid point)}; cur = copy
-// (launched over all n source records: how many of them are distinct is only known on the device yet)
-__global__ __launch_bounds__(kBlock) void k_source_weights(const float4 *src_all, const uint32_t *first, const uint32_t *nu, float4 *src,
-                                                           float4 *cur)
-{
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= *nu) return;
-    const uint32_t j = first[u];
-    float4 s = src_all[j];
-    s.w = s.w != 0.0f ? (float)(first[u + 1] - j) : 0.0f;
-    src[u] = s;
-    cur[u] = s;
-}
-
 // The whole load of a SMALL source in the caller's order (no Morton order, no merging of exact copies: at <= 65 536 points
 // neither buys the search anything -- 50 k raw frame, 36 k edge cloud: the same 30.1 us and 13 us per launch either way,
 // profiles/r03_small_sources.txt -- and together they are 17 launches and a round trip to the host):
-// src_all[j] = src[j] = cur[j] = {xyz, 1 or 0 (non-finite)}, perm / uniq_of / first = identity, count = n.
-__global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t stride, uint32_t n, float4 *src_all, float4 *src, float4 *cur,
+// src_all[j] = src[j] = {xyz, 1 or 0 (non-finite)}, perm / uniq_of / first = identity, count = n.
+__global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t stride, uint32_t n, float4 *src_all, float4 *src,
                                                          uint32_t *perm, uint32_t *uniq_of, uint32_t *first, uint32_t *count, uint32_t *host_count)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,7 +446,6 @@ __global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t
     const float4 s = make_float4(x, y, z, finite3(x, y, z) ? 1.0f : 0.0f);
     src_all[j] = s;
     src[j] = s;
-    cur[j] = s;
     perm[j] = j;
     uniq_of[j] = j;
     first[j] = j;

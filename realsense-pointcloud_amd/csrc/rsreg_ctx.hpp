@@ -116,6 +116,7 @@ struct IcpState {
     double svd_v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // V of the previous Umeyama solve (warm start of the next)
     bool have_search = false;     // corr buffers hold the current iteration's search
     bool pending_transform = false;  // fused mode: t_inc not yet applied to d_cur
+    bool restart_pending = false;    // d_cur = guess * d_src (and "no seeds") not done yet: ensure_restarted / launch_fused
     double ms_nn = 0, ms_reduce = 0, ms_transform = 0;
     int n_nn_launches = 0;
     int fused_launches = 0;        // fused dense launches of this alignment so far

@@ -226,8 +226,10 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     const uint32_t xbits = (uint32_t)gp.xbits;
     // a table that is only read where an occupancy bit points is written by the scatter kernel, occupied cells only: no
     // clear, no scan of (nx+2)(ny+2)(nz+2) entries; the occupancy words behind it are OR-ed together and start from zero
-    if (gp.table_sparse) RSREG_HIP(ctx, hipMemsetAsync(table + (total + 2), 0, (total + 2) * 4, st));
-    else RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));
+    // (the occupancy words alone are cleared by the keys kernel on its way, unless that would be more than 64 words a thread)
+    const bool occ_on_the_way = gp.table_sparse && (total + 2) <= 64ull * div_up((uint32_t)n, kBlock) * kBlock;
+    if (!gp.table_sparse) RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));
+    else if (!occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(table + (total + 2), 0, (total + 2) * 4, st));
     const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
     size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
     using SortCfg = typename RadixCfgOf<KeyT>::type;
@@ -235,7 +237,12 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     // keys kernel instead of nine memsets (radix32.hpp); otherwise rocPRIM's own driver
     const bool own_sort = sizeof(KeyT) == 4 && radix32_pays(n, end_bit);
     const Radix32Plan plan = radix32_plan(n, 0, end_bit);
-    if (own_sort) sort_bytes = (size_t)plan.words * 4;
+    // ... and then flag, scan and scatter are one launch too (compact.hpp), its look-back words cleared with the sort's state
+    static const bool scan_apart = std::getenv("RSREG_SCAN_APART") && std::getenv("RSREG_SCAN_APART")[0] == '1';
+    const bool one_tail = own_sort && !scan_apart && nfin < 0x7fffffffu;
+    const CompactPlan cplan = compact_plan(nfin, plan.words);
+    const uint32_t scratch_words = one_tail ? cplan.end : plan.words;
+    if (own_sort) sort_bytes = (size_t)scratch_words * 4;
     else RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
@@ -244,7 +251,8 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     const bool start_in_out = own_sort && plan.places % 2 == 0;
     k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, start_in_out ? keys2 : keys,
                                                                        start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
-                                                                       own_sort ? plan.words : 0u);
+                                                                       own_sort ? scratch_words : 0u, occ_on_the_way ? table + (total + 2) : nullptr,
+                                                                       occ_on_the_way ? (uint32_t)(total + 2) : 0u);
     RSREG_HIP(ctx, hipGetLastError());
     if (own_sort) {
         if constexpr (sizeof(KeyT) == 4) {
@@ -257,13 +265,22 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
         RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
     }
     const uint32_t nbf = div_up(nfin, kBlock);
-    k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
-    RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
-    k_dense_scatter<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags, scan, ctx->d_tgt_sorted.as<float4>(),
-                                                  ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8,
-                                                  gp.table_sparse ? table : nullptr);
-    RSREG_HIP(ctx, hipGetLastError());
+    if (one_tail) {
+        uint32_t *scr = ctx->d_tmp.as<uint32_t>();
+        k_dense_compact<KeyT><<<cplan.blocks, kCompactBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, ctx->d_tgt_sorted.as<float4>(),
+                                                                      ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8,
+                                                                      gp.table_sparse ? table : nullptr,
+                                                                      reinterpret_cast<unsigned long long *>(scr + cplan.off_state), scr + cplan.off_ticket);
+        RSREG_HIP(ctx, hipGetLastError());
+    } else {
+        k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
+        RSREG_HIP(ctx, hipGetLastError());
+        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
+        k_dense_scatter<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags, scan, ctx->d_tgt_sorted.as<float4>(),
+                                                      ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8,
+                                                      gp.table_sparse ? table : nullptr);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
     if (!gp.table_sparse) {
         k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
         RSREG_HIP(ctx, hipGetLastError());
@@ -549,7 +566,8 @@ constexpr size_t kPlainSourceMax = 65536;
 bool source_is_small(size_t n)
 {
     static const bool sort_small = std::getenv("RSREG_SORT_SMALL") && std::getenv("RSREG_SORT_SMALL")[0] == '1';
-    return n <= kPlainSourceMax && !sort_small;
+    static const size_t plain_max = std::getenv("RSREG_PLAIN_SOURCE_MAX") ? (size_t)std::atoll(std::getenv("RSREG_PLAIN_SOURCE_MAX")) : kPlainSourceMax;
+    return n <= plain_max && !sort_small;
 }
 
 // The part of a source load that queues work on stream_src (after one round trip for the bounding box); runs on the

@@ -53,13 +53,17 @@ __device__ __forceinline__ uint32_t dense_cell_id(const DenseDev &g, int x, int 
 // by x, which lets a search stop inside a cell (dense_walk); non-finite points sort to the very end (all-ones key).
 // KeyT = uint32_t whenever cell id and x position fit 32 bits together (any room-scale cloud: 23 + 9 bits at 1 M
 // points): the radix sort then moves half the bytes in four passes instead of six.
-// (sort_scratch: the state of the radix sort that follows, cleared on the way -- radix32.hpp)
+// (sort_scratch: the state of the radix sort that follows, cleared on the way -- radix32.hpp; occ: the occupancy words
+// k_dense_nbr will OR together, cleared on the way too -- as a hipMemsetAsync they were two fill kernels and 8 us of
+// launch gaps at the head of every build)
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_dense_keys(const char *pts, size_t stride, uint32_t n, DenseDev g, uint32_t xbits,
-                                                       KeyT *keys, uint32_t *vals, uint32_t *sort_scratch, uint32_t sort_scratch_words)
+                                                       KeyT *keys, uint32_t *vals, uint32_t *sort_scratch, uint32_t sort_scratch_words,
+                                                       uint32_t *occ, uint32_t occ_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (sort_scratch) radix32_clear(sort_scratch, sort_scratch_words, i, gridDim.x * blockDim.x);
+    if (occ) radix32_clear(occ, occ_words, i, gridDim.x * blockDim.x);
     if (i >= n) return;
     const float *p = rec_xyz(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];
@@ -139,6 +143,93 @@ __global__ __launch_bounds__(kBlock) void k_dense_scatter(const KeyT *keys, cons
         if (table) table[slot + 1u] = nu;
         // far-away points behind the last sorted point: a 4-wide candidate read may run past it
         for (uint32_t k = 0; k < 4; ++k) sorted[nu + k] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
+    }
+}
+
+// k_dense_flag, the scan of the flags and k_dense_scatter in one launch (compact.hpp): a workgroup flags 4 096 sorted
+// records (4 per thread, in order), scans (keep | cstart << 32) in place, looks back for what lies in front of it, and
+// scatters exactly as k_dense_scatter does.  `state` / `ticket`: zero at the start (cleared by k_dense_keys on its way).
+template <typename KeyT>
+__global__ __launch_bounds__(kCompactBlock) void k_dense_compact(const KeyT *keys, const uint32_t *vals, const char *pts, size_t stride, uint32_t nfin,
+                                                                 uint32_t xbits, float4 *sorted, uint32_t *pos_of, uint32_t *cellslot, uint32_t *cellpos,
+                                                                 uint32_t *stats, uint32_t *host_stats, uint32_t *table, unsigned long long *state,
+                                                                 uint32_t *ticket)
+{
+    __shared__ uint32_t s_bid;
+    __shared__ unsigned long long s_wave[kCompactBlock / 64];
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const uint32_t i0 = (bid * kCompactBlock + threadIdx.x) * kCompactItems;
+    KeyT k[kCompactItems + 1];   // k[j + 1] = key of record i0 + j, k[0] = the one in front of them
+    uint32_t kp[kCompactItems], cs[kCompactItems], v[kCompactItems];
+    float px[kCompactItems], py[kCompactItems], pz[kCompactItems];
+    k[0] = i0 > 0 && i0 <= nfin ? keys[i0 - 1] : (KeyT)0;
+    // every load a record needs goes out before the scan (the gathers of the points are what takes long, and nothing
+    // behind the first store could be moved in front of it by the compiler)
+#pragma unroll
+    for (uint32_t j = 0; j < kCompactItems; ++j) {
+        const uint32_t i = i0 + j;
+        k[j + 1] = (KeyT)0;
+        v[j] = 0;
+        px[j] = py[j] = pz[j] = 0.0f;
+        if (i < nfin) {
+            k[j + 1] = keys[i];
+            v[j] = vals[i];
+            const float *p = rec_xyz(pts, stride, v[j]);
+            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+        }
+    }
+    unsigned long long mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kCompactItems; ++j) {
+        const uint32_t i = i0 + j;
+        kp[j] = cs[j] = 0;
+        if (i < nfin) {
+            kp[j] = cs[j] = 1;
+            if (i > 0) {
+                cs[j] = (k[j + 1] >> xbits) != (k[j] >> xbits);
+                if (k[j + 1] == k[j]) {
+                    const float *b = rec_xyz(pts, stride, j > 0 ? v[j - 1] : vals[i - 1]);
+                    if (px[j] == b[0] && py[j] == b[1] && pz[j] == b[2]) kp[j] = 0;
+                }
+            }
+            mine += (unsigned long long)kp[j] | (unsigned long long)cs[j] << 32;
+        }
+    }
+    unsigned long long total;
+    unsigned long long run = compact_block_scan(mine, s_wave, total);
+    run += compact_lookback(state, bid, total, &s_excl);
+#pragma unroll
+    for (uint32_t j = 0; j < kCompactItems; ++j) {
+        const uint32_t i = i0 + j;
+        if (i >= nfin) break;
+        const uint32_t pos = (uint32_t)run, cid = (uint32_t)(run >> 32);
+        const uint32_t slot = (uint32_t)(k[j + 1] >> xbits);
+        if (kp[j]) {
+            sorted[pos] = tgt_rec(px[j], py[j], pz[j], v[j]);
+            pos_of[v[j]] = pos;
+        }
+        if (cs[j]) {
+            cellslot[cid] = slot;
+            cellpos[cid] = pos;
+            if (table) {
+                table[slot] = pos;
+                if (i > 0) table[(uint32_t)(k[j] >> xbits) + 1u] = pos;   // (the same value when the two slots coincide)
+            }
+        }
+        if (i == nfin - 1) {
+            const uint32_t nu = pos + kp[j], nc = cid + cs[j];
+            stats[0] = nc;
+            stats[2] = nu;
+            host_stats[0] = nc;   // (pinned host memory: what the host reads when the build has drained, no copy queued)
+            host_stats[2] = nu;
+            cellpos[nc] = nu;   // sentinel
+            if (table) table[slot + 1u] = nu;
+            for (uint32_t q = 0; q < 4; ++q) sorted[nu + q] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
+        }
+        run += (unsigned long long)kp[j] | (unsigned long long)cs[j] << 32;
     }
 }
 

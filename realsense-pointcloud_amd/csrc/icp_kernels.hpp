@@ -28,6 +28,7 @@
 #include "rsreg_ctx.hpp"
 #include "records.hpp"
 #include "radix32.hpp"
+#include "compact.hpp"
 
 namespace rsreg {
 

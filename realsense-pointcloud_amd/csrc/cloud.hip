@@ -37,6 +37,10 @@ struct rsreg_cloud {
     // which cloud this is and how often its records have been rewritten: an index built from (id, version) is still
     // good while both are unchanged (rsreg_icp_set_target_cloud)
     uint64_t id = 0, version = 0;
+    // bounding box and finite count of the records of version `box_version`, once an index build or a source load has
+    // measured them (rsreg_ctx.hpp: CloudBox): the frame that was a pair's source is the next pair's target
+    mutable rsreg::CloudBox box;
+    mutable uint64_t box_version = ~0ull;
 };
 
 extern "C" int rsreg_icp_set_target_scan_(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, double max_correspondence_distance);   // icp.hip
@@ -742,11 +746,25 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     return RSREG_OK;
 }
 
+// The source load that has been joined since left the box of the source cloud it read in the context: the handle keeps it
+// (if it is still that cloud, unchanged).
+static void harvest_source_box(rsreg_ctx *ctx)
+{
+    const rsreg_cloud *s = ctx->src_cloud;
+    if (!s || ctx->src_pending || !ctx->last_src_box.valid) return;
+    if (s->id == ctx->src_cloud_id && s->version == ctx->src_cloud_version) {
+        s->box = ctx->last_src_box;
+        s->box_version = s->version;
+    }
+    ctx->last_src_box.valid = false;
+}
+
 // ---- ICP on cloud handles (the handles must stay alive and unchanged until the align has returned)
 int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_correspondence_distance)
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
+    harvest_source_box(ctx);
     // IncrementalICP aligns the ten or twenty points a 1 m voxel filter leaves of a frame against the whole merged model
     // (incremental_icp.hpp:54-59): for so few queries the index is not worth building (icp.hip: scan_target).  The
     // source is set before the target in the reference; if it is not, or changes, rsreg_icp_begin builds the index.
@@ -755,9 +773,16 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
     // (a cloud that has grown since its index was built -- icp_edge_based_registration.hpp:119-120: *target = *icp_aligned +
     // *target, then the next frame's setInputTarget -- is indexed afresh: rounds 3-4 merged the new records into the index
     // instead, bit for bit the same index, and it did not pay: profiles/r04_experiments/README.md)
+    ctx->next_tgt_box.valid = false;
+    if (!few_queries && c->box.valid && c->box_version == c->version) ctx->next_tgt_box = c->box;
     int rc = few_queries ? rsreg_icp_set_target_scan_(ctx, c->buf.ptr, c->n, c->stride, max_correspondence_distance)
                          : rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
+    ctx->next_tgt_box.valid = false;
     if (rc) return rc;
+    if (!few_queries && ctx->last_tgt_box.valid) {
+        c->box = ctx->last_tgt_box;
+        c->box_version = c->version;
+    }
     ctx->tgt_cloud_id = c->id;
     ctx->tgt_cloud_version = c->version;
     return RSREG_OK;
@@ -776,8 +801,14 @@ int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
+    harvest_source_box(ctx);   // (of the load before this one, if an alignment has joined it)
+    ctx->next_src_box.valid = false;
+    if (c->box.valid && c->box_version == c->version) ctx->next_src_box = c->box;
     int rc = rsreg_icp_set_source_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense);
-    if (rc) return rc;
+    if (rc) {
+        ctx->next_src_box.valid = false;
+        return rc;
+    }
     ctx->src_cloud = c;
     ctx->src_cloud_id = c->id;
     ctx->src_cloud_version = c->version;

@@ -364,8 +364,24 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     }
     float mn[3], mx[3];
     uint32_t nfin = 0;
-    int rc = device_bbox(ctx, d_pts, n, stride, mn, mx, &nfin);
-    if (rc) return rc;
+    const rsreg::CloudBox known = ctx->next_tgt_box;   // (of the cloud handle this target comes from, if it has been measured before)
+    ctx->next_tgt_box.valid = false;
+    ctx->last_tgt_box.valid = false;
+    static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
+    if (known.valid && !no_box_cache && n > 0) {
+        RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
+        RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
+        RSREG_HIP(ctx, ctx->d_comm.reserve(1024 * 8 * sizeof(uint32_t) + 64 * sizeof(double)));
+        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_misc.ptr, 0, 16 * sizeof(uint32_t), st));   // (the counters k_bbox_final would have cleared)
+        for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }
+        nfin = known.nfin;
+    } else {
+        int rc = device_bbox(ctx, d_pts, n, stride, mn, mx, &nfin);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < 3; ++k) { ctx->last_tgt_box.mn[k] = mn[k]; ctx->last_tgt_box.mx[k] = mx[k]; }
+    ctx->last_tgt_box.nfin = nfin;
+    ctx->last_tgt_box.valid = n > 0;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
     const size_t misc_bytes = 16 * sizeof(uint32_t);
@@ -508,6 +524,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
             const double ms_first = gi.ms_build;
             const double r = std::max(0.2, std::sqrt(8.0 / per_cell));
             const float cell_before = gp.cell;
+            ctx->next_tgt_box = ctx->last_tgt_box;   // (the same records: no second measurement)
             int rc2 = build_grid(ctx, d_pts, n, stride, max_dist, r);
             if (rc2) return rc2;
             ctx->grid_info.ms_build += ms_first;
@@ -593,8 +610,20 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         float mn[3], mx[3];
         uint32_t nfin = 0;
-        int rc = device_bbox_on(ctx, st, d_misc, h_misc, d_misc + 64, d_raw, n, stride, mn, mx, &nfin);
-        if (rc) return rc;
+        const rsreg::CloudBox known = ctx->next_src_box;
+        ctx->next_src_box.valid = false;
+        static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
+        if (known.valid && !no_box_cache) {
+            RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0, 16 * sizeof(uint32_t), st));   // (the counters k_bbox_final would have cleared)
+            for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }
+            nfin = known.nfin;
+        } else {
+            int rc = device_bbox_on(ctx, st, d_misc, h_misc, d_misc + 64, d_raw, n, stride, mn, mx, &nfin);
+            if (rc) return rc;
+        }
+        for (int k = 0; k < 3; ++k) { ctx->last_src_box.mn[k] = mn[k]; ctx->last_src_box.mx[k] = mx[k]; }
+        ctx->last_src_box.nfin = nfin;
+        ctx->last_src_box.valid = true;
         if (nfin == 0) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
         double extent = 0;
         for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)mx[k] - (double)mn[k]);
@@ -694,6 +723,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     if (n > 0xfffffff0ull) return fail(ctx, RSREG_ERR_INVALID_ARG, "source too large");
     int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
     if (rcj) return rcj;
+    ctx->last_src_box.valid = false;   // (of the load before this one: cloud.hip has taken it over by now)
     if (!ctx->stream_src) {
         RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
         RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));

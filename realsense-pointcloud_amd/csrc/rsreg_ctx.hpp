@@ -83,6 +83,15 @@ struct PinnedBuf {
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// Bounding box and number of the finite points of a cloud: what an index build or a source load starts from (one kernel
+// pair and a round trip to the host).  A cloud handle keeps the box of its records as they are (cloud.hip: version), so a
+// frame that was the source of one pair and is the target of the next is not measured twice.
+struct CloudBox {
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    uint32_t nfin = 0;
+    bool valid = false;
+};
+
 // Uniform-grid index over the target cloud, all device-resident (layout: DESIGN.md §3).
 struct GridParams {
     float origin[3];
@@ -184,6 +193,9 @@ struct rsreg_ctx {
     rsreg::DevBuf d_recip_pts;    // float4 per ORIGINAL source point: the current source in the caller's order
     rsreg_ctx *recip = nullptr;   // child context holding the index over the current source (reciprocal search)
     rsreg::PinnedBuf h_sums;      // pinned double[64]
+    // next_*: the box of the cloud about to be set, when its handle knows it (consumed by build_grid / load_source_queue);
+    // last_*: what the last index build / source load started from (valid: computed or taken over)
+    rsreg::CloudBox next_tgt_box, last_tgt_box, next_src_box, last_src_box;
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     rsreg::IcpState icp;
 

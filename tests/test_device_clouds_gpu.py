@@ -665,3 +665,40 @@ def test_contexts_and_clouds_go_away_with_work_of_their_helper_threads_in_flight
                 np.testing.assert_array_equal(out["rgba"][lo:lo + len(f)], f.points["rgba"])
     ctx = api.Context(0)
     _same_records(api.DeviceCloud(frames[0], ctx).download(), frames[0])
+
+
+def test_a_clouds_bounding_box_is_measured_once_per_version(api, rs):
+    """A frame that was one pair's source is the next pair's target: its handle keeps the bounding box and the finite
+    count the source load measured, and the index build starts from them instead of measuring again (one kernel pair and a
+    round trip to the host less) -- for exactly the records that were measured: a handle rewritten since is measured anew."""
+    from rsreg_amd import lib
+    f = [rs.synth.render_frame(k, "N300", "parity") for k in range(3)]      # (> 65 536 points: the source load that sorts, and measures)
+    f[1].points["y"][5] = np.inf
+    prm = dict(max_iterations=2, criteria_mode=1, max_correspondence_distance=0.05)
+
+    def pair(ctx, s, t):
+        icp = api.IterativeClosestPoint(ctx)
+        icp.params = api.icp_params(**prm)
+        icp.setInputSource(s)
+        icp.setInputTarget(t)
+        icp.align()
+        gi = icp.grid_info()
+        return (icp.getFinalTransformation().tobytes(), tuple(gi.origin), tuple(gi.dims), gi.n_cells, gi.n_unique_points, gi.n_target_points,
+                icp.result.n_correspondences)
+
+    def fresh(s, t):
+        c = api.Context(0)
+        return pair(c, api.DeviceCloud(s, c), api.DeviceCloud(t, c))
+
+    ctx = api.Context(0)
+    dev = [api.DeviceCloud(x, ctx) for x in f]
+    pair(ctx, dev[1], dev[0])                                # frame 1 is measured as a source ...
+    assert pair(ctx, dev[2], dev[1]) == fresh(f[2], f[1])    # ... and indexed as a target from what its handle kept
+    assert pair(ctx, dev[2], dev[1]) == fresh(f[2], f[1])    # (both boxes kept now)
+    moved = api.transformPointCloud(f[0], rs.synth.small_transform(0.0, (0.5, -0.25, 0.125)).astype(np.float32))
+    dev[1].upload(moved)                                     # other records under the same handle: another box
+    assert pair(ctx, dev[2], dev[1]) == fresh(f[2], moved)
+    T = rs.synth.small_transform(0.0, (0.0, 1.0, 0.0)).astype(np.float32)
+    lib.check(lib.lib().rsreg_cloud_transform(ctx.h, dev[2].h, np.ascontiguousarray(T.T).ctypes.data, dev[2].h), ctx.h)   # the source moved in place
+    assert pair(ctx, dev[2], dev[1]) == fresh(api.transformPointCloud(f[2], T), moved)
+    assert pair(ctx, dev[1], dev[2]) == fresh(moved, api.transformPointCloud(f[2], T))   # and the two the other way round

@@ -19,6 +19,8 @@ import rsreg_amd  # noqa: E402,F401
 from rsreg_amd import api, synth  # noqa: E402
 
 size = sys.argv[1] if len(sys.argv) > 1 else "N1M"
+if "x" in size:
+    size = tuple(int(v) for v in size.split("x"))   # WxH
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 tgt, src = synth.render_frame(0, size, "bench"), synth.render_frame(1, size, "bench")
 guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)

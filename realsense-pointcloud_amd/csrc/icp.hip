@@ -372,7 +372,6 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
         RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
         RSREG_HIP(ctx, ctx->d_comm.reserve(1024 * 8 * sizeof(uint32_t) + 64 * sizeof(double)));
-        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_misc.ptr, 0, 16 * sizeof(uint32_t), st));   // (the counters k_bbox_final would have cleared)
         for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }
         nfin = known.nfin;
     } else {
@@ -441,6 +440,8 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     }
 
     // ---- sort by (brick, cell in brick, xyz hash)
+    // (the brick path counts with atomics in the words k_bbox_final clears; the dense table's kernels only store there)
+    if (known.valid && !no_box_cache && n > 0) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_misc.ptr, 0, 16 * sizeof(uint32_t), st));
     RSREG_HIP(ctx, ctx->d_keys.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_keys_alt.reserve(n * 8));
     RSREG_HIP(ctx, ctx->d_vals.reserve(n * 4));
@@ -613,8 +614,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         const rsreg::CloudBox known = ctx->next_src_box;
         ctx->next_src_box.valid = false;
         static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
-        if (known.valid && !no_box_cache) {
-            RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0, 16 * sizeof(uint32_t), st));   // (the counters k_bbox_final would have cleared)
+        if (known.valid && !no_box_cache) {   // (nothing of the load counts in the words k_bbox_final clears: the kernels below only store there)
             for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }
             nfin = known.nfin;
         } else {

@@ -850,7 +850,7 @@ int ensure_restarted(rsreg_ctx *ctx)
     s.restart_pending = false;
     const uint32_t n = (uint32_t)ctx->n_work;
     if (!n) return RSREG_OK;
-    k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), n, to_mat34(s.final_t), s.final_t.is_identity() ? 0 : 1,
+    k_restart_source<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src.as<float4>(), ctx->d_first.as<uint32_t>(), n, to_mat34(s.final_t), s.final_t.is_identity() ? 0 : 1,
                                                                     ctx->d_cur.as<float4>(), ctx->d_seed.as<int>());   // (and: no seeds yet)
     RSREG_HIP(ctx, hipGetLastError());
     return RSREG_OK;
@@ -1309,7 +1309,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 }
             }
             kern<<<grid, kTile, 0, ctx->stream>>>(
-                ctx->d_cur.as<float4>(), restart_here ? ctx->d_src.as<float4>() : nullptr, n, to_mat34(restart_here ? s.final_t : s.t_inc),
+                ctx->d_cur.as<float4>(), restart_here ? ctx->d_src.as<float4>() : nullptr, ctx->d_first.as<uint32_t>(), n, to_mat34(restart_here ? s.final_t : s.t_inc),
                 restart_here ? (s.final_t.is_identity() ? 0 : 1) : (s.pending_transform ? 1 : 0),
                 dense_dev(ctx, s.prm.max_correspondence_distance), gate2, want_corr ? ctx->d_corr_pos.as<int>() : nullptr,
                 ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev, sc);

@@ -910,7 +910,7 @@ __device__ __forceinline__ void light_stamp(unsigned long long *wave_times, unsi
 // instantiation (RSREG_WAVE_TIMES) also writes clock stamps and step counts per wave (1), or only the start and
 // end stamp and the hardware slot of each wave, at the product kernel's own occupancy (2: RSREG_WAVE_TIMES_LIGHT=1).
 template <int kDiag, int kFar>
-__global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, const float4 *restart, uint32_t n, Mat34 T, int apply_t, DenseDev g,
+__global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(float4 *cur, const float4 *restart, const uint32_t *first, uint32_t n, Mat34 T, int apply_t, DenseDev g,
                                                            double gate2, int *corr_pos, float *corr_d2, double *partials,
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev,
                                                            TileSched sched)
@@ -947,6 +947,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
         // host's), the working copy is written whatever the point, and there is no seed -- what k_restart_source did
         q = restart ? restart[i] : cur[i];
         if (q.w != 0.0f) {
+            if (restart) q.w = source_weight(first, i);   // (how many records of the caller's cloud this distinct point stands for)
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
                 q = make_float4(t.x, t.y, t.z, q.w);

@@ -395,11 +395,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_source(const char *raw, size_
 }
 
 // pos = exclusive scan of keep: first[u] = sorted index of unique point u, uniq_of[j] = its id, and
-// src[u] = {xyz, weight = number of copies (0: invalid point)}.  The copies of a point are the run j .. e - 1 behind its
-// first record; nearly every run is one record long (the next record is kept too), and the end of a longer one -- the
-// (0,0,0) pixels of a RealSense frame, 10^5 of them -- is where pos stops being u + 1: a binary search by the run's first
-// thread, not a second launch over first[].  (The working copy `cur` is written by the alignment that reads it:
-// k_restart_source, or the first search launch itself.)
+// src[u] = {xyz, 1 (0: invalid point)}.  How many copies a point stands for -- its weight in the 17 sums -- is
+// first[u + 1] - first[u]: whoever starts an alignment from src (k_restart_source, or the first search launch itself)
+// puts it into the working copy, no launch over first[] here.
 __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all, uint32_t n, const uint32_t *keep,
                                                           const uint32_t *pos, uint32_t *first, uint32_t *uniq_of,
                                                           uint32_t *count, uint32_t *host_count, float4 *src)
@@ -411,20 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all,
     uniq_of[j] = u;
     if (kp) {
         first[u] = j;
-        uint32_t e = j + 1;   // one past the run's last record
-        if (e < n && !keep[e]) {
-            // largest k in [j + 1, n - 1] with pos[k] == u + 1: the next kept record, or the last record of all
-            uint32_t lo = e, hi = n - 1;
-            while (lo < hi) {
-                const uint32_t mid = lo + (hi - lo + 1) / 2;
-                if (pos[mid] == u + 1) lo = mid;
-                else hi = mid - 1;
-            }
-            e = (lo == n - 1 && !keep[n - 1]) ? n : lo;
-        }
-        float4 s = src_all[j];
-        s.w = s.w != 0.0f ? (float)(e - j) : 0.0f;
-        src[u] = s;
+        src[u] = src_all[j];
     }
     if (j == n - 1) {
         count[0] = u + 1;
@@ -457,14 +442,18 @@ __global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t
     }
 }
 
-// cur = guess * src (or src); also: no seeds yet
-__global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, uint32_t n, Mat34 guess, int apply_guess,
+// the weight of distinct source point i in the 17 sums: how many records of the caller's cloud are exact copies of it
+__device__ __forceinline__ float source_weight(const uint32_t *first, uint32_t i) { return (float)(first[i + 1] - first[i]); }
+
+// cur = guess * src (or src) with the points' weights; also: no seeds yet
+__global__ __launch_bounds__(kBlock) void k_restart_source(const float4 *src, const uint32_t *first, uint32_t n, Mat34 guess, int apply_guess,
                                                            float4 *cur, int *seed)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     seed[i] = -1;
     float4 s = src[i];
+    if (s.w != 0.0f) s.w = source_weight(first, i);
     if (s.w != 0.0f && apply_guess) {
         const float3 t = xform(guess, s.x, s.y, s.z);
         s = make_float4(t.x, t.y, t.z, s.w);

@@ -1,5 +1,5 @@
 """GPU: the one-launch "flag, scan, scatter" of the index build (csrc/compact.hpp, k_dense_compact) and the source load's
-copies-to-weights step (k_source_unique) on clouds large enough to take those paths (the library's own radix sort from
+copies-to-weights step (k_source_unique, the weights formed by the first search launch) on clouds large enough to take those paths (the library's own radix sort from
 65 536 points on; smaller clouds go through rocPRIM's scan and the caller's order), with what a look-back and a run search
 get wrong first: runs of exact copies of every length around the 256-thread and 4 096-record boundaries, a record count
 that is no multiple of anything, non-finite records in between.

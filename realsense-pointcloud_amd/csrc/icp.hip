@@ -1586,6 +1586,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ss.host.release();
     }
     if (ctx->ev_side_gate) (void)hipEventDestroy(ctx->ev_side_gate);
+    if (ctx->ev_build) (void)hipEventDestroy(ctx->ev_build);
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);

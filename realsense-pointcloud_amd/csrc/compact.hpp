@@ -1,14 +1,16 @@
 // compact.hpp — "flag, scan, scatter" of a sorted array in ONE launch.
 //
-// Both halves of a pair end their radix sort the same way: flag the sorted records (kept / first of its cell), scan the
-// flags, scatter by the scan -- as separate launches that was a flag kernel, rocPRIM's scan (an init kernel and the scan
-// proper) and a scatter kernel: four launches, 55 us of a 10^6-point index build and as many gaps (the analogue of the
-// kd-tree PCL builds in setInputTarget, incremental_icp.hpp:58, and of the source's spatial order).  Here a workgroup
-// flags its 4 096 records, scans them in registers and LDS, learns what lies in front of it through a decoupled look-back
-// over one 64-bit word per workgroup (the two running counts and a status, so a word is complete the moment it is
-// visible: no fence), and scatters.  Workgroups number themselves by a ticket, so a workgroup only ever waits for
-// workgroups that are already running.  The words and the ticket must be zero when the kernel starts: the kernel in
-// front of the sort clears them on its way with the sort's own state (radix32.hpp).
+// The index build ends its radix sort by flagging the sorted records (kept / first of its cell), scanning the flags and
+// scattering the records by the scan -- as separate launches that was a flag kernel, rocPRIM's scan (an init kernel and
+// the scan proper) and a scatter kernel: four launches, 57 us of a 10^6-point index build and as many gaps (the analogue
+// of the kd-tree PCL builds in setInputTarget, incremental_icp.hpp:58).  Here a workgroup flags its 4 096 records, scans
+// them in registers and LDS, learns what lies in front of it through a decoupled look-back over one 64-bit word per
+// workgroup (the two running counts and a status, so a word is complete the moment it is visible: no fence), and
+// scatters.  Workgroups number themselves by a ticket, so a workgroup only ever waits for workgroups that are already
+// running.  The words and the ticket must be zero when the kernel starts: the kernel in front of the sort clears them on
+// its way with the sort's own state (radix32.hpp).  The block scan and the look-back are here; the kernel that uses them is
+// k_dense_compact (icp_dense.hpp).  (The same form for the source load's tail was measured and is level with rocPRIM's
+// scan there: profiles/r04_experiments/README.md.)
 #pragma once
 
 #include <cstdint>

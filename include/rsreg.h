@@ -338,10 +338,7 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
 /* PointCloud::operator+ : out = a followed by b (width = size, height = 1, is_dense = both); out may be a or b */
 int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *b, rsreg_cloud *out);
 /* icp.setInputTarget / setInputSource / align on handles; aligned_out (nullable, may be the source
- * cloud): the source records with xyz <- final * xyz and data[3] = 1.  The index build of a handle's records is
- * queued, not waited for (the context's own calls keep a handle's records in stream order; what the build has
- * counted -- rsreg_icp_grid_info -- is handed in where the alignment waits for the stream anyway); a raw device
- * pointer is consumed before rsreg_icp_set_target_device returns. */
+ * cloud): the source records with xyz <- final * xyz and data[3] = 1 */
 int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud, double max_correspondence_distance);
 int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *cloud);
 /* 1 when the ICP target index of `ctx` was built by rsreg_icp_set_target_cloud from this cloud, whose records have not

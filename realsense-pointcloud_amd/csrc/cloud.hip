@@ -775,12 +775,8 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
     // instead, bit for bit the same index, and it did not pay: profiles/r04_experiments/README.md)
     ctx->next_tgt_box.valid = false;
     if (!few_queries && c->box.valid && c->box_version == c->version) ctx->next_tgt_box = c->box;
-    // (a handle's records are only ever rewritten or handed on in the order of the context's streams: the build need not
-    // have drained when this call returns -- rsreg_ctx.hpp: build_async_next)
-    ctx->build_async_next = !few_queries;
     int rc = few_queries ? rsreg_icp_set_target_scan_(ctx, c->buf.ptr, c->n, c->stride, max_correspondence_distance)
                          : rsreg_icp_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, max_correspondence_distance);
-    ctx->build_async_next = false;
     ctx->next_tgt_box.valid = false;
     if (rc) return rc;
     if (!few_queries && ctx->last_tgt_box.valid) {

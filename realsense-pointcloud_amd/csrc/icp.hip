@@ -293,24 +293,6 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     return RSREG_OK;
 }
 
-// the counts of the dense index built last, if they have not been read yet (waits for that build's kernels)
-int finish_build_counts(rsreg_ctx *ctx)
-{
-    if (!ctx->counts_pending) return RSREG_OK;
-    ctx->counts_pending = false;
-    if (ctx->ev_build) RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_build));
-    GridParams &gp = ctx->grid;
-    const uint32_t *h_counts = ctx->h_smisc.as<uint32_t>() + 40;
-    gp.n_cells = h_counts[0];
-    gp.n_points = h_counts[2];
-    const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
-    rsreg_grid_info &gi = ctx->grid_info;
-    gi.n_unique_points = gp.n_points;
-    gi.n_cells = gp.n_cells;
-    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t) + (uint64_t)ctx->counts_n * sizeof(uint32_t);
-    return RSREG_OK;
-}
-
 int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, hipEvent_t ev0,
                 hipEvent_t ev1)
 {
@@ -341,33 +323,19 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
                     : build_dense_keyed<unsigned long long>(ctx, d_pts, n, stride, max_dist, nfin, id_bits);
     if (rc) return rc;
     if (ctx->profiling) (void)hipEventRecord(ev1, st);
+    RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in pinned words of their own)
+    const uint32_t *h_counts = ctx->h_smisc.as<uint32_t>() + 40;
+    gp.n_cells = h_counts[0];
+    gp.n_points = h_counts[2];
     gp.n_bricks = 0;
     rsreg_grid_info &gi = ctx->grid_info;
     for (int k = 0; k < 3; ++k) { gi.origin[k] = gp.origin[k]; gi.dims[k] = gp.dims[k]; }
     gi.cell_size = gp.cell;
+    gi.n_unique_points = gp.n_points;
+    gi.n_cells = gp.n_cells;
     gi.max_points_per_cell = 0;   // dense mode: computed on demand by rsreg_icp_grid_info
     gi.index_kind = 1;
-    // the two counts the scatter kernel leaves in pinned memory: read now (a raw device pointer is consumed before the
-    // call returns; the timing events of a profiling context have to have completed), or -- a cloud handle's records --
-    // where the stream is waited for anyway (finish_build_counts)
-    static const bool build_sync = std::getenv("RSREG_BUILD_SYNC") && std::getenv("RSREG_BUILD_SYNC")[0] == '1';
-    ctx->counts_n = (uint32_t)n;
-    if (ctx->build_async_next && !ctx->profiling && !build_sync) {
-        if (!ctx->ev_build) RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
-        RSREG_HIP(ctx, hipEventRecord(ctx->ev_build, st));
-        gp.n_points = nfin;   // (an upper bound: the sorted array is allocated for it)
-        gp.n_cells = 0;
-        gi.n_unique_points = 0;
-        gi.n_cells = 0;
-        gi.index_bytes = 0;
-        ctx->counts_pending = true;
-        ctx->have_target = true;
-        return RSREG_OK;
-    }
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
-    ctx->counts_pending = true;
-    int rcf = finish_build_counts(ctx);
-    if (rcf) return rcf;
+    gi.index_bytes = (uint64_t)(gp.n_points + 4) * sizeof(float4) + (uint64_t)(total + 1) * 2 * sizeof(uint32_t) + (uint64_t)n * sizeof(uint32_t);
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gi.ms_build = ms;
@@ -381,7 +349,6 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
 {
     hipStream_t st = ctx->stream;
     ctx->have_target = false;
-    ctx->counts_pending = false;   // (of the index this one replaces: nobody will ask for them any more)
     ctx->tgt_cloud_id = 0;
     ctx->n_target_raw = n;
     std::memset(&ctx->grid_info, 0, sizeof(ctx->grid_info));
@@ -1586,7 +1553,6 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ss.host.release();
     }
     if (ctx->ev_side_gate) (void)hipEventDestroy(ctx->ev_side_gate);
-    if (ctx->ev_build) (void)hipEventDestroy(ctx->ev_build);
     if (ctx->stream_src) {
         (void)hipStreamDestroy(ctx->stream_src);
         (void)hipEventDestroy(ctx->ev_src_done);
@@ -1798,10 +1764,6 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    {
-        int rcf = finish_build_counts(ctx);   // (a cloud handle's index: its counts have arrived long ago)
-        if (rcf) return rcf;
-    }
     if (const char *sd_path = std::getenv("RSREG_DUMP_SEED")) {   // dev: the position every query matched last, and the queries
         const size_t nq = ctx->n_work;
         std::vector<int> h(nq);
@@ -1912,10 +1874,6 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
 {
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
-    {
-        int rcf = finish_build_counts(ctx);
-        if (rcf) return rcf;
-    }
     static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
     if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
         const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);

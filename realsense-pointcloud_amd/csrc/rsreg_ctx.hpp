@@ -196,14 +196,7 @@ struct rsreg_ctx {
     // next_*: the box of the cloud about to be set, when its handle knows it (consumed by build_grid / load_source_queue);
     // last_*: what the last index build / source load started from (valid: computed or taken over)
     rsreg::CloudBox next_tgt_box, last_tgt_box, next_src_box, last_src_box;
-    // An index build over a cloud handle's records does not wait for its own kernels (rsreg_icp_set_target_cloud): what the
-    // host wants from them -- the number of kept points and of occupied cells -- is read where the stream is waited for
-    // anyway (the first sums of the alignment, rsreg_icp_end, rsreg_icp_grid_info: finish_build_counts).  Until then
-    // grid.n_points is the number of finite records, an upper bound.  A raw device pointer is still consumed before
-    // rsreg_icp_set_target_device returns.
-    bool build_async_next = false, counts_pending = false;
-    hipEvent_t ev_build = nullptr;
-    uint32_t counts_n = 0;          // records of the build whose counts are pending (index_bytes)
+
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     rsreg::IcpState icp;
 

@@ -1,0 +1,62 @@
+// pair_time.cpp -- what a C++ caller of the C ABI pays for one pair with the reference's parameters (setInputSource,
+// setInputTarget, align with the aligned cloud; incremental_icp.hpp:57-63): no Python between the calls.
+// usage: pair_time <target.f32> <source.f32> <n_target> <n_source>   (32-byte PointXYZRGB records, raw)
+// build: g++ -std=c++17 -O2 -I include tools/cpp/pair_time.cpp -o tools/_build/pair_time -L realsense-pointcloud_amd -lrsreg -Wl,-rpath,$PWD/realsense-pointcloud_amd
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rsreg.h"
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CK(x) do { int rc_ = (x); if (rc_) { std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, rsreg_last_error(ctx)); return 1; } } while (0)
+
+static std::vector<char> slurp(const char *path, size_t bytes)
+{
+    std::vector<char> v(bytes);
+    FILE *f = std::fopen(path, "rb");
+    if (!f || std::fread(v.data(), 1, bytes, f) != bytes) { std::fprintf(stderr, "cannot read %s\n", path); std::exit(2); }
+    std::fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    const size_t nt = std::strtoull(argv[3], nullptr, 10), ns = std::strtoull(argv[4], nullptr, 10);
+    const std::vector<char> t = slurp(argv[1], nt * 32), s = slurp(argv[2], ns * 32);
+    rsreg_ctx *ctx = nullptr;
+    if (rsreg_ctx_create(0, nullptr, &ctx)) return 1;
+    rsreg_cloud *ct, *cs, *out;
+    CK(rsreg_cloud_create(ctx, &ct)); CK(rsreg_cloud_create(ctx, &cs)); CK(rsreg_cloud_create(ctx, &out));
+    CK(rsreg_cloud_upload(ct, t.data(), nt, 32, (uint32_t)nt, 1, 0));
+    CK(rsreg_cloud_upload(cs, s.data(), ns, 32, (uint32_t)ns, 1, 0));
+    rsreg_icp_params prm;
+    rsreg_icp_params_reference(&prm);
+    rsreg_icp_result res;
+    for (int fresh = 0; fresh < 2; ++fresh) {
+        std::vector<double> ms;
+        for (int k = 0; k < 105; ++k) {
+            if (fresh) {   // new records under the handles (outside the clock): boxes measured again, caches cold from the copy
+                CK(rsreg_cloud_upload(ct, t.data(), nt, 32, (uint32_t)nt, 1, 0));
+                CK(rsreg_cloud_upload(cs, s.data(), ns, 32, (uint32_t)ns, 1, 0));
+            }
+            CK(rsreg_ctx_synchronize(ctx));
+            const double t0 = now_ms();
+            CK(rsreg_icp_set_source_cloud(ctx, cs));
+            CK(rsreg_icp_set_target_cloud(ctx, ct, prm.max_correspondence_distance));
+            CK(rsreg_icp_align_cloud(ctx, nullptr, &prm, &res, out));
+            CK(rsreg_ctx_synchronize(ctx));
+            if (k >= 5) ms.push_back(now_ms() - t0);
+        }
+        std::sort(ms.begin(), ms.end());
+        std::printf("C++ caller, %zu x %zu points, reference parameters, %s: median %.3f ms per pair (p10 %.3f, p90 %.3f), %d iteration(s), %llu correspondences\n",
+                    ns, nt, fresh ? "new records under the handles every time" : "the same clouds again (boxes measured)", ms[ms.size() / 2], ms[ms.size() / 10],
+                    ms[ms.size() * 9 / 10], res.iterations, (unsigned long long)res.n_correspondences);
+    }
+    rsreg_cloud_destroy(ct); rsreg_cloud_destroy(cs); rsreg_cloud_destroy(out);
+    rsreg_ctx_destroy(ctx);
+    return 0;
+}

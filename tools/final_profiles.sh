@@ -37,6 +37,8 @@ for s in N1M N300 50k; do
   timeout -k 10 200 python tools/step_breakdown.py $s 30 source-first 2>&1 | grep -v amdgpu.ids >> $O/step_breakdown.txt
   timeout -k 10 200 python tools/ref_mode.py $s 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 done
+echo "== python tools/cpp_pair_time.py: the same pair through tools/cpp/pair_time.cpp, a C++ caller of the C ABI (no Python between the calls)" >> $O/reference_mode.txt
+timeout -k 10 300 python tools/cpp_pair_time.py 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 timeout -k 10 200 python tools/small_align.py 300 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 timeout -k 10 200 python tools/small_ndt.py 100 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 cat $O/step_breakdown.txt $O/reference_mode.txt

@@ -45,6 +45,9 @@ def parse():
                     help="dev: take the multi-rank code path (process group, native RCCL transport, all-reduce per iteration) "
                          "even with one rank, e.g. under `torch.distributed.run --nproc-per-node 1`")
     ap.add_argument("--no-events", action="store_true", help="dev: run without the per-kernel HIP events (no roofline numbers)")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="the per-launch HIP events of the roofline leg are recorded in every E-th step of the timed region (two records "
+                         "between every two dependent launches cost 0.22 ms of a 3.4 ms step: in all steps they would lower `value` by 6 %%); 1: in all")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: if the native RCCL transport (rsreg_comm_init) cannot be set up, carry the 17 sums over torch.distributed "
                          "instead of exiting with an error (the line then says so in config.sharding)")
@@ -112,11 +115,20 @@ def run_chain(a, rank, world, local_rank, dist):
     for _ in range(a.warmup):
         step()
     sync()
+    every = max(1, a.event_every)
+    ctx.set_profiling(False)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        poses, local = step(collect=True)
+    for k in range(a.steps):
+        timed = (not a.no_events) and k % every == 0     # (this step carries the per-launch HIP events: bench.py --event-every)
+        if timed:
+            ctx.set_profiling(True)
+        poses, local = step(collect=timed)
+        if timed:
+            ctx.set_profiling(False)
     sync()
     elapsed = time.perf_counter() - t0
+    if not stats["launch"]:
+        L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,17 +306,27 @@ def main():
         step()
     sync()
     ms_nn = ms_red = ms_build = 0.0
-    n_launch = 0
+    n_launch = n_event_steps = 0
+    every = max(1, a.event_every)
+    ctx.set_profiling(False)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
+        timed = (not a.no_events) and k % every == 0     # (this step carries the per-launch HIP events)
+        if timed:
+            ctx.set_profiling(True)
         step()
-        ms_nn += res.ms_nn
-        ms_red += res.ms_reduce + res.ms_transform
-        n_launch += res.n_nn_launches
-        L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
-        ms_build += gi.ms_build
+        if timed:
+            ms_nn += res.ms_nn
+            ms_red += res.ms_reduce + res.ms_transform
+            n_launch += res.n_nn_launches
+            L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
+            ms_build += gi.ms_build
+            n_event_steps += 1
+            ctx.set_profiling(False)
     sync()
     elapsed = time.perf_counter() - t0
+    if not n_event_steps:
+        L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -372,10 +394,13 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
             "launches": n_launch,
+            "events": "HIP events around every search launch of %d of the %d timed steps (every %d-th; their two records between "
+                      "every two dependent launches cost 0.22 ms of a step, so the other steps run without them)" % (n_event_steps, a.steps, every),
         },
         "breakdown_ms_per_step": {
-            "grid_build": ms_build / a.steps, "nn_kernel": ms_nn / a.steps, "reduce_transform": ms_red / a.steps,
-            "iteration_rate_pairs_per_s": float(n_src_total) * a.iterations * a.steps / max((ms_nn + ms_red) * 1e-3, 1e-12),
+            "grid_build": ms_build / max(n_event_steps, 1), "nn_kernel": ms_nn / max(n_event_steps, 1), "reduce_transform": ms_red / max(n_event_steps, 1),
+            "iteration_rate_pairs_per_s": float(n_src_total) * a.iterations * max(n_event_steps, 1) / max((ms_nn + ms_red) * 1e-3, 1e-12),
+            "of": "the %d steps that carry the events" % n_event_steps,
         },
         "grid": {"kind": "dense cell-start table" if gi.index_kind == 1 else "brick hash", "cell_size": float(gi.cell_size),
                  "n_cells": int(gi.n_cells), "n_unique_points": n_unique, "n_source_distinct": n_distinct,
@@ -433,8 +458,8 @@ def main():
         pass
     # the index build as a rate: SURVEY.md §8d prices it at 116 algorithmic bytes per target point
     if ms_build > 0:
-        gb = 116.0 * n_tgt / (ms_build / a.steps * 1e-3) / 1e9
-        out["grid_build"] = {"ms": ms_build / a.steps, "algorithmic_bytes": 116 * n_tgt, "achieved": gb, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        gb = 116.0 * n_tgt / (ms_build / max(n_event_steps, 1) * 1e-3) / 1e9
+        out["grid_build"] = {"ms": ms_build / max(n_event_steps, 1), "algorithmic_bytes": 116 * n_tgt, "achieved": gb, "unit": "GB/s", "peak": HBM_PEAK_GBS,
                              "frac": gb / HBM_PEAK_GBS}
     if world == 1 and a.pipeline == 2:
         # the north star's default pipeline next to the headline: fused kernel, 136 bytes to the host and a host 3x3

@@ -597,6 +597,9 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         RSREG_HIP(ctx, hipSetDevice(ctx->device));   // (this may be the context's worker thread)
         uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
+        // (the box of the cloud this source comes from, if its handle knows it: taken over -- or dropped -- here, whatever the path)
+        const rsreg::CloudBox known = ctx->next_src_box;
+        ctx->next_src_box.valid = false;
         if (source_is_small(n)) {
             // one launch, the caller's order -- on the MAIN stream: the streams of a process share a few hardware queues,
             // and a kernel on the source stream can find itself behind a 0.4 ms voxel filter of a side stream
@@ -612,8 +615,6 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         float mn[3], mx[3];
         uint32_t nfin = 0;
-        const rsreg::CloudBox known = ctx->next_src_box;
-        ctx->next_src_box.valid = false;
         static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
         if (known.valid && !no_box_cache) {   // (nothing of the load counts in the words k_bbox_final clears: the kernels below only store there)
             for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }

@@ -588,6 +588,11 @@ def main():
                     pair(t, s_)
                 ctx.synchronize()
                 modes["device_clouds_boxes_known"] = (time.perf_counter() - t0) / reps * 1e3
+        # (the timed pairs above run without the per-launch HIP events; one more pair with them for the launch's own duration)
+        ctx.set_profiling(True)
+        pair(t, s_)
+        ctx.synchronize()
+        ctx.set_profiling(False)
         out["reference_mode"] = {
             "workload": "icp_pair_%sx%s reference parameters (100 max iterations, 1 cm gate, eps 1 / 1000 -> 1 iteration)" % (a.size, a.size),
             "iterations": int(ref.result.iterations), "n_correspondences": int(ref.result.n_correspondences),

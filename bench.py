@@ -52,13 +52,17 @@ def parse():
                     help="N > 1: if the native RCCL transport (rsreg_comm_init) cannot be set up, carry the 17 sums over torch.distributed "
                          "instead of exiting with an error (the line then says so in config.sharding)")
     ap.add_argument("--cpu-iterations", type=int, default=10)
+    ap.add_argument("--devices-per-node", type=int, default=0,
+                    help="dev: rank r runs on device r %% D (0: one device per rank, the driver's launch).  With more ranks than devices "
+                         "the process group is gloo (RCCL refuses two ranks on one device) and the 17 sums travel over torch.distributed: "
+                         "a rehearsal of the N > 1 code path on a one-GPU box, never a scaling number")
     ap.add_argument("--workload", default="pair", choices=["pair", "chain"],
                     help="pair: ONE 1M pair, source sharded over the ranks (configs[1]/[3], the headline line); "
                          "chain: 2 x N frames of 300k points as consecutive pairs, one pair per GPU at a time (configs[4])")
     return ap.parse_args()
 
 
-def run_chain(a, rank, world, local_rank, dist):
+def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
     """BASELINE configs[4]: a chain of frames as independent consecutive pairs (k-1, k), dealt round-robin
     to the ranks, pair transforms gathered and composed on the host (rsreg_amd/chain.py).  Weak scaling:
     2 x N frames (16 at N = 8), i.e. about two pairs per GPU whatever N.  No collective on the data path."""
@@ -86,7 +90,7 @@ def run_chain(a, rank, world, local_rank, dist):
     def allgather(buf):
         if dist is None:
             return [buf]
-        t = torch.from_numpy(buf).cuda()
+        t = torch.from_numpy(buf).to(coll_dev)
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         return [o.cpu().numpy() for o in outs]
@@ -129,8 +133,20 @@ def run_chain(a, rank, world, local_rank, dist):
     elapsed = time.perf_counter() - t0
     if not stats["launch"]:
         L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
+    # the same step with records the handles have never measured under the SOURCE frames (re-uploaded with the clock stopped): in the
+    # timed region above every handle keeps the bounding box an earlier load measured, which a stream of new frames has for its
+    # targets (last pair's sources) but never for its sources
+    fresh_s, fresh_n = 0.0, min(3, a.steps)
+    for _ in range(fresh_n):
+        for k in mine:
+            dev[k].upload(host[k])
+        sync()
+        tf = time.perf_counter()
+        step()
+        sync()
+        fresh_s += time.perf_counter() - tf
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
@@ -157,6 +173,7 @@ def run_chain(a, rank, world, local_rank, dist):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg_ms, "launches": stats["launch"]},
         "chain_pose_error_vs_ground_truth_frobenius_max": float(max(np.linalg.norm(poses[k] - gt[k]) for k in range(n_frames))),
+        "ms_per_step_fresh_source_frames": (fresh_s / fresh_n * 1e3) if fresh_n else None,
     }
     if not a.no_cpu_baseline:
         import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product
@@ -200,7 +217,14 @@ def main():
         lib.build()
     if not torch.cuda.is_available() or api.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    per_node = a.devices_per_node if a.devices_per_node > 0 else max(n_dev, 1)
+    shared_devices = world > per_node          # several ranks on one device: a rehearsal (--devices-per-node), gloo
+    if a.devices_per_node == 0 and local_rank >= n_dev:
+        raise SystemExit("rank %d has no device of its own (%d visible); --devices-per-node D rehearses N > D ranks on D devices" % (local_rank, n_dev))
+    device = local_rank % per_node
+    local_rank = device                        # (what every Context below is created on)
+    torch.cuda.set_device(device)
     dist = None
     multi = world > 1 or a.force_dist
     if multi:
@@ -211,10 +235,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_devices:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    coll_dev = "cpu" if shared_devices else "cuda"   # where the tensors of the bench's own collectives live
 
     if a.workload == "chain":
-        out = run_chain(a, rank, world, local_rank, dist)
+        out = run_chain(a, rank, world, local_rank, dist, coll_dev)
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:
@@ -243,17 +271,20 @@ def main():
         # driver whose all-reduce is torch.distributed (also RCCL on ROCm).
         ok = 1
         try:
-            uid = torch.zeros(lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if shared_devices:
+                raise RuntimeError("%d ranks on %d device(s): RCCL refuses two ranks on one device" % (world, per_node))
+            uid = torch.zeros(lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device=coll_dev)
             if rank == 0:
-                uid = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).cuda()
+                uid = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).to(coll_dev)
             dist.broadcast(uid, 0)
             ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
         except Exception as e:  # noqa: BLE001
             print("[bench] rank %d: native RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        transport = "rccl-native" if int(flag.item()) == 1 else "torch-distributed"
+        transport = "rccl-native" if int(flag.item()) == 1 else ("torch-distributed (gloo: %d ranks on %d device(s), a rehearsal)" % (world, per_node)
+                                                                   if shared_devices else "torch-distributed")
         if transport != "rccl-native" and ok:
             lib.lib().rsreg_comm_destroy(ctx.h)
         if transport != "rccl-native" and not a.allow_fallback:
@@ -275,13 +306,13 @@ def main():
     res = lib.IcpResult()
     gi = lib.GridInfo()
 
-    if transport == "torch-distributed":
+    if transport.startswith("torch-distributed"):
         stepper = api.IterativeClosestPoint(ctx)
         stepper.params = prm
         stepper._quiet_search = True
 
         def allreduce(v):
-            t = torch.from_numpy(v).cuda()
+            t = torch.from_numpy(v).to(coll_dev)
             dist.all_reduce(t)
             return t.cpu().numpy()
 
@@ -305,7 +336,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
-    ms_nn = ms_red = ms_build = 0.0
+    ms_nn = ms_red = ms_build = ms_allreduce = 0.0
     n_launch = n_event_steps = 0
     every = max(1, a.event_every)
     ctx.set_profiling(False)
@@ -318,6 +349,7 @@ def main():
         if timed:
             ms_nn += res.ms_nn
             ms_red += res.ms_reduce + res.ms_transform
+            ms_allreduce += res.ms_allreduce
             n_launch += res.n_nn_launches
             L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
             ms_build += gi.ms_build
@@ -328,7 +360,7 @@ def main():
     if not n_event_steps:
         L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     T_gpu = api._rowmajor(res.transform)
@@ -399,6 +431,9 @@ def main():
         },
         "breakdown_ms_per_step": {
             "grid_build": ms_build / max(n_event_steps, 1), "nn_kernel": ms_nn / max(n_event_steps, 1), "reduce_transform": ms_red / max(n_event_steps, 1),
+            # N > 1, native transport: the ncclAllReduce of the 17 sums between HIP events on the ctx stream, all iterations of a step
+            # (inside reduce_transform); None where nothing was all-reduced by the library (one rank, or the torch.distributed transport)
+            "allreduce": (ms_allreduce / max(n_event_steps, 1)) if (multi and transport == "rccl-native") else None,
             "iteration_rate_pairs_per_s": float(n_src_total) * a.iterations * max(n_event_steps, 1) / max((ms_nn + ms_red) * 1e-3, 1e-12),
             "of": "the %d steps that carry the events" % n_event_steps,
         },
@@ -483,18 +518,46 @@ def main():
         torch.cuda.synchronize()
         out["pipeline1_ms_per_step"] = (time.perf_counter() - t1) / reps1 * 1e3
         out["pipeline1_same_transform"] = bool((api._rowmajor(res1.transform) == T_gpu).all())
-        # does ICP move the pair at all?  The headline's guess is 1 % of the motion off; from the identity (the whole
-        # motion of the "bench" preset off: 1.5 degrees, 16 mm) the same 30 iterations must close most of the gap
+        # does ICP move the pair at all?  The headline's guess is two thirds of the way there (guess 1.0 degree / (8, -4, 6) mm against the
+        # preset's motion of 1.5 degrees / (12, -6, 9) mm: a third of the motion off), so its 30 iterations run mostly in the settled,
+        # seeded regime.  From the identity (the whole motion off) the same 30 iterations must close most of the gap -- and that
+        # alignment is TIMED here too, the same step as the headline's (source load + index build + 30 iterations), no events
         gt_ = synth.ground_truth(1, 0, "bench")
         eye = np.ascontiguousarray(np.eye(4, dtype=np.float32))
-        lib.check(L.rsreg_icp_set_source_device(ctx1.h, d_src.data_ptr(), n_src, stride, 0), ctx1.h)
-        lib.check(L.rsreg_icp_set_target_device(ctx1.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx1.h)
         prm2_ = api.icp_params(max_iterations=a.iterations, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=a.max_dist)
-        lib.check(L.rsreg_icp_align(ctx1.h, eye.ctypes.data, C.byref(prm2_), C.byref(res1), None, 0), ctx1.h)
+
+        def step_eye():
+            lib.check(L.rsreg_icp_set_source_device(ctx1.h, d_src.data_ptr(), n_src, stride, 0), ctx1.h)
+            lib.check(L.rsreg_icp_set_target_device(ctx1.h, d_tgt.data_ptr(), n_tgt, stride, 0, a.max_dist), ctx1.h)
+            lib.check(L.rsreg_icp_align(ctx1.h, eye.ctypes.data, C.byref(prm2_), C.byref(res1), None, 0), ctx1.h)
+
+        for _ in range(2):
+            step_eye()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps1):
+            step_eye()
+        torch.cuda.synchronize()
+        eye_ms = (time.perf_counter() - t1) / reps1 * 1e3
         out["convergence_from_identity"] = {
             "initial_error_frobenius": float(np.linalg.norm(np.eye(4) - gt_)),
             "final_error_frobenius": float(np.linalg.norm(api._rowmajor(res1.transform) - gt_)), "iterations": int(res1.iterations),
-            "note": "same pair and gate, guess = identity (the frame-to-frame motion of the bench preset is 1.5 degrees + 16 mm)"}
+            "ms_per_step": eye_ms, "point_pairs_per_s": float(n_src_total) * a.iterations / (eye_ms * 1e-3), "steps_timed": reps1,
+            "note": "same pair, gate and step as the headline, guess = identity (the frame-to-frame motion of the bench preset is "
+                    "1.5 degrees + 16 mm; the headline's guess is a third of that motion off)"}
+        # the headline's own step with the per-launch HIP events in EVERY step (rounds 1-3 measured `value` that way): the like-for-like
+        # column for comparisons across rounds
+        if not a.no_events and every > 1:
+            ctx.set_profiling(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps1):
+                step()
+            torch.cuda.synchronize()
+            ev_ms = (time.perf_counter() - t1) / reps1 * 1e3
+            ctx.set_profiling(False)
+            out["value_with_events_in_all_steps"] = {"value": float(n_src_total) * a.iterations / (ev_ms * 1e-3), "ms_per_step": ev_ms, "steps_timed": reps1,
+                                                     "note": "`value` is measured with the events in every %d-th step only" % every}
 
     if not a.no_cpu_baseline:
         import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define RSREG_VERSION_MAJOR 0
-#define RSREG_VERSION_MINOR 2
+#define RSREG_VERSION_MINOR 3
 
 typedef struct rsreg_ctx rsreg_ctx;
 
@@ -142,6 +142,7 @@ typedef struct rsreg_icp_result {
     double ms_transform;
     int32_t n_nn_launches;
     int32_t reserved1;
+    double ms_allreduce;        /* N > 1 ranks: the all-reduce of the 17 sums, all iterations (0.3; 0 with one rank)   */
 } rsreg_icp_result;
 
 typedef struct rsreg_ndt_result {
@@ -396,9 +397,6 @@ typedef struct rsreg_grid_info {
                                  * target set for at most 64 source points is searched whole (IncrementalICP) */
     uint32_t n_source_distinct; /* distinct source points the iterations work on (0: no source) */
     uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
-    uint32_t n_updates;         /* always 0 since round 4 (the index of a grown target cloud is built afresh: merging the
-                                 * new points into the old index, rounds 3-4, was bit-identical and did not pay)      */
-    uint32_t reserved;
 } rsreg_grid_info;
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
 

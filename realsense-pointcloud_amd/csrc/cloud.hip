@@ -516,8 +516,9 @@ int side_wait_input(rsreg_ctx *ctx, const InFlight &f, hipStream_t st)
     if (!f.filling || !f.ev) return RSREG_OK;
     // (a third party's wait: a failed upload stays for the poster's own settle() to report, and this job does not run on
     // a buffer that was never filled)
-    if (ctx->up_worker && ctx->up_worker->peek(f.ticket)) return RSREG_ERR_HIP;
-    return hipStreamWaitEvent(st, f.ev, 0) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;
+    if (ctx->up_worker && ctx->up_worker->peek(f.ticket)) return fail(ctx, RSREG_ERR_HIP, "the upload of this job's input cloud failed");
+    RSREG_HIP(ctx, hipStreamWaitEvent(st, f.ev, 0));
+    return RSREG_OK;
 }
 
 }  // namespace

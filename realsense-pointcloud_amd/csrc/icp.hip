@@ -591,15 +591,14 @@ bool source_is_small(size_t n)
 
 // The part of a source load that queues work on stream_src (after one round trip for the bounding box); runs on the
 // context's worker thread (rsreg_ctx.hpp: SourceWorker) or, with RSREG_NO_WORKER=1, on the caller's.
-int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
+// `known`: the box of the cloud handle this source comes from, if the handle has one (by value: ctx->next_src_box belongs
+// to the caller's thread alone)
+int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride, const rsreg::CloudBox known)
 {
     {
         RSREG_HIP(ctx, hipSetDevice(ctx->device));   // (this may be the context's worker thread)
         uint32_t *d_misc = ctx->d_smisc.as<uint32_t>();
         uint32_t *h_misc = ctx->h_smisc.as<uint32_t>();
-        // (the box of the cloud this source comes from, if its handle knows it: taken over -- or dropped -- here, whatever the path)
-        const rsreg::CloudBox known = ctx->next_src_box;
-        ctx->next_src_box.valid = false;
         if (source_is_small(n)) {
             // one launch, the caller's order -- on the MAIN stream: the streams of a process share a few hardware queues,
             // and a kernel on the source stream can find itself behind a 0.4 ms voxel filter of a side stream
@@ -726,6 +725,10 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
     if (rcj) return rcj;
     ctx->last_src_box.valid = false;   // (of the load before this one: cloud.hip has taken it over by now)
+    // the box of the cloud this source comes from, if its handle knows it: taken over -- or dropped -- here, on the caller's
+    // thread, after the load before this one has been joined; the worker's job gets a copy
+    const rsreg::CloudBox known = ctx->next_src_box;
+    ctx->next_src_box.valid = false;
     if (!ctx->stream_src) {
         RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
         RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
@@ -756,13 +759,13 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         static const bool no_worker = std::getenv("RSREG_NO_WORKER") && std::getenv("RSREG_NO_WORKER")[0] == '1';
         if (no_worker || source_is_small(n)) {   // (a small source is one launch: not worth a hand-over)
-            int rc = load_source_queue(ctx, d_raw, n, stride);
+            int rc = load_source_queue(ctx, d_raw, n, stride, known);
             if (rc) return rc;
         } else {
             // the rest -- a bounding-box round trip and ~25 launches -- on the context's worker thread: the caller goes on
             // (to the target's index build, in the reference's order of calls) while the source's queue is being filled
             if (!ctx->src_worker) ctx->src_worker = new rsreg::SourceWorker();
-            ctx->src_worker->post([ctx, d_raw, n, stride] { return load_source_queue(ctx, d_raw, n, stride); });
+            ctx->src_worker->post([ctx, d_raw, n, stride, known] { return load_source_queue(ctx, d_raw, n, stride, known); });
         }
         ctx->src_pending = true;
     }
@@ -974,6 +977,7 @@ double *host_sums_target(rsreg_ctx *ctx) { return ctx->comm ? ctx->d_sums.as<dou
 int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
     if (global && ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
+        ScopedEvents ev(ctx, &ctx->ev_allreduce);
         int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
         if (rc) return rc;
     }
@@ -1312,6 +1316,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     RSREG_HIP(ctx, hipGetLastError());
     if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass
         if (ctx->comm) {
+            ScopedEvents ev(ctx, &ctx->ev_allreduce);
             int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_sums.as<double>(), RSREG_NUM_SUMS);
             if (rc) return rc;
         }
@@ -1689,6 +1694,7 @@ int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
     ctx->ev_nn.clear();
     ctx->ev_reduce.clear();
     ctx->ev_transform.clear();
+    ctx->ev_allreduce.clear();
     s.restart_pending = true;   // input_transformed = guess * input (App. A.2 prologue): ensure_restarted / launch_fused
     return RSREG_OK;
 }
@@ -1834,6 +1840,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
                         result->ms_reduce += t;
                 }
             result->ms_transform = sum_events(ctx, ctx->ev_transform);
+            result->ms_allreduce = sum_events(ctx, ctx->ev_allreduce);   // (already inside ms_reduce in the fused pipelines)
             result->ms_total = result->ms_nn + result->ms_reduce + result->ms_transform;
         }
     }

@@ -15,15 +15,29 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include <rocprim/rocprim_version.hpp>
+
 #include "sort_cfg.hpp"
+
+// The three kernels below wrap device functions of rocPRIM's onesweep that live in its `detail` namespace: an internal
+// interface, checked here against the one release it was written for.  On any other rocPRIM every sort goes through the
+// public rocprim::radix_sort_pairs (radix32_pays() is false, the callers' rocPRIM branch runs): slower by nine memsets per
+// sort, never wrong.
+#if ROCPRIM_VERSION == 400200
+#define RSREG_RADIX32_DETAIL 1
+#else
+#define RSREG_RADIX32_DETAIL 0
+#endif
 
 namespace rsreg {
 
 constexpr unsigned kR32SortBlock = 1024, kR32SortItems = 4, kR32Bits = 8, kR32HistBlock = 256, kR32HistItems = 12;
 constexpr unsigned kR32MaxPlaces = 4;
 
+#if RSREG_RADIX32_DETAIL
 using R32Bid = rocprim::detail::block_id_wrapper<unsigned int, true>;
 using R32State = rocprim::detail::onesweep_lookback_state;
+#endif
 
 struct Radix32Plan {
     uint32_t places = 0, blocks = 0, hist_blocks = 0;
@@ -53,7 +67,8 @@ inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit, 
 inline bool radix32_pays(size_t n, unsigned bits)
 {
     static const bool off = std::getenv("RSREG_ROCPRIM_SORT") && std::getenv("RSREG_ROCPRIM_SORT")[0] == '1';
-    if (off || bits == 0 || bits > 32) return false;
+    if (!RSREG_RADIX32_DETAIL || off || bits == 0 || bits > 32) return false;
+    if (n >= (1ull << 30)) return false;   // (radix32_sort_pairs counts in 32 bits with room to spare: larger sorts are rocPRIM's)
     return n >= 65536 || (n >= 8192 && bits <= 16);
 }
 
@@ -63,6 +78,7 @@ __device__ __forceinline__ void radix32_clear(uint32_t *scratch, uint32_t words,
     for (uint32_t w = t; w < words; w += threads) scratch[w] = 0u;
 }
 
+#if RSREG_RADIX32_DETAIL
 // (templates, so that the several translation units of the library that include this header share one definition)
 template <int kDummy = 0>
 __global__ __launch_bounds__(kR32HistBlock) void k_r32_histograms(const uint32_t *keys, uint32_t *digits, uint32_t n, uint32_t full_blocks,
@@ -96,16 +112,17 @@ inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, ui
 {
     *in_first = true;
     if (n == 0 || p.places == 0) return hipSuccess;
+    // (every check before the first launch: an error return leaves nothing queued on a dirty scratch block)
     if (p.places > kR32MaxPlaces || n >= (1ull << 30)) return hipErrorInvalidValue;
-    uint32_t *digits = scratch + p.off_digits;
-    {
-        const uint32_t per = kR32HistBlock * kR32HistItems;
-        const uint32_t full = (uint32_t)(n % per == 0 ? p.hist_blocks : p.hist_blocks - 1);
-        k_r32_histograms<0><<<p.hist_blocks, kR32HistBlock, 0, st>>>(keys_a, digits, (uint32_t)n, full, begin_bit, end_bit);
-        k_r32_scan_histograms<0><<<p.places, kR32HistBlock, 0, st>>>(digits);
-    }
     const uint32_t per = kBlockT * kItemsT;
     if (p.blocks != (uint32_t)((n + per - 1) / per)) return hipErrorInvalidValue;   // (the plan was made for another tiling)
+    uint32_t *digits = scratch + p.off_digits;
+    {
+        const uint32_t hper = kR32HistBlock * kR32HistItems;
+        const uint32_t hfull = (uint32_t)(n % hper == 0 ? p.hist_blocks : p.hist_blocks - 1);
+        k_r32_histograms<0><<<p.hist_blocks, kR32HistBlock, 0, st>>>(keys_a, digits, (uint32_t)n, hfull, begin_bit, end_bit);
+        k_r32_scan_histograms<0><<<p.places, kR32HistBlock, 0, st>>>(digits);
+    }
     const uint32_t full = (uint32_t)(n % per == 0 ? p.blocks : p.blocks - 1);
     bool from_a = true;
     unsigned bit = begin_bit;
@@ -121,5 +138,14 @@ inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, ui
     *in_first = from_a;
     return hipGetLastError();
 }
+#else
+template <unsigned kBlockT = kR32SortBlock, unsigned kItemsT = kR32SortItems>
+inline hipError_t radix32_sort_pairs(const Radix32Plan &, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, size_t, unsigned, unsigned,
+                                     hipStream_t, bool *in_first)
+{
+    *in_first = true;
+    return hipErrorNotSupported;   // (never reached: radix32_pays() is false on this rocPRIM)
+}
+#endif
 
 }  // namespace rsreg

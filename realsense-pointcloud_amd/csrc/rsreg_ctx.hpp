@@ -259,7 +259,7 @@ struct rsreg_ctx {
     // ---- profiling events
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    std::vector<std::pair<size_t, size_t>> ev_nn, ev_reduce, ev_transform;
+    std::vector<std::pair<size_t, size_t>> ev_nn, ev_reduce, ev_transform, ev_allreduce;
 };
 
 namespace rsreg {

@@ -9,6 +9,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace rsreg {
@@ -167,7 +168,7 @@ struct TicketWorker {
     std::vector<std::function<int()>> queue;
     uint64_t posted = 0, done = 0;
     bool stop = false;
-    int err = 0;
+    std::vector<std::pair<uint64_t, int>> errs;   // (ticket, status) of the jobs that failed and whose poster has not asked yet
 
     void loop()
     {
@@ -180,7 +181,7 @@ struct TicketWorker {
             lk.unlock();
             const int r = f();
             lk.lock();
-            if (r && !err) err = r;
+            if (r) errs.emplace_back(done + 1, r);
             ++done;
             cv.notify_all();
         }
@@ -193,19 +194,26 @@ struct TicketWorker {
         cv.notify_all();
         return ++posted;
     }
-    int wait(uint64_t ticket)   // until job `ticket` has run; the first error of any job since the last wait
+    int wait(uint64_t ticket)   // until job `ticket` has run; ITS status (the poster's own wait: the entry is taken out)
     {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return done >= ticket; });
-        const int e = err;
-        err = 0;
-        return e;
+        for (size_t k = 0; k < errs.size(); ++k) {
+            if (errs[k].first == ticket) {
+                const int e = errs[k].second;
+                errs.erase(errs.begin() + (long)k);
+                return e;
+            }
+        }
+        return 0;
     }
-    int peek(uint64_t ticket)   // the same for a third party: the error stays for the poster's own wait
+    int peek(uint64_t ticket)   // the status of job `ticket` ALONE, for a third party: the error stays for the poster's own wait
     {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return done >= ticket; });
-        return err;
+        for (const auto &e : errs)
+            if (e.first == ticket) return e.second;
+        return 0;
     }
     void shutdown()
     {

@@ -27,7 +27,7 @@ def test_header_and_exports_agree(L):
 
 
 def test_version_and_status_strings(L):
-    assert L.lib().rsreg_version() == 2          # 0.2: rsreg_icp_params grew the optional correspondence filters
+    assert L.lib().rsreg_version() == 3          # 0.3: rsreg_grid_info lost n_updates (dead since round 4), rsreg_icp_result gained ms_allreduce
     assert L.status_string(0) == "ok"
     assert "device" in L.status_string(-6)
 
@@ -36,8 +36,8 @@ def test_struct_layouts_match_header(L):
     # sizes the C compiler gives the same structs
     assert C.sizeof(L.IcpParams) == 64
     assert C.sizeof(L.NdtParams) == 40
-    assert C.sizeof(L.IcpResult) == 64 + 16 + 8 + 8 + 17 * 8 + 4 * 8 + 8
-    assert C.sizeof(L.GridInfo) == 80   # (round 3: + n_updates, reserved)
+    assert C.sizeof(L.IcpResult) == 64 + 16 + 8 + 8 + 17 * 8 + 4 * 8 + 8 + 8
+    assert C.sizeof(L.GridInfo) == 72
 
 
 def test_reference_presets(rs, L):

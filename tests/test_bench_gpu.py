@@ -44,6 +44,36 @@ def test_bench_multi_rank_path_with_one_rank():
              str(29600 + os.getpid() % 300), "bench.py", "--gpus", "1", "--size", "50k", "--steps", "2", "--warmup", "1",
              "--no-cpu-baseline", "--force-dist"])
     assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["breakdown_ms_per_step"]["allreduce"] is not None and j["breakdown_ms_per_step"]["allreduce"] >= 0   # ncclAllReduce between events
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it on an 8-GPU node (BASELINE configs[3]: one pair, source blocks dealt to the
+    ranks, the 17 sums all-reduced per iteration, max-over-ranks timing, ONE line from rank 0) -- rehearsed with both ranks on
+    device 0 (--devices-per-node 1: gloo, since RCCL refuses two ranks on one device), so that the first multi-GPU box is not
+    the first run of the sharding string, the rank-0-only printing and the clean exit of the other rank."""
+    port = str(29300 + os.getpid() % 250)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, "bench.py", "--gpus", "2", "--size", "50k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--devices-per-node", "1", "--allow-fallback"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]        # (torch.distributed.run: non-zero if ANY rank fails)
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["value"] > 0
+    sh = j["config"]["sharding"]
+    assert "dealt round-robin to 2 ranks" in sh and "all-reduce of 17 f64 per iteration" in sh and "gloo" in sh and "rehearsal" in sh
+    assert j["config"]["n_src"] == 50000 and j["breakdown_ms_per_step"]["allreduce"] is None     # (the library all-reduced nothing: gloo)
+    # the two ranks together matched what one rank matches: the same pair, the same transform to float noise
+    one = run(["bench.py", "--size", "50k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert abs(j["transform_error_vs_ground_truth_frobenius"] - one["transform_error_vs_ground_truth_frobenius"]) < 1e-5
+    # without --allow-fallback the same launch refuses to measure another transport than the one the config names: exit code 3
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(int(port) + 1), "bench.py", "--gpus", "2", "--size", "50k", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--devices-per-node", "1"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode != 0 and not [l for l in r.stdout.split("\n") if l.startswith("{")]
 
 
 def test_bench_chain_workload():

@@ -414,7 +414,7 @@ def test_grown_target_is_indexed_as_it_is_now(api, rs, frames):
     time.  A cloud handle that has grown -- in front, behind, by points outside the old box, by exact copies -- must be
     searched as the cloud it is now: matches and transforms those of a fresh context given the same records on the host.
     (Rounds 3-4 merged the new records into the old index instead; it was bit-identical and did not pay,
-    profiles/r04_experiments/README.md: the index is built afresh, rsreg_grid_info.n_updates stays 0.)"""
+    profiles/r04_experiments/README.md: the index is built afresh.)"""
     ctx = api.Context(0)
     prm = dict(max_iterations=3, criteria_mode=1, max_correspondence_distance=0.05)
     src = frames[2]
@@ -466,7 +466,7 @@ def test_grown_target_is_indexed_as_it_is_now(api, rs, frames):
         np.testing.assert_array_equal(i1, i0)
         np.testing.assert_array_equal(d1, d0)
         assert icp.getFinalTransformation().tobytes() == t0
-        assert (g.n_unique_points, g.n_target_points, g.n_cells, g.n_updates) == (g0.n_unique_points, g0.n_target_points, g0.n_cells, 0)
+        assert (g.n_unique_points, g.n_target_points, g.n_cells) == (g0.n_unique_points, g0.n_target_points, g0.n_cells)
     # a cloud rewritten in place (a transform) is indexed again too
     tgt2 = api.DeviceCloud(frames[0], ctx)
     icp.setInputTarget(tgt2)

@@ -188,7 +188,8 @@ int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
 /* icp.setInputSource(cloud) (incremental_icp.hpp:57, icp_edge...hpp:78,108).  The source is put into the
  * engine's order on a stream of its own and joined when the alignment begins: called BEFORE rsreg_icp_set_target
  * (the reference's order) it runs beside the target's index build.  A host buffer is consumed before the call
- * returns; a device buffer must stay alive and unchanged until rsreg_icp_begin / rsreg_icp_align has returned. */
+ * returns (packed into pinned memory; its way over the PCIe link goes on while the caller packs the target); a device
+ * buffer must stay alive and unchanged until rsreg_icp_begin / rsreg_icp_align has returned. */
 int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t stride, int is_dense);
 int rsreg_icp_set_source_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,
                                 int is_dense);
@@ -399,6 +400,18 @@ typedef struct rsreg_grid_info {
     uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
 } rsreg_grid_info;
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
+
+/* Where the HOST-pointer entry points (rsreg_icp_set_source, rsreg_icp_set_target, rsreg_icp_align with aligned_out: the
+ * literal call surface of incremental_icp.hpp:57-63, clouds in host memory in, 4x4 and aligned cloud out) spent the host's
+ * wall clock in their last call, ms.  *_stage_wait: waiting for the staging buffer's previous trip over the link;
+ * *_pack: packing the caller's records into pinned memory and queueing their copies (the copies run meanwhile);
+ * target_build: the index build, behind the target's copy (ends with the host's wait for the build's counts);
+ * align: rsreg_icp_begin .. the last iteration; aligned_copy: the aligned cloud's way home, device -> pinned -> caller. */
+typedef struct rsreg_host_timing {
+    double source_stage_wait, source_pack, target_stage_wait, target_pack, target_build, align, aligned_copy;
+    double reserved;
+} rsreg_host_timing;
+int rsreg_ctx_host_timing(rsreg_ctx *ctx, rsreg_host_timing *out);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
 #include <new>
 #include <thread>
@@ -19,6 +20,7 @@
 
 #include "icp_kernels.hpp"
 #include "icp_dense.hpp"
+#include "cellsort.hpp"
 #include "sort_cfg.hpp"
 
 using namespace rsreg;
@@ -293,6 +295,65 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     return RSREG_OK;
 }
 
+// The same index by counting (cellsort.hpp): no sort, four launches + k_dense_nbr.  For grids a pass over all table
+// entries is cheap for: at most 32 cells per point, or 16 M cells.  RSREG_COUNT_SORT=0: never.
+bool count_sort_pays(size_t n, size_t total)
+{
+    static const bool off = std::getenv("RSREG_COUNT_SORT") && std::getenv("RSREG_COUNT_SORT")[0] == '0';
+    return !off && total <= std::max<size_t>(32 * n, (size_t)16 << 20) && total < (1ull << 31);
+}
+
+int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin)
+{
+    hipStream_t st = ctx->stream;
+    GridParams &gp = ctx->grid;
+    const size_t total = (size_t)(gp.dims[0] + 2) * (gp.dims[1] + 2) * (gp.dims[2] + 2);
+    uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
+    uint32_t *h_counts = ctx->h_smisc.as<uint32_t>() + 40;   // pinned words of the counts' own
+    // the counts are zero between builds (k_cc_scan puts them back); a new or larger buffer, or a build that did not
+    // get to its end, starts from a memset
+    RSREG_HIP(ctx, ctx->d_cnt.reserve((total + 16) * 4 + 2 * (size_t)kCcMaxSpans * 8));
+    if (ctx->cnt_zero_ptr != ctx->d_cnt.ptr || ctx->cnt_zero_cap != ctx->d_cnt.cap || ctx->cnt_dirty) {
+        RSREG_HIP(ctx, hipMemsetAsync(ctx->d_cnt.ptr, 0, ctx->d_cnt.cap, st));
+        ctx->cnt_zero_ptr = ctx->d_cnt.ptr;
+        ctx->cnt_zero_cap = ctx->d_cnt.cap;
+    }
+    ctx->cnt_dirty = true;
+    RSREG_HIP(ctx, ctx->d_arrived.reserve(((size_t)nfin + 8) * sizeof(float4)));
+    const DenseDev g = dense_dev(ctx, max_dist);
+    uint32_t *cnt = ctx->d_cnt.as<uint32_t>() + 4u * kCcMaxSpans, *rank = ctx->d_vals.as<uint32_t>();   // (behind the two sets of per-span totals)
+    uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
+    uint32_t *table = ctx->d_dense.as<uint32_t>(), *occ = table + (total + 2);
+    uint32_t *stats = d_misc + 8;
+    // per-span totals of the counts (what k_cc_scan's workgroups start from): two sets used in turn, each cleared by the
+    // counting kernel of the build before the one that fills it; they lie in front of the counts (zeroed with them)
+    const uint32_t chunks = cc_span_chunks(total), spans = cc_spans(total), span = chunks * kCcChunk;
+    auto *coarse_all = ctx->d_cnt.as<unsigned long long>();   // (at the head of the buffer, wherever the table ends)
+    unsigned long long *coarse = coarse_all + (size_t)(ctx->cnt_flip ? kCcMaxSpans : 0), *coarse_next = coarse_all + (size_t)(ctx->cnt_flip ? 0 : kCcMaxSpans);
+    ctx->cnt_flip = !ctx->cnt_flip;
+    const uint32_t count_blocks = div_up((uint32_t)n, kCcTile);
+    // the occupancy words are cleared by the counting kernel on its way, unless that would be more than 64 words a thread
+    const bool occ_on_the_way = (total + 2) <= 64ull * count_blocks * kCcBlock;
+    if (!occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(occ, 0, (total + 2) * 4, st));
+    k_cc_count<<<count_blocks, kCcBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, cnt, rank, coarse, span, occ_on_the_way ? occ : nullptr,
+                                                   occ_on_the_way ? (uint32_t)(total + 2) : 0u, reinterpret_cast<uint32_t *>(coarse_next), 2u * kCcMaxSpans);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_cc_scan<<<spans, kCcScanBlock, 0, st>>>(cnt, (uint32_t)total, chunks, coarse, table, cellslot, cellpos, stats, h_counts);
+    RSREG_HIP(ctx, hipGetLastError());
+    k_cc_scatter<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>());
+    RSREG_HIP(ctx, hipGetLastError());
+    const uint32_t nbf = div_up(nfin, kBlock);
+    k_cc_small<<<nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
+    RSREG_HIP(ctx, hipGetLastError());
+    // (a lane per occupied cell -- at most one per finite point --, a wave per crowded one)
+    k_cc_big<<<nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, cellslot, cellpos, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
+    RSREG_HIP(ctx, hipGetLastError());
+    // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
+    k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, stats, g.sx, g.sxy, occ);
+    RSREG_HIP(ctx, hipGetLastError());
+    return RSREG_OK;
+}
+
 int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, hipEvent_t ev0,
                 hipEvent_t ev1)
 {
@@ -319,14 +380,27 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     // the searches of gates up to four cells go through the occupancy words only (icp_dense.hpp: dense_far_blocks);
     // the row search of wider or unbounded gates reads table entries of empty cells too and needs all of them
     gp.table_sparse = (gp.max_ring <= 4 && !full_table && !std::getenv("RSREG_FAR_ROWS")) ? 1 : 0;
-    int rc = narrow ? build_dense_keyed<uint32_t>(ctx, d_pts, n, stride, max_dist, nfin, id_bits)
-                    : build_dense_keyed<unsigned long long>(ctx, d_pts, n, stride, max_dist, nfin, id_bits);
-    if (rc) return rc;
-    if (ctx->profiling) (void)hipEventRecord(ev1, st);
-    RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in pinned words of their own)
     const uint32_t *h_counts = ctx->h_smisc.as<uint32_t>() + 40;
-    gp.n_cells = h_counts[0];
-    gp.n_points = h_counts[2];
+    const bool counted = count_sort_pays(n, total);
+    if (counted) {
+        gp.xbits = (int)kCcXBits;   // what the crowded cells are ordered by (g.x_slack follows)
+        gp.table_sparse = 0;        // every table entry is written
+        int rc = build_dense_counted(ctx, d_pts, n, stride, max_dist, nfin);
+        if (rc) return rc;
+        if (ctx->profiling) (void)hipEventRecord(ev1, st);
+        RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the counts lie in pinned words of their own)
+        ctx->cnt_dirty = false;
+        gp.n_cells = h_counts[0];
+        gp.n_points = h_counts[1];
+    } else {
+        int rc = narrow ? build_dense_keyed<uint32_t>(ctx, d_pts, n, stride, max_dist, nfin, id_bits)
+                        : build_dense_keyed<unsigned long long>(ctx, d_pts, n, stride, max_dist, nfin, id_bits);
+        if (rc) return rc;
+        if (ctx->profiling) (void)hipEventRecord(ev1, st);
+        RSREG_HIP(ctx, hipStreamSynchronize(st));   // (the scatter kernel left the two counts in pinned words of their own)
+        gp.n_cells = h_counts[0];
+        gp.n_points = h_counts[2];
+    }
     gp.n_bricks = 0;
     rsreg_grid_info &gi = ctx->grid_info;
     for (int k = 0; k < 3; ++k) { gi.origin[k] = gp.origin[k]; gi.dims[k] = gp.dims[k]; }
@@ -642,10 +716,11 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         MortonBits mb{0, 0, 0};
         bool narrow = false;
         if (!wide_keys) {
-            for (double c = cell; c <= 2.0 * (double)cell + 1e-12; c *= 1.05) {
+            static const int morton_bits = std::getenv("RSREG_MORTON_BITS") ? std::max(6, std::min(31, std::atoi(std::getenv("RSREG_MORTON_BITS")))) : 24;
+            for (double c = cell; c <= (morton_bits < 31 ? 64.0 : 2.0) * (double)cell + 1e-12; c *= 1.05) {
                 mb = MortonBits{axis_bits_of((double)mx[0] - (double)mn[0], c), axis_bits_of((double)mx[1] - (double)mn[1], c),
                                 axis_bits_of((double)mx[2] - (double)mn[2], c)};
-                if (mb.x + mb.y + mb.z <= 31 && std::max(mb.x, std::max(mb.y, mb.z)) <= 12) {
+                if (mb.x + mb.y + mb.z <= morton_bits && std::max(mb.x, std::max(mb.y, mb.z)) <= 12) {
                     narrow = true;
                     cell = (float)c;
                     break;
@@ -1407,6 +1482,44 @@ int update_from_sums(rsreg_ctx *ctx, const double *sums, int *done)
     return RSREG_OK;
 }
 
+// A host cloud on its way into HBM, packed xyz (PCL's ICP reads nothing else of a point): the caller's records are
+// packed into pinned memory piece by piece (the pool of host threads, workers.hpp) and every piece goes over the PCIe link
+// on the context's upload stream while the next one is being packed; `stage` / `ev`: the staging buffer of this kind of
+// cloud (source / target: one each, so that the target is packed while the source is still on the link) and the event behind
+// its last piece.  The stream `waiter` is made to wait for that event; the caller's buffer has been read when this returns.
+int upload_packed(rsreg_ctx *ctx, PinnedBuf &stage, hipEvent_t &ev, DevBuf &d_raw, const void *points, size_t n, size_t stride,
+                  hipStream_t waiter, double *ms_pack, double *ms_wait)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    if (!ctx->stream_h2d) RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_h2d, hipStreamNonBlocking));
+    if (!ev) RSREG_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else RSREG_HIP(ctx, hipEventSynchronize(ev));   // (the staging buffer's last trip over the link is over)
+    const auto t1 = clk::now();
+    RSREG_HIP(ctx, stage.reserve(n * 12 + 16));
+    RSREG_HIP(ctx, d_raw.reserve(n * 12 + 16));
+    float *dst = stage.as<float>();
+    const char *src = static_cast<const char *>(points);
+    const size_t piece = (size_t)1 << 18;   // 3 MB of packed xyz: ~0.1 ms on the link
+    for (size_t lo = 0; lo < n; lo += piece) {
+        const size_t hi = std::min(n, lo + piece);
+        host_parallel_for(hi - lo, [=](size_t a, size_t b) {
+            if (stride == 12) {
+                std::memcpy(dst + 3 * (lo + a), src + 12 * (lo + a), (b - a) * 12);
+            } else {
+                for (size_t i = lo + a; i < lo + b; ++i) std::memcpy(dst + 3 * i, src + i * stride, 12);
+            }
+        });
+        RSREG_HIP(ctx, hipMemcpyAsync(d_raw.as<char>() + lo * 12, dst + 3 * lo, (hi - lo) * 12, hipMemcpyHostToDevice, ctx->stream_h2d));
+    }
+    RSREG_HIP(ctx, hipEventRecord(ev, ctx->stream_h2d));
+    RSREG_HIP(ctx, hipStreamWaitEvent(waiter, ev, 0));
+    const auto t2 = clk::now();
+    if (ms_wait) *ms_wait = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (ms_pack) *ms_pack = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    return RSREG_OK;
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -1510,7 +1623,13 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
-                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys};
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys, &ctx->d_cnt, &ctx->d_arrived};
+    if (ctx->stream_h2d) { (void)hipStreamSynchronize(ctx->stream_h2d); (void)hipStreamDestroy(ctx->stream_h2d); }
+    ctx->h_stage_src.release();
+    ctx->h_stage_tgt.release();
+    if (ctx->ev_stage_src) (void)hipEventDestroy(ctx->ev_stage_src);
+    if (ctx->ev_stage_tgt) (void)hipEventDestroy(ctx->ev_stage_tgt);
+    for (hipEvent_t e : ctx->ev_home) (void)hipEventDestroy(e);
     for (DevBuf *b : bufs) b->release();
     ctx->h_sums.release();
     ctx->h_smisc.release();
@@ -1628,11 +1747,13 @@ int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     (void)is_dense;
     if (!ctx || (n && !points) || stride < 12) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = pack_to_stage(ctx, points, n, stride);
+    rsreg_host_timing &ht = ctx->host_timing;
+    int rc = upload_packed(ctx, ctx->h_stage_tgt, ctx->ev_stage_tgt, ctx->d_tgt_raw, points, n, stride, ctx->stream, &ht.target_pack, &ht.target_stage_wait);
     if (rc) return rc;
-    RSREG_HIP(ctx, ctx->d_tgt_raw.reserve(n * 12 + 16));
-    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tgt_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
-    return build_grid(ctx, ctx->d_tgt_raw.as<char>(), n, 12, max_correspondence_distance);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = build_grid(ctx, ctx->d_tgt_raw.as<char>(), n, 12, max_correspondence_distance);   // (behind the upload, by the stream's order)
+    ht.target_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 int rsreg_icp_set_source_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride, int is_dense)
@@ -1650,15 +1771,13 @@ int rsreg_icp_set_source(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     int rc = join_source(ctx);   // (a load still in flight reads d_src_raw)
     if (rc) return rc;
-    rc = pack_to_stage(ctx, points, n, stride);
+    // packed and sent piece by piece on the upload stream; the load itself (stream_src, the worker thread) starts behind the
+    // event the main stream is made to wait for.  Nothing is waited for here: the caller goes on to rsreg_icp_set_target,
+    // whose cloud is packed (into a staging buffer of its own) while this one is on the link and being sorted
+    rsreg_host_timing &ht = ctx->host_timing;
+    rc = upload_packed(ctx, ctx->h_stage_src, ctx->ev_stage_src, ctx->d_src_raw, points, n, stride, ctx->stream, &ht.source_pack, &ht.source_stage_wait);
     if (rc) return rc;
-    RSREG_HIP(ctx, ctx->d_src_raw.reserve(n * 12 + 16));
-    if (n) RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_src_raw.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
-    rc = load_source(ctx, ctx->d_src_raw.as<char>(), n, 12);
-    if (rc) return rc;
-    // the pinned staging buffer is reused by the next call: drain the copy first
-    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RSREG_OK;
+    return load_source(ctx, ctx->d_src_raw.as<char>(), n, 12);
 }
 
 int rsreg_icp_begin(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params)
@@ -1768,7 +1887,34 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         k_apply_final<<<div_up((uint32_t)n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, to_mat34(s.final_t),
                                                                                 ctx->d_perm.as<uint32_t>(), ctx->d_tmp.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.ptr, ctx->d_tmp.ptr, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+        // home in pieces: while piece k + 1 is on the link, piece k is written into the caller's records by the host's threads
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t piece = (size_t)1 << 18;
+        const size_t pieces = (n + piece - 1) / piece;
+        while (ctx->ev_home.size() < pieces) {
+            hipEvent_t e;
+            RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_home.push_back(e);
+        }
+        for (size_t k = 0; k < pieces; ++k) {
+            const size_t lo = k * piece, hi = std::min(n, lo + piece);
+            RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_stage.as<char>() + lo * 12, ctx->d_tmp.as<char>() + lo * 12, (hi - lo) * 12, hipMemcpyDeviceToHost, ctx->stream));
+            RSREG_HIP(ctx, hipEventRecord(ctx->ev_home[k], ctx->stream));
+        }
+        const float *src = ctx->h_stage.as<float>();
+        char *dst = static_cast<char *>(aligned_out);
+        for (size_t k = 0; k < pieces; ++k) {
+            const size_t lo = k * piece, hi = std::min(n, lo + piece);
+            RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_home[k]));
+            host_parallel_for(hi - lo, [=](size_t a, size_t b) {
+                const float one = 1.0f;
+                for (size_t i = lo + a; i < lo + b; ++i) {
+                    std::memcpy(dst + i * out_stride, src + 3 * i, 12);
+                    if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
+                }
+            });
+        }
+        ctx->host_timing.aligned_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (const char *sd_path = std::getenv("RSREG_DUMP_SEED")) {   // dev: the position every query matched last, and the queries
@@ -1799,17 +1945,6 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
                 std::fclose(f);
             }
         }
-    }
-    if (aligned_out && n) {
-        const float *src = ctx->h_stage.as<float>();
-        char *dst = static_cast<char *>(aligned_out);
-        host_parallel_for(n, [=](size_t lo, size_t hi) {
-            const float one = 1.0f;
-            for (size_t i = lo; i < hi; ++i) {
-                std::memcpy(dst + i * out_stride, src + 3 * i, 12);
-                if (out_stride >= 16) std::memcpy(dst + i * out_stride + 12, &one, 4);
-            }
-        });
     }
     if (result) {
         std::memset(result, 0, sizeof(*result));
@@ -1848,9 +1983,23 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     return RSREG_OK;
 }
 
+int rsreg_ctx_host_timing(rsreg_ctx *ctx, rsreg_host_timing *out)
+{
+    if (!ctx || !out) return RSREG_ERR_INVALID_ARG;
+    *out = ctx->host_timing;
+    return RSREG_OK;
+}
+
 int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result,
                     void *aligned_out, size_t out_stride)
 {
+    const auto t_align0 = std::chrono::steady_clock::now();
+    struct AlignClock {   // (whatever way the call ends: begin .. the last iteration + the aligned cloud's way home)
+        rsreg_ctx *c;
+        std::chrono::steady_clock::time_point t0;
+        ~AlignClock() { if (c) c->host_timing.align = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - c->host_timing.aligned_copy; }
+    } align_clock{ctx, t_align0};
+    if (ctx) ctx->host_timing.aligned_copy = 0;
     int rc = rsreg_icp_begin(ctx, guess, params);
     if (rc) return rc;
     int done = 0;

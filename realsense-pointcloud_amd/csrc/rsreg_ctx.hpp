@@ -157,6 +157,12 @@ struct rsreg_ctx {
     rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items (4 per tile) | wave costs | done counters | sort scratch
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
+    rsreg::DevBuf d_cnt;          // counting build (cellsort.hpp): points per table slot, all zero between builds
+    rsreg::DevBuf d_arrived;      // ... and the records in arrival order, cell by cell
+    void *cnt_zero_ptr = nullptr;
+    size_t cnt_zero_cap = 0;
+    bool cnt_flip = false;        // which of the two sets of per-span totals the next counting build fills
+    bool cnt_dirty = false;       // a counting build is under way (or did not finish): the counts are not known to be zero
     size_t n_target_raw = 0;
 
     // ---- ICP source
@@ -198,6 +204,12 @@ struct rsreg_ctx {
     rsreg::CloudBox next_tgt_box, last_tgt_box, next_src_box, last_src_box;
 
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
+    // host clouds of rsreg_icp_set_source / _set_target: a staging buffer each, the upload stream, the event behind each buffer's last copy
+    rsreg::PinnedBuf h_stage_src, h_stage_tgt;
+    hipStream_t stream_h2d = nullptr;
+    hipEvent_t ev_stage_src = nullptr, ev_stage_tgt = nullptr;
+    rsreg_host_timing host_timing{};
+    std::vector<hipEvent_t> ev_home;   // one per piece of an aligned cloud on its way to the host (rsreg_icp_end)
     rsreg::IcpState icp;
 
     // ---- ApproximateVoxelGrid on the device (voxel.hip)
@@ -280,20 +292,12 @@ inline int fail(rsreg_ctx *ctx, int code, const char *what, hipError_t e = hipSu
 }
 
 // Host-side record loops (32-byte AoS records <-> packed xyz in pinned staging) are memory-bound
-// copies of tens of MB: split them over a few threads.  f(lo, hi) handles records [lo, hi).
+// copies of tens of MB: split over the process's pool of host threads (workers.hpp).  f(lo, hi) handles records [lo, hi).
 template <typename F> inline void host_parallel_for(size_t n, F f)
 {
-    static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    const unsigned nt = (unsigned)std::min<size_t>(hw, n / 65536 + 1);
-    if (nt <= 1) {
-        f((size_t)0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    th.reserve(nt - 1);
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
-    f((size_t)0, n / nt);
-    for (auto &t : th) t.join();
+    const size_t pieces = std::min<size_t>(n / 32768 + 1, 4 * (host_pool().th.size() + 1));
+    const std::function<void(size_t, size_t)> fn = f;
+    host_pool().run(n, pieces, fn);
 }
 
 // 32-byte (or any stride) AoS records -> packed xyz in the pinned staging buffer

@@ -227,4 +227,73 @@ struct TicketWorker {
     }
 };
 
+
+// Host-side record loops (32-byte records <-> packed xyz in pinned staging, staging <-> the caller's memory) are memory-bound
+// copies of tens of MB that want a handful of cores for a fraction of a millisecond: the threads are kept (starting eight
+// threads costs as much as the copy they are started for).  One loop at a time, process-wide; the caller's thread works too.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m, call_m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(size_t, size_t)> *f = nullptr;
+    size_t n = 0, parts = 0, next = 0, running = 0;
+    bool stop = false;
+
+    explicit HostPool(unsigned workers)
+    {
+        for (unsigned k = 0; k < workers; ++k) th.emplace_back([this] { loop(); });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    // (m held) runs parts until none is left; returns with m held
+    void work(std::unique_lock<std::mutex> &lk)
+    {
+        while (f && next < parts) {
+            const size_t p = next++;
+            const std::function<void(size_t, size_t)> *g = f;
+            const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
+            ++running;
+            lk.unlock();
+            if (lo < hi) (*g)(lo, hi);
+            lk.lock();
+            if (--running == 0 && next >= parts) cv_done.notify_all();
+        }
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (f && next < parts); });
+            if (stop) return;
+            work(lk);
+        }
+    }
+    // f(lo, hi) over [0, count) in `pieces` pieces (more pieces than threads: a slow thread does not hold the others up)
+    void run(size_t count, size_t pieces, const std::function<void(size_t, size_t)> &fn)
+    {
+        if (count == 0) return;
+        if (pieces <= 1 || th.empty()) { fn(0, count); return; }
+        std::lock_guard<std::mutex> one(call_m);
+        std::unique_lock<std::mutex> lk(m);
+        f = &fn; n = count; parts = pieces; next = 0;
+        cv.notify_all();
+        work(lk);
+        cv_done.wait(lk, [&] { return running == 0 && next >= parts; });
+        f = nullptr;
+    }
+};
+
+inline HostPool &host_pool()
+{
+    static HostPool pool(std::max(1u, std::min(16u, std::thread::hardware_concurrency())) - 1u);
+    return pool;
+}
+
 }  // namespace rsreg

@@ -33,7 +33,7 @@ EXPORTS = [
     "rsreg_icp_set_target_cloud", "rsreg_icp_target_is_cloud", "rsreg_icp_set_source_cloud", "rsreg_icp_align_cloud", "rsreg_ndt_set_target_cloud",
     "rsreg_ndt_align_cloud", "rsreg_ndt_set_target_device", "rsreg_ndt_align_device",
     "rsreg_extract_edge_features", "rsreg_cloud_edge_features", "rsreg_cloud_edge_features_async",
-    "rsreg_icp_grid_info", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
+    "rsreg_icp_grid_info", "rsreg_ctx_host_timing", "rsreg_lzf_max_encoded_size", "rsreg_lzf_encode", "rsreg_lzf_decode",
 ]
 
 
@@ -85,6 +85,11 @@ class GridInfo(C.Structure):
         ("max_points_per_cell", C.c_uint32), ("ms_build", C.c_double),
         ("index_kind", C.c_uint32), ("n_source_distinct", C.c_uint32), ("index_bytes", C.c_uint64),
     ]
+
+
+class HostTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("source_stage_wait", "source_pack", "target_stage_wait", "target_pack", "target_build", "align",
+                                           "aligned_copy", "reserved")]
 
 
 def hipcc_command(out=SO_PATH):
@@ -203,6 +208,7 @@ def lib():
     L.rsreg_comm_destroy.argtypes = [vp]
     L.rsreg_comm_allreduce_f64.argtypes = [vp, vp, i32]
     L.rsreg_icp_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    L.rsreg_ctx_host_timing.argtypes = [vp, C.POINTER(HostTiming)]
     u32 = C.c_uint32
     L.rsreg_cloud_create.argtypes = [vp, C.POINTER(vp)]
     L.rsreg_cloud_destroy.argtypes = [vp]

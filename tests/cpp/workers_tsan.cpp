@@ -131,8 +131,38 @@ static void download_worker()
     w.shutdown();
 }
 
+// the pool of host threads behind host_parallel_for: loops from several caller threads at once, every element exactly once
+static void host_pool_loops()
+{
+    HostPool pool(5);
+    std::vector<std::thread> callers;
+    std::atomic<long long> grand{0};
+    for (int c = 0; c < 3; ++c)
+        callers.emplace_back([&, c] {
+            for (int k = 0; k < 60; ++k) {
+                const size_t n = (size_t)(1000 + 7919 * k + c);
+                std::vector<unsigned char> hit(n, 0);
+                const std::function<void(size_t, size_t)> fn = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) ++hit[i]; };
+                pool.run(n, 1 + (size_t)(k % 23), fn);
+                long long sum = 0;
+                for (unsigned char h : hit) { REQUIRE(h == 1); sum += h; }
+                grand += sum;
+            }
+        });
+    for (auto &t : callers) t.join();
+    REQUIRE(grand > 0);
+    HostPool none(0);   // no worker at all: the caller's thread does the loop
+    int ran = 0;
+    const std::function<void(size_t, size_t)> one = [&](size_t lo, size_t hi) { ran += (int)(hi - lo); };
+    none.run(10, 4, one);
+    REQUIRE(ran == 10);
+    none.run(0, 4, one);
+    REQUIRE(ran == 10);
+}
+
 int main()
 {
+    host_pool_loops();
     source_worker();
     ticket_worker();
     download_worker();

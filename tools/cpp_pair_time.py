@@ -16,10 +16,11 @@ exe = os.path.join(out, "pair_time")
 pkg = os.path.join(ROOT, "realsense-pointcloud_amd")
 subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "pair_time.cpp"), "-o", exe,
                 "-L", pkg, "-lrsreg", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
-for size in sys.argv[1:] or ["N1M", "N300", "50k"]:
+host = "--host" in sys.argv
+for size in [a for a in sys.argv[1:] if not a.startswith("--")] or ["N1M", "N300", "50k"]:
     t, s = synth.render_frame(0, size, "parity"), synth.render_frame(1, size, "parity")
     with tempfile.TemporaryDirectory() as d:
         pt, ps = os.path.join(d, "t.f32"), os.path.join(d, "s.f32")
         t.points.tofile(pt)
         s.points.tofile(ps)
-        subprocess.run([exe, pt, ps, str(len(t.points)), str(len(s.points))], check=True)
+        subprocess.run([exe, pt, ps, str(len(t.points)), str(len(s.points))] + (["host"] if host else []), check=True)

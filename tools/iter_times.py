@@ -17,6 +17,10 @@ if "x" in size:
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 pipeline = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 tgt, src = synth.render_frame(0, size, "bench"), synth.render_frame(1, size, "bench")
+if os.environ.get("ITER_SHUFFLE"):   # both clouds in random order (an unorganized cloud: what the source's spatial sort is for)
+    rng = np.random.default_rng(5)
+    tgt = rsreg_amd.PointCloud(tgt.points[rng.permutation(len(tgt))], width=len(tgt), height=1, is_dense=False)
+    src = rsreg_amd.PointCloud(src.points[rng.permutation(len(src))], width=len(src), height=1, is_dense=False)
 guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
 icp = api.IterativeClosestPoint(api.Context(0, profiling=True))
 icp.params = api.icp_params(max_iterations=iters, criteria_mode=1, pipeline_mode=pipeline, max_correspondence_distance=0.05)

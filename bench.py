@@ -656,6 +656,35 @@ def main():
         pair(t, s_)
         ctx.synchronize()
         ctx.set_profiling(False)
+        # the literal call surface from C++ (tools/cpp/pair_time.cpp, host mode: rsreg_icp_set_source / _set_target / rsreg_icp_align with
+        # aligned_out on host clouds, no Python between the calls), with the library's own account of the host's time
+        cpp = None
+        try:
+            import subprocess
+            import tempfile
+
+            exe = os.path.join(ROOT, "tools", "_build", "pair_time")
+            pkg = os.path.dirname(lib.SO_PATH)
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            src_cpp = os.path.join(ROOT, "tools", "cpp", "pair_time.cpp")
+            if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src_cpp), os.path.getmtime(os.path.join(ROOT, "include", "rsreg.h"))):
+                subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src_cpp, "-o", exe, "-L", pkg, "-lrsreg",
+                                "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True, capture_output=True)
+            with tempfile.TemporaryDirectory() as d:
+                pt, ps = os.path.join(d, "t.f32"), os.path.join(d, "s.f32")
+                tp.points.tofile(pt)
+                sp.points.tofile(ps)
+                r = subprocess.run([exe, pt, ps, str(len(tp.points)), str(len(sp.points)), "host"], capture_output=True, text=True, timeout=300, check=True)
+            cpp = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:  # noqa: BLE001  (no g++ on the box, ...: the line says so instead of failing the bench)
+            cpp = {"error": str(e)[:200]}
+        # the CPU side of THIS mode: the port's kd-tree build + the one iteration the reference's parameters run, 1 thread
+        o_ref = oracle.IcpOracle()
+        tcr = time.perf_counter()
+        o_ref.set_target(tp.points)
+        o_ref.set_source(sp.points)
+        r_ref = o_ref.align(None, oracle.IcpParams.reference())
+        cpu_ref_s = time.perf_counter() - tcr
         out["reference_mode"] = {
             "workload": "icp_pair_%sx%s reference parameters (100 max iterations, 1 cm gate, eps 1 / 1000 -> 1 iteration)" % (a.size, a.size),
             "iterations": int(ref.result.iterations), "n_correspondences": int(ref.result.n_correspondences),
@@ -665,6 +694,11 @@ def main():
             "same_transform": bool((modes["host_clouds_T"] == modes["device_clouds_T"]).all()),
             # what the reference's one iteration per align runs: the first, unseeded and unscheduled search launch
             "first_launch_us": (float(ref.result.ms_nn) / max(int(ref.result.n_nn_launches), 1) * 1e3) if ref.result.ms_nn > 0 else None,
+            "ms_per_pair_host_clouds_cpp": cpp.get("ms_per_pair") if cpp else None,
+            "host_clouds_cpp": cpp,
+            "cpu_baseline": {"ms_per_pair": cpu_ref_s * 1e3, "value": float(len(sp)) * int(r_ref.iterations) / cpu_ref_s, "unit": "point-pairs/s", "cores": 1,
+                             "kind": "port", "sample": "the same pair: kd-tree build + %d iteration(s), 1 thread" % int(r_ref.iterations),
+                             "transform_error_vs_cpu_frobenius": float(np.linalg.norm(modes["device_clouds_T"] - r_ref.T))},
         }
     gt = synth.ground_truth(1, 0, "bench")
     out["transform_error_vs_ground_truth_frobenius"] = float(np.linalg.norm(T_gpu - gt))

@@ -68,15 +68,16 @@ constexpr uint32_t kCcScanBlock = 256, kCcChunk = kCcScanBlock * kCcScanItems, k
 inline uint32_t cc_span_chunks(size_t slots) { return (uint32_t)std::max<size_t>(1, (slots + (size_t)kCcChunk * kCcMaxSpans - 1) / ((size_t)kCcChunk * kCcMaxSpans)); }
 inline uint32_t cc_spans(size_t slots) { const size_t span = (size_t)kCcChunk * cc_span_chunks(slots); return (uint32_t)((slots + span - 1) / span); }
 
-// stats (device words): [0] occupied cells, [1] records in the sorted array
+// stats (device words): [0] occupied cells, [1] records in the sorted array, [2] crowded cells (entries of `big`)
 __global__ __launch_bounds__(kCcBlock) void k_cc_count(const char *pts, size_t stride, uint32_t n, DenseDev g, uint32_t *gcnt, uint32_t *rank,
-                                                       unsigned long long *coarse, uint32_t span, uint32_t *clear_a, uint32_t clear_a_words, uint32_t *clear_b, uint32_t clear_b_words)
+                                                       unsigned long long *coarse, uint32_t span, uint32_t *clear_a, uint32_t clear_a_words, uint32_t *clear_b, uint32_t clear_b_words, uint32_t *stats)
 {
     __shared__ uint32_t s_key[kCcHash], s_min[kCcHash], s_hash[kCcHash];
     const uint32_t t = threadIdx.x, gt = blockIdx.x * kCcBlock + t, gthreads = gridDim.x * kCcBlock;
     // on the way: the occupancy words k_dense_nbr will OR together, and the coarse totals of the NEXT build
     if (clear_a) radix32_clear(clear_a, clear_a_words, gt, gthreads);
     if (clear_b) radix32_clear(clear_b, clear_b_words, gt, gthreads);
+    if (gt == 0) stats[2] = 0u;
     for (uint32_t h = t; h < kCcHash; h += kCcBlock) { s_key[h] = kCcEmpty; s_min[h] = 0xffffffffu; }
     __syncthreads();
     const uint32_t i0 = blockIdx.x * kCcTile + t;
@@ -157,10 +158,11 @@ __global__ __launch_bounds__(kCcBlock) void k_cc_count(const char *pts, size_t s
 
 // One pass over the counts of all `slots` table entries: table[slot] = first record of EVERY cell (so a cell's end is the
 // entry behind it, and the row search of unbounded gates finds empty cells' entries valid too), the occupied cells' slots and
-// first records in slot order (cellslot / cellpos), and the counts back to zero.  Everything a workgroup reads and writes of the table and the counts is one contiguous piece.
+// first records in slot order (cellslot / cellpos), the slots of the cells beyond kCcSmall records (`big`, in any order),
+// and the counts back to zero.  Everything a workgroup reads and writes of the table and the counts is one contiguous piece.
 // coarse[b]: points | occupied cells << 32 of span b (k_cc_count); chunks: kCcChunk-entry pieces per span.
 __global__ __launch_bounds__(kCcScanBlock) void k_cc_scan(uint32_t *gcnt, uint32_t slots, uint32_t chunks, const unsigned long long *coarse, uint32_t *table,
-                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *stats, uint32_t *host_stats)
+                                                          uint32_t *cellslot, uint32_t *cellpos, uint32_t *big, uint32_t *stats, uint32_t *host_stats)
 {
     __shared__ unsigned long long s_wave[kCcScanBlock / 64];
     __shared__ unsigned long long s_front[kCcScanBlock / 64];
@@ -237,6 +239,25 @@ __global__ __launch_bounds__(kCcScanBlock) void k_cc_scan(uint32_t *gcnt, uint32
                 table[slots] = nrec;
             }
         }
+        // the crowded cells (k_cc_big takes them one wave each) are listed in any order: a wave pools its own and takes one
+        // place in the list for all of them (same-address atomics from every thread would queue up behind each other)
+        uint32_t nb = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kCcScanItems; ++j) nb += (i0 + j < slots && v[j] > kCcSmall) ? 1u : 0u;
+        if (__any(nb != 0u)) {
+            uint32_t incl = nb;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += o;
+            }
+            uint32_t at_list = 0;
+            if (lane == 63u) at_list = atomicAdd(&stats[2], incl);
+            at_list = __shfl(at_list, 63) + incl - nb;
+#pragma unroll
+            for (uint32_t j = 0; j < kCcScanItems; ++j)
+                if (i0 + j < slots && v[j] > kCcSmall) big[at_list++] = i0 + j;
+        }
 #pragma unroll
         for (uint32_t q4 = 0; q4 < kCcScanItems / 4; ++q4) {
             const uint32_t at = i0 + 4u * q4;
@@ -293,24 +314,19 @@ __global__ __launch_bounds__(kBlock) void k_cc_small(const float4 *arrived, Dens
     pos_of[idx] = s + before;
 }
 
-// The crowded cells (more than kCcSmall records), one wave per cell: count the cell's records per x bucket (kCcXBits bits)
-// in LDS, scan the 256 counts, place every record behind the buckets before its own, in arrival order inside a bucket.
-// A wave looks at 64 occupied cells at a time (a lane each) and takes the crowded ones among them in turn.
-__global__ __launch_bounds__(kBlock) void k_cc_big(const float4 *arrived, DenseDev g, const uint32_t *cellslot, const uint32_t *cellpos, float4 *sorted,
+// The crowded cells (more than kCcSmall records: `big`, k_cc_scan's list), one wave per cell: count the cell's records per
+// x bucket (kCcXBits bits) in LDS, scan the 256 counts, place every record behind the buckets before its own, in arrival
+// order inside a bucket.
+__global__ __launch_bounds__(kBlock) void k_cc_big(const float4 *arrived, DenseDev g, const uint32_t *table, const uint32_t *big, float4 *sorted,
                                                    uint32_t *pos_of, const uint32_t *stats)
 {
     constexpr uint32_t kBins = 1u << kCcXBits;
     __shared__ uint32_t s_bin[kBlock / 64][kBins];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nc = stats[0];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nbig = stats[2];
     uint32_t *bin = s_bin[wave];
-    const uint32_t c = (blockIdx.x * (kBlock / 64) + wave) * 64u + lane;
-    uint32_t my_s = 0, my_e = 0, my_slot = 0;
-    if (c < nc) { my_s = cellpos[c]; my_e = cellpos[c + 1u]; my_slot = cellslot[c]; }
-    unsigned long long todo = __ballot(my_e - my_s > kCcSmall);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const uint32_t s = __shfl(my_s, src), e = __shfl(my_e, src), slot = __shfl(my_slot, src);
+    for (uint32_t c = blockIdx.x * (kBlock / 64) + wave; c < nbig; c += gridDim.x * (kBlock / 64)) {
+        const uint32_t slot = big[c];
+        const uint32_t s = table[slot], e = table[slot + 1u];
         // (the slot's x coordinate: the padded table's index is ((z + 1) * (ny + 2) + (y + 1)) * (nx + 2) + (x + 1))
         const int cx = (int)(slot % (uint32_t)(g.nx + 2)) - 1;
         for (uint32_t b = lane; b < kBins; b += 64u) bin[b] = 0u;

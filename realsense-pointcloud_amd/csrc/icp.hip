@@ -250,7 +250,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
     RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
     // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
-    const bool start_in_out = own_sort && plan.places % 2 == 0;
+    const bool start_in_out = own_sort && plan.ends_in_first;
     k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, start_in_out ? keys2 : keys,
                                                                        start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
                                                                        own_sort ? scratch_words : 0u, occ_on_the_way ? table + (total + 2) : nullptr,
@@ -324,6 +324,7 @@ int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stri
     uint32_t *cnt = ctx->d_cnt.as<uint32_t>() + 4u * kCcMaxSpans, *rank = ctx->d_vals.as<uint32_t>();   // (behind the two sets of per-span totals)
     uint32_t *cellslot = ctx->d_brick.as<uint32_t>(), *cellpos = ctx->d_cellpos.as<uint32_t>();
     uint32_t *table = ctx->d_dense.as<uint32_t>(), *occ = table + (total + 2);
+    uint32_t *big = ctx->d_flags.as<uint32_t>();   // (n * 8 bytes: room for every cell beyond kCcSmall records)
     uint32_t *stats = d_misc + 8;
     // per-span totals of the counts (what k_cc_scan's workgroups start from): two sets used in turn, each cleared by the
     // counting kernel of the build before the one that fills it; they lie in front of the counts (zeroed with them)
@@ -336,17 +337,18 @@ int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stri
     const bool occ_on_the_way = (total + 2) <= 64ull * count_blocks * kCcBlock;
     if (!occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(occ, 0, (total + 2) * 4, st));
     k_cc_count<<<count_blocks, kCcBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, cnt, rank, coarse, span, occ_on_the_way ? occ : nullptr,
-                                                   occ_on_the_way ? (uint32_t)(total + 2) : 0u, reinterpret_cast<uint32_t *>(coarse_next), 2u * kCcMaxSpans);
+                                                   occ_on_the_way ? (uint32_t)(total + 2) : 0u, reinterpret_cast<uint32_t *>(coarse_next), 2u * kCcMaxSpans, stats);
     RSREG_HIP(ctx, hipGetLastError());
-    k_cc_scan<<<spans, kCcScanBlock, 0, st>>>(cnt, (uint32_t)total, chunks, coarse, table, cellslot, cellpos, stats, h_counts);
+    k_cc_scan<<<spans, kCcScanBlock, 0, st>>>(cnt, (uint32_t)total, chunks, coarse, table, cellslot, cellpos, big, stats, h_counts);
     RSREG_HIP(ctx, hipGetLastError());
     k_cc_scatter<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>());
     RSREG_HIP(ctx, hipGetLastError());
     const uint32_t nbf = div_up(nfin, kBlock);
     k_cc_small<<<nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
     RSREG_HIP(ctx, hipGetLastError());
-    // (a lane per occupied cell -- at most one per finite point --, a wave per crowded one)
-    k_cc_big<<<nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, cellslot, cellpos, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
+    // (one wave per crowded cell, the waves of the grid in turn; the grid covers every cell a cloud of nfin points can crowd)
+    k_cc_big<<<std::max(1u, std::min(div_up(nfin / (kCcSmall + 1u) + 1u, kBlock / 64), 2048u)), kBlock, 0, st>>>(
+        ctx->d_arrived.as<float4>(), g, table, big, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
     RSREG_HIP(ctx, hipGetLastError());
     // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
     k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, stats, g.sx, g.sxy, occ);
@@ -716,7 +718,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         MortonBits mb{0, 0, 0};
         bool narrow = false;
         if (!wide_keys) {
-            static const int morton_bits = std::getenv("RSREG_MORTON_BITS") ? std::max(6, std::min(31, std::atoi(std::getenv("RSREG_MORTON_BITS")))) : 24;
+            static const int morton_bits = std::getenv("RSREG_MORTON_BITS") ? std::max(6, std::min(31, std::atoi(std::getenv("RSREG_MORTON_BITS")))) : 23;   // (+ the invalid bit: three digit passes)
             for (double c = cell; c <= (morton_bits < 31 ? 64.0 : 2.0) * (double)cell + 1e-12; c *= 1.05) {
                 mb = MortonBits{axis_bits_of((double)mx[0] - (double)mn[0], c), axis_bits_of((double)mx[1] - (double)mn[1], c),
                                 axis_bits_of((double)mx[2] - (double)mn[2], c)};
@@ -748,7 +750,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
             // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
-            const bool start_in_out = own_sort && plan.places % 2 == 0;
+            const bool start_in_out = own_sort && plan.ends_in_first;
             uint32_t *keys_a = start_in_out ? keys2 : keys, *vals_a = start_in_out ? perm : vals;
             uint32_t *keys_b = start_in_out ? keys : keys2, *vals_b = start_in_out ? vals : perm;
             k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys_a, vals_a,
@@ -984,16 +986,32 @@ int apply_filters(rsreg_ctx *ctx)
         RSREG_HIP(ctx, ctx->d_vals_alt.reserve((size_t)n * 4));
         uint32_t *keys = ctx->d_keys.as<uint32_t>(), *vals = keys + n, *keys2 = ctx->d_keys_alt.as<uint32_t>(), *order = keys2 + n;
         uint32_t *ws = ctx->d_vals.as<uint32_t>(), *cum = ctx->d_vals_alt.as<uint32_t>();
-        k_trim_keys<<<nb, kBlock, 0, st>>>(cw, ctx->d_corr_d2.as<float>(), n, keys, vals);
-        RSREG_HIP(ctx, hipGetLastError());
+        // (the distances' sort: the library's own, four digit passes that end in the pair they start from -- the keys are
+        // written into the pair that makes that (keys2, order); its state is cleared by the keys kernel on its way)
         size_t sort_bytes = 0, scan_bytes = 0;
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));
+        const bool own_sort = radix32_pays(n, 32);
+        const Radix32Plan plan = radix32_plan(n, 0, 32);
+        if (own_sort) sort_bytes = (size_t)plan.words * 4;
+        else RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));
         RSREG_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
-        RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));   // stable: ties by position
+        const size_t off_scan = (sort_bytes + 255) & ~(size_t)255;
+        RSREG_HIP(ctx, ctx->d_tmp.reserve(off_scan + scan_bytes + 256));
+        char *tmp = ctx->d_tmp.as<char>();
+        uint32_t *k_a = own_sort && plan.ends_in_first ? keys2 : keys, *v_a = own_sort && plan.ends_in_first ? order : vals;
+        uint32_t *k_b = k_a == keys ? keys2 : keys, *v_b = v_a == vals ? order : vals;
+        k_trim_keys<<<nb, kBlock, 0, st>>>(cw, ctx->d_corr_d2.as<float>(), n, k_a, v_a, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
+                                           own_sort ? plan.words : 0u);
+        RSREG_HIP(ctx, hipGetLastError());
+        if (own_sort) {
+            bool in_first = false;
+            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 32, st, &in_first));   // stable: ties by position
+            if ((in_first ? v_a : v_b) != order) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+        } else {
+            RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));   // stable: ties by position
+        }
         k_trim_gather<<<nb, kBlock, 0, st>>>(cw, order, n, ws);
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::inclusive_scan(ctx->d_tmp.ptr, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, rocprim::inclusive_scan(tmp + off_scan, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
         k_trim_apply<<<nb, kBlock, 0, st>>>(order, ws, cum, n, (float)s.prm.trim_overlap_ratio, cw, corr_pos);
         RSREG_HIP(ctx, hipGetLastError());
     }
@@ -1622,7 +1640,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
-                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
+                      &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_ctl, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
                       &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys, &ctx->d_cnt, &ctx->d_arrived};
     if (ctx->stream_h2d) { (void)hipStreamSynchronize(ctx->stream_h2d); (void)hipStreamDestroy(ctx->stream_h2d); }
     ctx->h_stage_src.release();

@@ -1030,9 +1030,12 @@ __global__ __launch_bounds__(kBlock) void k_recip_points(const float4 *cur, cons
 }
 
 // CorrespondenceRejectorTrimmed: sort keys (squared distance of the matched points, unmatched ones last)
-__global__ __launch_bounds__(kBlock) void k_trim_keys(const uint32_t *cw, const float *corr_d2, uint32_t n, uint32_t *keys, uint32_t *vals)
+// (sort_scratch: the state of the sort that follows, cleared on the way -- radix32.hpp)
+__global__ __launch_bounds__(kBlock) void k_trim_keys(const uint32_t *cw, const float *corr_d2, uint32_t n, uint32_t *keys, uint32_t *vals,
+                                                      uint32_t *sort_scratch, uint32_t sort_scratch_words)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sort_scratch) radix32_clear(sort_scratch, sort_scratch_words, u, gridDim.x * blockDim.x);
     if (u >= n) return;
     keys[u] = cw[u] ? __float_as_uint(corr_d2[u]) : 0xffffffffu;   // (squared distances are >= 0: their bits order like the values)
     vals[u] = u;

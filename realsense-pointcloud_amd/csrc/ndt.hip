@@ -92,19 +92,8 @@ struct Pose {
     double p[6];
 };
 
-// Translation(p0..2) * Rx(p3) * Ry(p4) * Rz(p5) assembled in f32 (PCL builds it with
-// Eigen::Translation<float> * AngleAxis<float> products)
-Mat4f pose_matrix(const double *p)
-{
-    const float ax = (float)p[3], ay = (float)p[4], az = (float)p[5];
-    const float cx = std::cos(ax), sx = std::sin(ax), cy = std::cos(ay), sy = std::sin(ay), cz = std::cos(az), sz = std::sin(az);
-    Mat4f Rx = Mat4f::identity(), Ry = Mat4f::identity(), Rz = Mat4f::identity(), Tr = Mat4f::identity();
-    Rx(1, 1) = cx; Rx(1, 2) = -sx; Rx(2, 1) = sx; Rx(2, 2) = cx;
-    Ry(0, 0) = cy; Ry(0, 2) = sy; Ry(2, 0) = -sy; Ry(2, 2) = cy;
-    Rz(0, 0) = cz; Rz(0, 1) = -sz; Rz(1, 0) = sz; Rz(1, 1) = cz;
-    Tr(0, 3) = (float)p[0]; Tr(1, 3) = (float)p[1]; Tr(2, 3) = (float)p[2];
-    return mul(mul(mul(Tr, Rx), Ry), Rz);
-}
+// (the pose matrix, the angle terms and the line search's arithmetic: ndt_math.hpp, one source for the host and the device)
+Mat4f pose_matrix(const double *p) { return ndt_pose_matrix(p); }
 
 // Eigen 3.3 Matrix3f::eulerAngles(0, 1, 2)
 void euler_xyz(const Mat4f &M, float *res)
@@ -132,39 +121,10 @@ void gauss_constants(const rsreg_ndt_params &prm, double &d1, double &d2)
     d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / d1);
 }
 
-// computeAngleDerivatives (Magnusson 2009 eq. 6.19 / 6.21), with PCL's small-angle snap
-void angle_terms(const double *p, NdtPassParams &pp)
-{
-    double cx, cy, cz, sx, sy, sz;
-    if (std::fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p[3]); sx = std::sin(p[3]); }
-    if (std::fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p[4]); sy = std::sin(p[4]); }
-    if (std::fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p[5]); sz = std::sin(p[5]); }
-    auto set = [](double *v, double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; };
-    set(pp.jang[0], -sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy);
-    set(pp.jang[1], cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy);
-    set(pp.jang[2], -sy * cz, sy * sz, cy);
-    set(pp.jang[3], sx * cy * cz, -sx * cy * sz, sx * sy);
-    set(pp.jang[4], -cx * cy * cz, cx * cy * sz, -cx * sy);
-    set(pp.jang[5], -cy * sz, -cy * cz, 0);
-    set(pp.jang[6], cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0);
-    set(pp.jang[7], sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0);
-    set(pp.hang[0], -cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy);
-    set(pp.hang[1], -sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy);
-    set(pp.hang[2], cx * cy * cz, -cx * cy * sz, cx * sy);
-    set(pp.hang[3], sx * cy * cz, -sx * cy * sz, sx * sy);
-    set(pp.hang[4], -sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0);
-    set(pp.hang[5], cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0);
-    set(pp.hang[6], -cy * cz, cy * sz, sy);
-    set(pp.hang[7], -sx * sy * cz, sx * sy * sz, sx * cy);
-    set(pp.hang[8], cx * sy * cz, -cx * sy * sz, -cx * cy);
-    set(pp.hang[9], sy * sz, sy * cz, 0);
-    set(pp.hang[10], -sx * cy * sz, -sx * cy * cz, 0);
-    set(pp.hang[11], cx * cy * sz, cx * cy * cz, 0);
-    set(pp.hang[12], -cy * cz, cy * sz, 0);
-    set(pp.hang[13], -cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0);
-    set(pp.hang[14], -sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0);
-}
+void angle_terms(const double *p, NdtPassParams &pp) { ndt_angle_terms(p, pp.jang, pp.hang); }
 
+constexpr int kNdtLsOffset = 64;   // h_ndt, in doubles: where a finished resident line search leaves its NdtLs (behind the sums and the flag)
+constexpr size_t kNdtHostBytes = (kNdtLsOffset + 16) * 8 + sizeof(NdtLs) + sizeof(NdtLsCtl) + 64;   // sums, flag | NdtLs | the staged NdtLsCtl
 constexpr int kNdtFlagSlot = 32;  // h_ndt: 28 sums, then the pass number the final reduce stamps
 
 // partial sums of a pass + the counter the final reduce counts its workgroups on (zero between passes)
@@ -188,21 +148,15 @@ struct NdtRun {
     double ms_derivatives = 0;
 };
 
-// One derivative pass at pose p with transform M; mode as in NdtPassParams.
-// On return grad (6) / hess (36, symmetric) hold the requested parts; returns the score.
-int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool store_trans, double *score,
-                    double *grad, double *hess)
+// One derivative pass with the parameters `pp` (pose matrix, angle terms, mode): the launch pair and the wait for its 28 sums
+// (h_ndt: pinned).
+int derivative_pass_pp(NdtRun &r, NdtPassParams &pp, bool store_trans)
 {
     rsreg_ctx *ctx = r.ctx;
-    NdtPassParams pp;
-    for (int row = 0; row < 3; ++row)
-        for (int c = 0; c < 4; ++c) pp.M[row * 4 + c] = M(row, c);
-    angle_terms(p, pp);
     pp.d1 = r.d1;
     pp.d2 = r.d2;
     pp.r2 = (float)(r.prm.resolution * r.prm.resolution);
     pp.n_vox = ctx->ndt_n_voxels;
-    pp.mode = mode;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
         for (hipEvent_t &e : ctx->ev_ndt)
@@ -246,6 +200,22 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) r.ms_derivatives += ms;
     }
     r.passes++;
+    return RSREG_OK;
+}
+
+// One derivative pass at pose p with transform M; mode as in NdtPassParams.
+// On return grad (6) / hess (36, symmetric) hold the requested parts; returns the score.
+int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool store_trans, double *score,
+                    double *grad, double *hess)
+{
+    NdtPassParams pp;
+    for (int row = 0; row < 3; ++row)
+        for (int c = 0; c < 4; ++c) pp.M[row * 4 + c] = M(row, c);
+    angle_terms(p, pp);
+    pp.mode = mode;
+    int rc = derivative_pass_pp(r, pp, store_trans);
+    if (rc) return rc;
+    const double *h = r.ctx->h_ndt.as<double>();
     if (mode != 2) {
         *score = h[0];
         for (int i = 0; i < 6; ++i) grad[i] = h[1 + i];
@@ -263,115 +233,89 @@ int derivative_pass(NdtRun &r, const double *p, const Mat4f &M, int mode, bool s
     return RSREG_OK;
 }
 
-// More-Thuente helpers (ndt.hpp auxilaryFunction_PsiMT / dPsiMT, updateIntervalMT, trialValueSelectionMT)
-double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
-double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
-
-bool update_interval(double &a_l, double &f_l, double &g_l, double &a_u, double &f_u, double &g_u, double a_t, double f_t,
-                     double g_t)
+// Can the 512 workgroups of k_ndt_line_search be resident together on this device?  (They wait for each other inside the launch.)
+bool line_search_fits(rsreg_ctx *ctx)
 {
-    if (f_t > f_l) {
-        a_u = a_t; f_u = f_t; g_u = g_t;
-        return false;
+    static int fits[64] = {0};   // per device: 0 unknown, 1 yes, -1 no
+    int &f = fits[ctx->device & 63];
+    if (f == 0) {
+        int per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ndt_line_search, kNdtBlock, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        f = (long long)per_cu * cus >= kPassBlocks ? 1 : -1;
     }
-    if (g_t * (a_l - a_t) > 0) {
-        a_l = a_t; f_l = f_t; g_l = g_t;
-        return false;
-    }
-    if (g_t * (a_l - a_t) < 0) {
-        a_u = a_l; f_u = f_l; g_u = g_l;
-        a_l = a_t; f_l = f_t; g_l = g_t;
-        return false;
-    }
-    return true;
+    return f > 0;
 }
 
-double cubic_min(double a_1, double f_1, double g_1, double a_t, double f_t, double g_t)
-{
-    const double z = 3 * (f_t - f_1) / (a_t - a_1) - g_t - g_1;
-    const double w = std::sqrt(z * z - g_t * g_1);
-    return a_1 + (a_t - a_1) * (w - g_1 - z) / (g_t - g_1 + 2 * w);
-}
-
-double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
-{
-    if (f_t > f_l) {  // case 1
-        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
-        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
-        return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
-    }
-    if (g_t * g_l < 0) {  // case 2
-        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
-    }
-    if (std::fabs(g_t) <= std::fabs(g_l)) {  // case 3
-        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        const double a_next = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
-        return a_t > a_l ? std::min(a_t + 0.66 * (a_u - a_t), a_next) : std::max(a_t + 0.66 * (a_u - a_t), a_next);
-    }
-    return cubic_min(a_u, f_u, g_u, a_t, f_t, g_t);  // case 4
-}
-
-// computeStepLengthMT
+// computeStepLengthMT (More-Thuente): the state machine of ndt_math.hpp.  On one GPU all the passes of the search run in
+// ONE launch (k_ndt_line_search, which advances the machine itself); with a communicator, with profiling on, when the
+// workgroups of that launch do not fit the device together, or with RSREG_NDT_HOST_LS=1 the host advances it, a launch
+// pair and a wait per pass.  Both ways run the same source on the same sums in the same order: the same bits.
 int step_length(NdtRun &r, const double *x, double *dir, double step_init, double step_max, double step_min,
                 double &score, double *grad, double *hess, double &a_out)
 {
-    const double phi_0 = -score;
-    double d_phi_0 = 0;
-    for (int i = 0; i < 6; ++i) d_phi_0 -= grad[i] * dir[i];
-    if (d_phi_0 >= 0) {
-        if (d_phi_0 == 0) { a_out = 0; return RSREG_OK; }
-        d_phi_0 = -d_phi_0;
-        for (int i = 0; i < 6; ++i) dir[i] = -dir[i];
-    }
-    const int max_step_iterations = 10;
-    int step_iterations = 0;
-    const double mu = 1.e-4, nu = 0.9;
-    double a_l = 0, a_u = 0;
-    double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
-    double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
-    bool interval_converged = (step_max - step_min) < 0, open_interval = true;
-    double a_t = std::max(std::min(step_init, step_max), step_min);
-    double x_t[6];
-    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-    r.final_t = pose_matrix(x_t);
-    int rc = derivative_pass(r, x_t, r.final_t, 0, true, &score, grad, hess);
-    if (rc) return rc;
-    double phi_t = -score, d_phi_t = 0;
-    for (int i = 0; i < 6; ++i) d_phi_t -= grad[i] * dir[i];
-    double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-    while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        a_t = open_interval ? trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                            : trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = std::max(std::min(a_t, step_max), step_min);
-        for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-        r.final_t = pose_matrix(x_t);
-        rc = derivative_pass(r, x_t, r.final_t, 1, true, &score, grad, hess);
-        if (rc) return rc;
-        phi_t = -score;
-        d_phi_t = 0;
-        for (int i = 0; i < 6; ++i) d_phi_t -= grad[i] * dir[i];
-        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
-        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-            open_interval = false;
-            f_l = f_l + phi_0 - mu * d_phi_0 * a_l;
-            g_l = g_l + mu * d_phi_0;
-            f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
-            g_u = g_u + mu * d_phi_0;
+    rsreg_ctx *ctx = r.ctx;
+    NdtLs ls;
+    ndt_ls_begin(ls, x, dir, step_init, step_max, step_min, score, grad, hess);
+    static const bool host_only = std::getenv("RSREG_NDT_HOST_LS") && std::getenv("RSREG_NDT_HOST_LS")[0] == '1';
+    bool resident = ls.phase != kNdtLsDone && !host_only && !ctx->comm && !ctx->profiling && !ctx->ndt_ls_failed && line_search_fits(ctx);
+    if (resident) {
+        RSREG_HIP(ctx, ctx->d_ndt_ctl.reserve(sizeof(NdtLsCtl) + 64));
+        RSREG_HIP(ctx, ctx->h_ndt.reserve(kNdtHostBytes));
+        double *h = ctx->h_ndt.as<double>();
+        volatile uint64_t *flag = reinterpret_cast<volatile uint64_t *>(h + kNdtFlagSlot);
+        NdtLs *host_out = reinterpret_cast<NdtLs *>(h + kNdtLsOffset);
+        NdtLsCtl *stage = reinterpret_cast<NdtLsCtl *>(h + kNdtLsOffset + (sizeof(NdtLs) + 7) / 8 + 8);
+        std::memset(stage, 0, sizeof(NdtLsCtl));
+        stage->ls = ls;
+        stage->pp.d1 = r.d1;
+        stage->pp.d2 = r.d2;
+        stage->pp.r2 = (float)(r.prm.resolution * r.prm.resolution);
+        stage->pp.n_vox = ctx->ndt_n_voxels;
+        ndt_fill_pass(stage->pp, ls);
+        stage->release = 1;   // the first pass may start
+        const uint64_t seq = ++ctx->ndt_seq;
+        *flag = 0;
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_ndt_ctl.ptr, stage, sizeof(NdtLsCtl), hipMemcpyHostToDevice, ctx->stream));
+        k_ndt_line_search<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), ctx->d_ndt_ctl.as<NdtLsCtl>(),
+                                                                    ctx->d_ndt_trans.as<float>(), ctx->d_ndt_partials.as<double>(), host_out,
+                                                                    const_cast<uint64_t *>(flag), seq);
+        RSREG_HIP(ctx, hipGetLastError());
+        // the outcome lands in pinned memory, the launch's number behind it; a stream query now and then notices a fault or a time-out
+        for (uint32_t spins = 1; *flag != seq; ++spins)
+            if ((spins & 0xFFFFu) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*flag != seq) {
+            RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            std::atomic_thread_fence(std::memory_order_acquire);
         }
-        interval_converged = open_interval ? update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                                           : update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        ++step_iterations;
+        if (*flag == seq) {
+            std::memcpy(&ls, host_out, sizeof(NdtLs));
+            r.passes += ls.passes;
+        } else {
+            // (a bounded wait inside the launch ran out: not again on this context; this search pass by pass, from its start)
+            ctx->ndt_ls_failed = true;
+            resident = false;
+            ndt_ls_begin(ls, x, dir, step_init, step_max, step_min, score, grad, hess);
+        }
     }
-    if (step_iterations) {
-        double dummy;
-        rc = derivative_pass(r, x_t, r.final_t, 2, false, &dummy, grad, hess);
-        if (rc) return rc;
+    if (!resident) {
+        while (ls.phase != kNdtLsDone) {
+            NdtPassParams pp;
+            ndt_fill_pass(pp, ls);
+            int rc = derivative_pass_pp(r, pp, ls.next_mode != 2);
+            if (rc) return rc;
+            ndt_ls_consume(ls, ctx->h_ndt.as<double>());
+        }
     }
-    a_out = a_t;
+    for (int i = 0; i < 6; ++i) dir[i] = ls.dir[i];
+    if (ls.passes) r.final_t = pose_matrix(ls.x_t);
+    score = ls.score;
+    for (int i = 0; i < 6; ++i) grad[i] = ls.grad[i];
+    for (int k = 0; k < 36; ++k) hess[k] = ls.hess[k];
+    a_out = ls.a_t;
     return RSREG_OK;
 }
 
@@ -381,7 +325,7 @@ int load_ndt_source_device(rsreg_ctx *ctx, const void *d_source, size_t n, size_
     RSREG_HIP(ctx, ctx->d_ndt_src.reserve((n + 1) * sizeof(float4)));
     RSREG_HIP(ctx, reserve_partials(ctx));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
-    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(kNdtHostBytes));
     if (n) {
         k_ndt_load_source<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(static_cast<const char *>(d_source), stride,
                                                                                         (uint32_t)n, ctx->d_ndt_src.as<float4>());
@@ -399,7 +343,7 @@ int load_ndt_source(rsreg_ctx *ctx, const void *source, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_tmp.reserve(n * 12 + 16));
     RSREG_HIP(ctx, reserve_partials(ctx));
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(64 * 8));
-    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(kNdtHostBytes));
     if (n) {
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.ptr, ctx->h_stage.ptr, n * 12, hipMemcpyHostToDevice, ctx->stream));
         k_ndt_load_source<<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, ctx->stream>>>(ctx->d_tmp.as<char>(), 12, (uint32_t)n,
@@ -452,7 +396,7 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
 
     // ---- bounding box of the finite points (pcl::getMinMax3D)
     RSREG_HIP(ctx, ctx->d_misc.reserve(64 * 4));
-    RSREG_HIP(ctx, ctx->h_ndt.reserve(64 * 8));
+    RSREG_HIP(ctx, ctx->h_ndt.reserve(kNdtHostBytes));
     const char *d_pts = static_cast<const char *>(d_points);
     const size_t pstride = stride;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
@@ -514,7 +458,7 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
         if (own_sort) sort_bytes = (size_t)plan.words * 4;
         else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        const bool start_in_out = own_sort && plan.places % 2 == 0;   // (an even number of passes ends in the pair it started from)
+        const bool start_in_out = own_sort && plan.ends_in_first;   // (an even number of passes ends in the pair it started from)
         k_ndt_keys<uint32_t><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, (uint32_t)n_leaves, start_in_out ? keys2 : keys,
                                                                                  start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
                                                                                  own_sort ? plan.words : 0u);

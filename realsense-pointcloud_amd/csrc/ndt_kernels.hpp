@@ -19,6 +19,8 @@
 #include "records.hpp"
 #include "rsreg_ctx.hpp"
 
+#include "ndt_math.hpp"
+
 namespace rsreg {
 
 constexpr int kNdtBlock = 256;
@@ -246,8 +248,10 @@ __device__ __forceinline__ void ndt_pair(const NdtPassParams &pp, const float4 &
 // its voxels (7-14 us of dependent f64 work whether the cloud had 2 k or 36 k points); with pairs over four times as many
 // workgroups a lane holds one or two.  Which lane adds which pair depends on n, the pose and the table only, and the
 // sums are reduced in the fixed tree below.
-__global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp,
-                                                        float *trans_out, double *partials)
+// the body of a derivative pass (k_ndt_pass: one pass per launch; k_ndt_line_search: the passes of a whole line search in one
+// launch, their sums handed to other workgroups inside it)
+template <bool kCoherent>
+__device__ __forceinline__ void ndt_pass_body(const float4 *src, uint32_t n, const NdtVoxel *vox, const NdtPassParams &pp, float *trans_out, double *partials)
 {
     __shared__ NdtVoxel sv[kNdtVoxChunk];
     __shared__ double sh[kNdtBlock / 64][kNdtAcc];
@@ -335,8 +339,19 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint3
     if (threadIdx.x < kNdtAcc) {
         double s = sh[0][threadIdx.x];
         for (int w = 1; w < kNdtBlock / 64; ++w) s += sh[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
+        if (kCoherent) {   // (read by workgroups of other XCDs inside the same launch: written through)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials) + (size_t)blockIdx.x * kNdtAcc + threadIdx.x,
+                               (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            partials[(size_t)blockIdx.x * kNdtAcc + threadIdx.x] = s;
+        }
     }
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp,
+                                                        float *trans_out, double *partials)
+{
+    ndt_pass_body<false>(src, n, vox, pp, trans_out, partials);
 }
 
 // One workgroup per sum: fixed order (each thread its share of the partials in ascending order, shuffle tree, waves in
@@ -373,6 +388,157 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_final_reduce(const double *pa
                 __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
+}
+
+// ---- a whole line search in one launch ---------------------------------------------------------------------------------
+// computeStepLengthMT evaluates the score and its gradient at a sequence of trial steps, each a derivative pass over the
+// source cloud, each depending on the one before.  With a launch pair and the host between any two of them a pass is 19 us
+// of kernels and 17 us of round trip (17 passes per alignment of a 36 k-point edge cloud).  k_ndt_line_search runs ALL the
+// passes of one line search: its 512 workgroups are resident together (2 per CU), a pass ends in a grid-wide count
+// (16 group counters and one on top: same-address atomics queue up), workgroups 0 .. 27 then add one sum each over the 512
+// partials -- the order k_ndt_final_reduce adds them in --, workgroup 0's first thread takes the 28 sums through the state
+// machine of ndt_math.hpp (the host loop's own source: same bits) and either leaves the next pass's pose, matrix and angle
+// terms and lets the workgroups go on, or leaves the search's outcome in pinned host memory and lets them end.  What the
+// workgroups hand each other inside the launch is written through and read past the XCDs' L2s (agent-scope atomics); every
+// wait is bounded (a workgroup that never comes would otherwise hang the queue): on a time-out the launch ends with
+// `error` set and the host runs the search pass by pass.
+struct NdtLsCtl {
+    NdtLs ls;                       // the state machine (workgroup 0's)
+    NdtPassParams pp;               // the pass every workgroup runs next
+    unsigned long long release;     // passes the workgroups may run so far (from 1 on) | kNdtLsStop: end
+    uint32_t arrive[16 + 1];        // workgroups that have finished pass k, by group, and groups complete (both keep counting)
+    uint32_t reduced;               // sums added up (keeps counting)
+    uint32_t error;
+    uint32_t pad;
+    double out[kNdtAcc];
+};
+constexpr unsigned long long kNdtLsStop = 1ull << 63;
+constexpr uint32_t kNdtLsSpins = 1u << 22;   // bounded waits: ~1 s of s_sleep
+
+__host__ __device__ inline void ndt_fill_pass(NdtPassParams &pp, const NdtLs &ls)
+{
+    const Mat4f M = ndt_pose_matrix(ls.x_t);
+    for (int row = 0; row < 3; ++row)
+        for (int c = 0; c < 4; ++c) pp.M[row * 4 + c] = M(row, c);
+    ndt_angle_terms(ls.x_t, pp.jang, pp.hang);
+    pp.mode = ls.next_mode;
+}
+
+__device__ __forceinline__ unsigned long long ndt_load64(const void *p)
+{
+    return __hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<void *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ndt_store64(void *p, unsigned long long v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ndt_load32(const uint32_t *p)
+{
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_line_search(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtLsCtl *ctl, float *trans_out,
+                                                               double *partials, NdtLs *host_out, uint64_t *host_flag, uint64_t seq)
+{
+    __shared__ NdtPassParams s_pp;
+    __shared__ NdtLs s_ls;
+    __shared__ double s_sums[kNdtAcc];
+    __shared__ double s_shw[kNdtBlock / 64];
+    __shared__ unsigned long long s_cmd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per_group = gridDim.x / 16u;
+    if (blockIdx.x == 0) {   // the state the host has left
+        const unsigned long long *g = reinterpret_cast<const unsigned long long *>(&ctl->ls);
+        unsigned long long *l = reinterpret_cast<unsigned long long *>(&s_ls);
+        for (uint32_t w = threadIdx.x; w < sizeof(NdtLs) / 8; w += kNdtBlock) l[w] = g[w];
+    }
+    for (uint32_t pass = 1;; ++pass) {
+        if (threadIdx.x == 0) {
+            unsigned long long c = 0;
+            for (uint32_t spin = 0; spin < kNdtLsSpins; ++spin) {
+                c = ndt_load64(&ctl->release);
+                if ((c & kNdtLsStop) || c >= pass) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!(c & kNdtLsStop) && c < pass) { c = kNdtLsStop; atomicExch(&ctl->error, 1u); }
+            s_cmd = c;
+        }
+        __syncthreads();
+        if (s_cmd & kNdtLsStop) return;
+        {
+            unsigned long long *l = reinterpret_cast<unsigned long long *>(&s_pp);
+            for (uint32_t w = threadIdx.x; w < sizeof(NdtPassParams) / 8; w += kNdtBlock) l[w] = ndt_load64(reinterpret_cast<const unsigned long long *>(&ctl->pp) + w);
+        }
+        __syncthreads();
+        ndt_pass_body<true>(src, n, vox, s_pp, s_pp.mode != 2 ? trans_out : nullptr, partials);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's partial sums have arrived device-wide)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t before = __hip_atomic_fetch_add(&ctl->arrive[blockIdx.x & 15u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((before + 1u) % per_group == 0u) __hip_atomic_fetch_add(&ctl->arrive[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (blockIdx.x < (uint32_t)kNdtAcc) {
+            // one sum: k_ndt_final_reduce's order (each thread its partials in ascending order, shuffle tree, waves in order)
+            if (threadIdx.x == 0) {
+                uint32_t spin = 0;
+                while (ndt_load32(&ctl->arrive[16]) < 16u * pass && ++spin < kNdtLsSpins) __builtin_amdgcn_s_sleep(1);
+                s_cmd = spin < kNdtLsSpins ? 0ull : kNdtLsStop;
+            }
+            __syncthreads();
+            if (s_cmd & kNdtLsStop) {   // (a workgroup never came: end the launch)
+                if (threadIdx.x == 0) { atomicExch(&ctl->error, 1u); ndt_store64(&ctl->release, kNdtLsStop); }
+                return;
+            }
+            const int k = (int)blockIdx.x;
+            double v = 0.0;
+            for (uint32_t b = threadIdx.x; b < gridDim.x; b += kNdtBlock * 4) {
+                double x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[j] = b + j * kNdtBlock < gridDim.x ? __longlong_as_double((long long)ndt_load64(partials + (size_t)(b + j * kNdtBlock) * kNdtAcc + k)) : 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (b + j * kNdtBlock < gridDim.x) v += x[j];
+            }
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) s_shw[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = s_shw[0];
+                for (int w = 1; w < kNdtBlock / 64; ++w) t += s_shw[w];
+                ndt_store64(&ctl->out[k], (unsigned long long)__double_as_longlong(t));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&ctl->reduced, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // the controller: the 28 sums through the state machine, then the next pass -- or the outcome
+            uint32_t spin = 0;
+            while (ndt_load32(&ctl->reduced) < (uint32_t)kNdtAcc * pass && ++spin < kNdtLsSpins) __builtin_amdgcn_s_sleep(1);
+            if (spin >= kNdtLsSpins) {
+                atomicExch(&ctl->error, 1u);
+                ndt_store64(&ctl->release, kNdtLsStop);
+            } else {
+                for (int k = 0; k < kNdtAcc; ++k) s_sums[k] = __longlong_as_double((long long)ndt_load64(&ctl->out[k]));
+                ndt_ls_consume(s_ls, s_sums);
+                if (s_ls.phase != kNdtLsDone) {
+                    ndt_fill_pass(s_pp, s_ls);   // (d1, d2, r2, n_vox stay)
+                    const unsigned long long *l = reinterpret_cast<const unsigned long long *>(&s_pp);
+                    for (uint32_t w = 0; w < sizeof(NdtPassParams) / 8; ++w) ndt_store64(reinterpret_cast<unsigned long long *>(&ctl->pp) + w, l[w]);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ndt_store64(&ctl->release, (unsigned long long)pass + 1ull);
+                } else {
+                    const unsigned long long *l = reinterpret_cast<const unsigned long long *>(&s_ls);
+                    unsigned long long *h = reinterpret_cast<unsigned long long *>(host_out);
+                    for (uint32_t w = 0; w < sizeof(NdtLs) / 8; ++w) h[w] = l[w];
+                    __threadfence_system();
+                    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ndt_store64(&ctl->release, kNdtLsStop);
+                }
+            }
+        }
+        __syncthreads();   // (workgroup 0: s_pp is the controller's scratch until here)
     }
 }
 

@@ -16,7 +16,8 @@
 //               neighbouring threads write neighbouring addresses.
 // State (histograms, look-back words, tickets) lives in one scratch block that must be ZERO when the histogram kernel
 // starts: the kernel that writes the keys clears it on its way (osort_clear), so a sort queues no memset.
-// The passes ping-pong between the caller's two buffer pairs.
+// The passes ping-pong between the caller's two buffer pairs.  At most 4 096 pairs are sorted by ONE workgroup in one launch
+// (k_os_small: the same passes, in LDS).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -78,6 +79,103 @@ __global__ __launch_bounds__(kOsHistBlock) void k_os_hist(const uint32_t *keys, 
         if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
 }
 
+// Ranks of a wave's 4 x 64 pairs among the pairs of the same digit earlier in the wave (order: round, lane), and the wave's
+// count per digit in cnt[256] (LDS, zero on entry).  The lanes holding my digit are the AND over the digit's bits of "ballot
+// of that bit, or its complement"; the first of them bumps the counter, the others sit behind it in lane order.
+__device__ __forceinline__ void os_wave_ranks(const uint32_t (&key)[kOsItems], uint32_t bit, uint32_t mask, uint32_t *cnt, uint32_t (&rank)[kOsItems])
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t r = 0; r < kOsItems; ++r) {
+        const uint32_t d = (key[r] >> bit) & mask;
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (uint32_t b = 0; b < kOsBits; ++b) {
+            const bool one = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t prev = 0;
+        if ((int)lane == leader) {
+            prev = cnt[d];
+            cnt[d] = prev + (uint32_t)__popcll(peers);
+        }
+        prev = __shfl(prev, leader);
+        rank[r] = prev + (uint32_t)__popcll(peers & lt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// At most 4 096 pairs: the whole sort in one workgroup, every pass in LDS (one launch, no scratch).
+template <int kDummy = 0>
+__global__ __launch_bounds__(kOsBlock) void k_os_small(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
+                                                       uint32_t begin_bit, uint32_t end_bit)
+{
+    __shared__ uint32_t s_cnt[kOsBlock / 64][kOsDigits];
+    __shared__ uint32_t s_keys[kOsTile], s_vals[kOsTile];
+    __shared__ uint32_t s_start[kOsDigits], s_part[kOsDigits / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, base = wave * (kOsItems * 64u);
+    uint32_t key[kOsItems], val[kOsItems], rank[kOsItems];
+#pragma unroll
+    for (uint32_t r = 0; r < kOsItems; ++r) {
+        const uint32_t i = base + r * 64u + lane;
+        key[r] = i < n ? keys_in[i] : 0xffffffffu;   // (padding: the last digit of every pass, behind every real pair)
+        val[r] = i < n ? vals_in[i] : 0u;
+    }
+    for (uint32_t bit = begin_bit; bit < end_bit; bit += kOsBits) {
+        const uint32_t mask = (1u << min(kOsBits, end_bit - bit)) - 1u;
+        for (uint32_t k = t; k < (kOsBlock / 64) * kOsDigits; k += kOsBlock) (&s_cnt[0][0])[k] = 0u;
+        __syncthreads();
+        os_wave_ranks(key, bit, mask, s_cnt[wave], rank);
+        __syncthreads();
+        uint32_t total = 0, excl = 0;
+        if (t < kOsDigits) {
+#pragma unroll
+            for (uint32_t w = 0; w < kOsBlock / 64; ++w) {
+                const uint32_t c = s_cnt[w][t];
+                s_cnt[w][t] = total;
+                total += c;
+            }
+            uint32_t incl = total;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += o;
+            }
+            if (lane == 63u) s_part[wave] = incl;
+            excl = incl - total;
+        }
+        __syncthreads();
+        if (t < kOsDigits) {
+            for (uint32_t w = 0; w < wave; ++w) excl += s_part[w];
+            s_start[t] = excl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < kOsItems; ++r) {
+            const uint32_t d = (key[r] >> bit) & mask;
+            const uint32_t p = s_start[d] + s_cnt[wave][d] + rank[r];
+            s_keys[p] = key[r];
+            s_vals[p] = val[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < kOsItems; ++r) {
+            key[r] = s_keys[base + r * 64u + lane];
+            val[r] = s_vals[base + r * 64u + lane];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kOsItems; ++r) {
+        const uint32_t i = base + r * 64u + lane;
+        if (i < n) { keys_out[i] = key[r]; vals_out[i] = val[r]; }
+    }
+}
+
 // look-back word of (workgroup, digit): status << 30 | count; 0 = nothing yet, 1 = the workgroup's own count, 2 = inclusive
 constexpr uint32_t kOsPartial = 1u << 30, kOsInclusive = 2u << 30, kOsValue = (1u << 30) - 1u;
 
@@ -104,28 +202,7 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
         key[r] = i < n ? keys_in[i] : 0xffffffffu;   // (padding: the last digit, behind every real pair of the last workgroup)
         val[r] = i < n ? vals_in[i] : 0u;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (uint32_t r = 0; r < kOsItems; ++r) {
-        const uint32_t d = (key[r] >> bit) & mask;
-        unsigned long long peers = ~0ull;
-#pragma unroll
-        for (uint32_t b = 0; b < kOsBits; ++b) {
-            const bool one = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(one);
-            peers &= one ? bal : ~bal;
-        }
-        const int leader = __ffsll((long long)peers) - 1;
-        uint32_t prev = 0;
-        if ((int)lane == leader) {
-            prev = s_cnt[wave][d];
-            s_cnt[wave][d] = prev + (uint32_t)__popcll(peers);
-        }
-        prev = __shfl(prev, leader);
-        rank[r] = prev + (uint32_t)__popcll(peers & lt);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
+    os_wave_ranks(key, bit, mask, s_cnt[wave], rank);
     __syncthreads();
     // per digit: what the waves before hold, the workgroup's total (published at once: nobody behind waits longer than
     // that); the digits' first local positions and the first global position of every digit's segment are two exclusive
@@ -199,6 +276,9 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
 // Sorts n pairs by bits [begin_bit, end_bit) of the key.  `scratch` (plan.words words) must be all zero when the first
 // kernel starts and is dirty afterwards.  Returns through *in_first whether the sorted pairs lie in (keys_a, vals_a)
 // (true) or in (keys_b, vals_b); the other pair is overwritten too.
+// whether osort_pairs leaves the result in the pair it started from
+inline bool osort_ends_in_first(const OsortPlan &p, size_t n) { return n == 0 || p.passes == 0 || (n > kOsTile && p.passes % 2 == 0); }
+
 inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
                               unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first)
 {
@@ -207,6 +287,11 @@ inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, uint32_t *k
     // (every check before the first launch: an error return leaves nothing queued on a dirty scratch block)
     if (p.passes > kOsMaxPasses || n >= (1ull << 30)) return hipErrorInvalidValue;
     if (p.blocks != (uint32_t)((n + kOsTile - 1) / kOsTile)) return hipErrorInvalidValue;
+    if (n <= kOsTile) {   // one workgroup, one launch; the result in the second pair
+        k_os_small<0><<<1, kOsBlock, 0, st>>>(keys_a, keys_b, vals_a, vals_b, (uint32_t)n, begin_bit, end_bit);
+        *in_first = false;
+        return hipGetLastError();
+    }
     k_os_hist<0><<<p.hist_blocks, kOsHistBlock, 0, st>>>(keys_a, (uint32_t)n, begin_bit, end_bit, p.passes, scratch + p.off_hist);
     bool from_a = true;
     unsigned bit = begin_bit;

@@ -256,6 +256,8 @@ struct rsreg_ctx {
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt
     rsreg::DevBuf d_ndt_vox;      // per voxel: 3 mean + 9 icov doubles + centroid float3 ...
     rsreg::DevBuf d_ndt_src, d_ndt_trans, d_ndt_partials, d_ndt_out;
+    rsreg::DevBuf d_ndt_ctl;      // a line search in one launch (ndt_kernels.hpp: NdtLsCtl): its state, the next pass's parameters, its counters
+    bool ndt_ls_failed = false;   // ... ran into one of its bounded waits once: the host advances the searches of this context from then on
     rsreg::DevBuf d_ndt_seg;      // first sorted point of every occupied leaf (NDT's own: d_cellpos belongs to the live ICP hash index)
     hipEvent_t ev_ndt[2] = {nullptr, nullptr};   // NDT's own event pair (the pool's indices belong to an ICP begin..end)
     std::vector<double> ndt_mean_cov_icov;   // 21 per voxel (host copy)

@@ -330,30 +330,40 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     uint32_t *stats = b_misc.as<uint32_t>() + 32;
     const uint32_t nb = div_up_u(N, kVBlock);
     size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
-    // the slot sort (10 bits, stable): two onesweep passes driven by this library, their state cleared by the keys kernel
-    // (radix32.hpp) -- rocPRIM's driver merge-sorts below 65 536 records (42 us for an edge cloud of 36 k against 25) and
-    // queues five memsets above
-    const bool own_sort = radix32_pays(n, 10);
-    const Radix32Plan plan = radix32_plan(n, 0, 10);
-    if (own_sort) sort_bytes = (size_t)plan.words * 4;
-    else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
+    // both sorts are the library's own (osort.hpp through radix32.hpp): the slot sort (10 bits, stable) and, further down,
+    // the sort of the runs by emission position (as many bits as n + 512 has).  Their state lies in one scratch block that
+    // the keys kernel clears on its way: [slot sort | emission sort, sized for n runs | rocPRIM's scan]
+    unsigned ebits = 1;
+    while ((1ull << ebits) < (unsigned long long)n + kHist + 1ull) ++ebits;
+    const bool own_sort = radix32_pays(n, 10) && radix32_pays(n, ebits);
+    const Radix32Plan plan = radix32_plan(n, 0, 10), plan2max = radix32_plan(n, 0, ebits);
+    if (own_sort) {
+        sort_bytes = (size_t)plan.words * 4;
+        sort2_bytes = (size_t)plan2max.words * 4;
+    } else {
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
+    }
     RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
-    RSREG_HIP(ctx, b_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, sort2_bytes)) + 256));
-    // (two passes end in the pair they started from: the keys are written where the sorted pairs belong)
-    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, own_sort ? skeys : keys, own_sort ? svals : vals, stats,
-                                       own_sort ? b_tmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
+    const size_t off_sort2 = (sort_bytes + 255) & ~(size_t)255, off_scan = (off_sort2 + sort2_bytes + 255) & ~(size_t)255;
+    RSREG_HIP(ctx, b_tmp.reserve(off_scan + scan_bytes + 256));
+    char *tmp = b_tmp.as<char>();
+    // (the slot sort ends in the pair (skeys, svals): the keys are written into whichever pair that takes)
+    uint32_t *k_a = !own_sort || !plan.ends_in_first ? keys : skeys, *v_a = !own_sort || !plan.ends_in_first ? vals : svals;
+    uint32_t *k_b = k_a == keys ? skeys : keys, *v_b = v_a == vals ? svals : vals;
+    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, k_a, v_a, stats, own_sort ? b_tmp.as<uint32_t>() : nullptr,
+                                       own_sort ? (uint32_t)((off_sort2 + sort2_bytes) / 4) : 0u);
     RSREG_HIP(ctx, hipGetLastError());
     if (own_sort) {
         bool in_first = false;
-        RSREG_HIP(ctx, radix32_sort_pairs(plan, b_tmp.as<uint32_t>(), skeys, keys, svals, vals, n, 0, 10, st, &in_first));
-        if (!in_first) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
+        RSREG_HIP(ctx, radix32_sort_pairs(plan, b_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 10, st, &in_first));
+        if ((in_first ? k_a : k_b) != skeys) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
     } else {
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(b_tmp.ptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable (radix above 65 536 items: sort_cfg.hpp)
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
     }
     k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, rocprim::exclusive_scan(tmp + off_scan, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
     k_vox_starts<<<nb, kVBlock, 0, st>>>(skeys, flag, rid, N, start, stats);
     RSREG_HIP(ctx, hipGetLastError());
     uint32_t *h = b_host.as<uint32_t>();
@@ -366,8 +376,16 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     k_vox_long_runs<<<std::min(div_up_u(nr, 4u), 2048u), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun,
                                                                            long_runs);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(b_tmp.ptr, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
-    k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, order, stats, stride, d_out);
+    const uint32_t *emit_order = order;
+    if (own_sort) {
+        const Radix32Plan plan2 = radix32_plan(nr, 0, ebits);   // (nr <= n: its state fits the block cleared for n runs)
+        bool in_first = false;
+        RSREG_HIP(ctx, radix32_sort_pairs(plan2, reinterpret_cast<uint32_t *>(tmp + off_sort2), ekey, ekey2, erun, order, nr, 0, ebits, st, &in_first));
+        emit_order = in_first ? erun : order;
+    } else {
+        RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp + off_sort2, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
+    }
+    k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, emit_order, stats, stride, d_out);
     RSREG_HIP(ctx, hipGetLastError());
     *n_out = nr;
     return RSREG_OK;

@@ -141,7 +141,7 @@ typedef struct rsreg_icp_result {
                                    kernels (final reduce + host round trip or device solve)            */
     double ms_transform;
     int32_t n_nn_launches;
-    int32_t reserved1;
+    int32_t n_scheduled_launches; /* ... of them launched from the tile schedule (fused dense kernel: DESIGN.md §4)       */
     double ms_allreduce;        /* N > 1 ranks: the all-reduce of the 17 sums, all iterations (0.3; 0 with one rank)   */
 } rsreg_icp_result;
 

@@ -369,7 +369,7 @@ int rsreg_cloud_upload_async(rsreg_cloud *c, const void *points, size_t n, size_
 // aligned, and the 0.2 ms it takes to stage a frame no longer sit on the caller's thread with the GPU idle.
 int rsreg_cloud_upload_deferred(rsreg_cloud *c, const void *points, size_t n, size_t stride, uint32_t width, uint32_t height, int is_dense)
 {
-    static const bool on_caller = std::getenv("RSREG_UPLOAD_WAIT_STAGED") && std::getenv("RSREG_UPLOAD_WAIT_STAGED")[0] == '1';   // (dev: A/B)
+    const bool on_caller = rsreg::tunables().upload_wait_staged;   // (dev: A/B)
     return upload_on_worker(c, points, n, stride, width, height, is_dense, on_caller);
 }
 
@@ -770,7 +770,7 @@ int rsreg_icp_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double max_
     // (incremental_icp.hpp:54-59): for so few queries the index is not worth building (icp.hip: scan_target).  The
     // source is set before the target in the reference; if it is not, or changes, rsreg_icp_begin builds the index.
     const bool few_queries = ctx->have_source && ctx->n_source > 0 && ctx->n_source <= kScanSourceLimit && c->n >= kScanTargetFloor &&
-                             !std::getenv("RSREG_NO_SCAN");
+                             rsreg::tunables().scan_target;
     // (a cloud that has grown since its index was built -- icp_edge_based_registration.hpp:119-120: *target = *icp_aligned +
     // *target, then the next frame's setInputTarget -- is indexed afresh: rounds 3-4 merged the new records into the index
     // instead, bit for bit the same index, and it did not pay: profiles/r04_experiments/README.md)

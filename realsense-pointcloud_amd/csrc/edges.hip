@@ -336,7 +336,8 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
     k_edge_gather<<<nb, kBlock, 0, st>>>(d_rec, stride, N, flag, pos, b_out.as<char>(), b_vals_alt.as<int32_t>());
     RSREG_HIP(ctx, hipGetLastError());
-    if (const char *dump = std::getenv("RSREG_EDGE_DUMP")) {   // dev: the stage images, for a stage-by-stage comparison
+#ifdef RSREG_DIAG
+    if (const char *dump = rsreg::tunables().edge_dump) {   // diagnostic builds: the stage images, for a stage-by-stage comparison
         std::vector<float> hbuf(n * 3);
         std::vector<uint8_t> hdir(n);
         (void)hipMemcpyAsync(hbuf.data(), sm, n * 4, hipMemcpyDeviceToHost, st);
@@ -350,6 +351,7 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
             std::fclose(f);
         }
     }
+#endif
     uint32_t *hb = b_host.as<uint32_t>() + 200;
     RSREG_HIP(ctx, hipMemcpyAsync(hb, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipMemcpyAsync(hb + 1, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));

@@ -113,15 +113,7 @@ int host_cell_coord(float p, float origin, float inv_cell)
     return (int)f;
 }
 
-double cell_cap_from_env()
-{
-    const char *e = std::getenv("RSREG_CELL_CAP");
-    if (e) {
-        double v = std::atof(e);
-        if (v > 0) return v;
-    }
-    return 0.014;   // metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
-}
+double cell_cap_from_env() { return tunables().cell_cap; }
 
 // bounding box + count of the finite points of a device-resident cloud (one host sync), on the given stream with
 // the given scratch: d_misc (64 words; result in the first 16), h_misc (pinned, 16 words), partial (1024 x 8 words)
@@ -183,8 +175,7 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     g.nbr = ctx->d_dense.as<uint32_t>() + g.table_bytes / 4;   // the occupancy words lie right behind the table (one memset clears both)
     g.pos_of = ctx->d_pos_of.as<uint32_t>();
 #ifdef RSREG_DIAG   // (diagnostic builds only -- RSREG_CXXFLAGS=-DRSREG_DIAG: the shipped library has no switch that changes a result)
-    static const uint32_t debug_skip = std::getenv("RSREG_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("RSREG_DEBUG_SKIP")) : 0u;
-    g.debug_skip = debug_skip;
+    g.debug_skip = tunables().debug_skip;
 #endif
     // positions in cell units carry the rounding of (p - origin) * inv_cell, ~2^-23 of their size
     g.margin = std::min(kCellMargin, std::max(0.004f, 6.0e-7f * (float)std::max(p.dims[0], std::max(p.dims[1], p.dims[2]))));
@@ -194,16 +185,7 @@ DenseDev dense_dev(const rsreg_ctx *ctx, double max_dist)
     return g;
 }
 
-long long dense_cell_budget()
-{
-    static const long long v = [] {
-        if (const char *f = std::getenv("RSREG_FORCE_HASH"))
-            if (f[0] == '1') return 0ll;
-        if (const char *e = std::getenv("RSREG_DENSE_MAX_CELLS")) return std::atoll(e);
-        return 1ll << 28;   // 1 GiB of cell starts at most (out of 288 GB)
-    }();
-    return v;
-}
+long long dense_cell_budget() { return tunables().dense_max_cells; }
 
 // Dense-table index (icp_dense.hpp).  The grid geometry (ctx->grid) is already decided.
 // KeyT: the sort key's type -- uint32_t when the cell id and at least 6 bits of x position fit 32 bits (build_dense).
@@ -240,7 +222,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     const bool own_sort = sizeof(KeyT) == 4 && radix32_pays(n, end_bit);
     const Radix32Plan plan = radix32_plan(n, 0, end_bit);
     // ... and then flag, scan and scatter are one launch too (compact.hpp), its look-back words cleared with the sort's state
-    static const bool scan_apart = std::getenv("RSREG_SCAN_APART") && std::getenv("RSREG_SCAN_APART")[0] == '1';
+    const bool scan_apart = tunables().scan_apart;
     const bool one_tail = own_sort && !scan_apart && nfin < 0x7fffffffu;
     const CompactPlan cplan = compact_plan(nfin, plan.words);
     const uint32_t scratch_words = one_tail ? cplan.end : plan.words;
@@ -299,8 +281,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
 // entries is cheap for: at most 32 cells per point, or 16 M cells.  RSREG_COUNT_SORT=0: never.
 bool count_sort_pays(size_t n, size_t total)
 {
-    static const bool off = std::getenv("RSREG_COUNT_SORT") && std::getenv("RSREG_COUNT_SORT")[0] == '0';
-    return !off && total <= std::max<size_t>(32 * n, (size_t)16 << 20) && total < (1ull << 31);
+    return tunables().count_sort && total <= std::max<size_t>(32 * n, (size_t)16 << 20) && total < (1ull << 31);
 }
 
 int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin)
@@ -375,13 +356,12 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     RSREG_HIP(ctx, ctx->d_pos_of.reserve((n + 1) * 4));
     int id_bits = 1;
     while ((1ull << id_bits) <= total) ++id_bits;   // all-ones (non-finite) stays above every valid id
-    static const bool wide_keys = std::getenv("RSREG_KEYS64") && std::getenv("RSREG_KEYS64")[0] == '1';
-    static const bool full_table = std::getenv("RSREG_FULL_TABLE") && std::getenv("RSREG_FULL_TABLE")[0] == '1';
+    const bool wide_keys = tunables().keys64, full_table = tunables().full_table;
     const bool narrow = !wide_keys && id_bits <= 26;   // at least 6 bits of x order inside a cell
     gp.xbits = narrow ? std::min(16, 32 - id_bits) : 16;
     // the searches of gates up to four cells go through the occupancy words only (icp_dense.hpp: dense_far_blocks);
     // the row search of wider or unbounded gates reads table entries of empty cells too and needs all of them
-    gp.table_sparse = (gp.max_ring <= 4 && !full_table && !std::getenv("RSREG_FAR_ROWS")) ? 1 : 0;
+    gp.table_sparse = (gp.max_ring <= 4 && !full_table && !tunables().far_rows) ? 1 : 0;
     const uint32_t *h_counts = ctx->h_smisc.as<uint32_t>() + 40;
     const bool counted = count_sort_pays(n, total);
     if (counted) {
@@ -444,7 +424,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     const rsreg::CloudBox known = ctx->next_tgt_box;   // (of the cloud handle this target comes from, if it has been measured before)
     ctx->next_tgt_box.valid = false;
     ctx->last_tgt_box.valid = false;
-    static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
+    const bool no_box_cache = !tunables().box_cache;
     if (known.valid && !no_box_cache && n > 0) {
         RSREG_HIP(ctx, ctx->d_misc.reserve(64 * sizeof(uint32_t)));
         RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
@@ -489,7 +469,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
         cell = padded / parts;
         // a gate below the cap (the reference's 1 cm on sparse edge clouds): cells as large as the cap still need one
         // ring only, and the table (cleared and scanned on every build) shrinks with the cube of the cell
-        static const bool wide = !(std::getenv("RSREG_NO_WIDE_CELLS") && std::getenv("RSREG_NO_WIDE_CELLS")[0] == '1');
+        const bool wide = tunables().wide_cells;
         if (wide && parts == 1 && cap * refine > padded) cell = cap * refine;
     } else {
         cell = cap * refine;
@@ -595,7 +575,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     }
     ctx->have_target = true;
     // dense cloud: rebuild once with smaller cells (fewer candidates per query)
-    static const bool adaptive = !(std::getenv("RSREG_NO_ADAPTIVE_CELL") && std::getenv("RSREG_NO_ADAPTIVE_CELL")[0] == '1');
+    const bool adaptive = tunables().adaptive_cell;
     if (adaptive && refine == 1.0 && n_cells > 0) {
         const double per_cell = (double)n_unique / (double)n_cells;
         if (per_cell > 14.0) {
@@ -660,9 +640,7 @@ int join_source(rsreg_ctx *ctx)
 constexpr size_t kPlainSourceMax = 65536;
 bool source_is_small(size_t n)
 {
-    static const bool sort_small = std::getenv("RSREG_SORT_SMALL") && std::getenv("RSREG_SORT_SMALL")[0] == '1';
-    static const size_t plain_max = std::getenv("RSREG_PLAIN_SOURCE_MAX") ? (size_t)std::atoll(std::getenv("RSREG_PLAIN_SOURCE_MAX")) : kPlainSourceMax;
-    return n <= plain_max && !sort_small;
+    return n <= tunables().plain_source_max && !tunables().sort_small;
 }
 
 // The part of a source load that queues work on stream_src (after one round trip for the bounding box); runs on the
@@ -690,7 +668,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         RSREG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
         float mn[3], mx[3];
         uint32_t nfin = 0;
-        static const bool no_box_cache = std::getenv("RSREG_NO_BOX_CACHE") && std::getenv("RSREG_NO_BOX_CACHE")[0] == '1';
+        const bool no_box_cache = !tunables().box_cache;
         if (known.valid && !no_box_cache) {   // (nothing of the load counts in the words k_bbox_final clears: the kernels below only store there)
             for (int k = 0; k < 3; ++k) { mn[k] = known.mn[k]; mx[k] = known.mx[k]; }
             nfin = known.nfin;
@@ -709,7 +687,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         // a 32-bit key (31 bits of Morton code + the invalid bit) halves the bytes the radix sort moves and saves it a pass
         // or two: the cell grows (by at most 2x: the search time moves by +- 1.5 % between 1.5 and 3 mm)
         // until the three axes need 31 bits together
-        static const bool wide_keys = std::getenv("RSREG_KEYS64") && std::getenv("RSREG_KEYS64")[0] == '1';
+        const bool wide_keys = tunables().keys64;
         auto axis_bits_of = [](double ext, double c) {
             int b = 1;
             while (b < 16 && (double)(1u << b) <= ext / c + 2.0) ++b;
@@ -718,7 +696,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         MortonBits mb{0, 0, 0};
         bool narrow = false;
         if (!wide_keys) {
-            static const int morton_bits = std::getenv("RSREG_MORTON_BITS") ? std::max(6, std::min(31, std::atoi(std::getenv("RSREG_MORTON_BITS")))) : 23;   // (+ the invalid bit: three digit passes)
+            const int morton_bits = tunables().morton_bits;   // (23 + the invalid bit: three digit passes)
             for (double c = cell; c <= (morton_bits < 31 ? 64.0 : 2.0) * (double)cell + 1e-12; c *= 1.05) {
                 mb = MortonBits{axis_bits_of((double)mx[0] - (double)mn[0], c), axis_bits_of((double)mx[1] - (double)mn[1], c),
                                 axis_bits_of((double)mx[2] - (double)mn[2], c)};
@@ -821,7 +799,18 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     RSREG_HIP(ctx, ctx->d_uniq_of.reserve((n + 1) * 4));
     RSREG_HIP(ctx, ctx->d_first.reserve((n + 2) * 4));
     RSREG_HIP(ctx, ctx->d_partials.reserve((size_t)reduce_blocks(n) * RSREG_NUM_SUMS * 8));
-    RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
+    {
+        // the tile schedule's arrays (items | wave costs | done counters | ...) lie at offsets that depend on the buffer's capacity
+        // only, so that a schedule can be carried over to the next alignment (launch_fused); a new buffer starts from zero
+        // (the done counters go back to zero by themselves) and without a schedule
+        void *before = ctx->d_sched.ptr;
+        RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
+        if (ctx->d_sched.ptr != before) {
+            RSREG_HIP(ctx, hipMemsetAsync(ctx->d_sched.ptr, 0, ctx->d_sched.cap, ctx->stream));
+            ctx->sched_cap_tiles = (uint32_t)((ctx->d_sched.cap - 256) / (11 * 4));
+            ctx->sched_keep_items = 0;
+        }
+    }
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->h_sums.reserve(64 * 8));
     RSREG_HIP(ctx, ctx->d_smisc.reserve((64 + 1024 * 8) * sizeof(uint32_t)));
@@ -834,7 +823,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     if (n) {
         // the raw cloud may have been produced (uploaded, filtered, transformed) on the main stream just now
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-        static const bool no_worker = std::getenv("RSREG_NO_WORKER") && std::getenv("RSREG_NO_WORKER")[0] == '1';
+        const bool no_worker = !tunables().worker;
         if (no_worker || source_is_small(n)) {   // (a small source is one launch: not worth a hand-over)
             int rc = load_source_queue(ctx, d_raw, n, stride, known);
             if (rc) return rc;
@@ -884,8 +873,7 @@ bool criteria_has_converged(IcpState &s)
 
 int *seed_ptr(rsreg_ctx *ctx)
 {
-    static const bool off = std::getenv("RSREG_NO_SEED") && std::getenv("RSREG_NO_SEED")[0] == '1';
-    return off ? nullptr : ctx->d_seed.as<int>();
+    return !tunables().seed ? nullptr : ctx->d_seed.as<int>();
 }
 
 // rsreg_icp_begin leaves "working copy = guess * source, no seeds" pending: the first search launch of the fused
@@ -907,10 +895,14 @@ int ensure_restarted(rsreg_ctx *ctx)
 // diagnostic: per-wave start/end stamps of the last fused launch, dumped at rsreg_icp_end
 unsigned long long *wave_times_ptr(rsreg_ctx *ctx, uint32_t n)
 {
-    static const bool on = std::getenv("RSREG_WAVE_TIMES") != nullptr;
-    if (!on) return nullptr;
+#ifndef RSREG_DIAG
+    (void)ctx; (void)n;
+    return nullptr;
+#else
+    if (!tunables().wave_times) return nullptr;
     if (ctx->d_brick.reserve(((size_t)n / 64 + 2) * 256 + (size_t)n * 4 + 64) != hipSuccess) return nullptr;   // (a scheduled launch has up to 2x the waves)
     return ctx->d_brick.as<unsigned long long>();
+#endif
 }
 
 bool filters_on(const rsreg_icp_params &p)
@@ -1118,21 +1110,19 @@ struct SchedCfg {
     int at_launch = 1;             // the launch that is timed (0 = the first, which runs without seeds)
 };
 
-SchedCfg sched_cfg()   // (read per launch: a handful of getenv calls; lets one process compare settings)
+SchedCfg sched_cfg()
 {
-    const SchedCfg cfg = [] {
-        SchedCfg c;
-        if (const char *e = std::getenv("RSREG_SCHED")) c.on = e[0] != '0';
-        if (const char *e = std::getenv("RSREG_SCHED_F4")) c.f4 = std::atof(e);
-        if (const char *e = std::getenv("RSREG_SCHED_F2")) c.f2 = std::atof(e);
-        if (const char *e = std::getenv("RSREG_SCHED_MIN_TILES")) c.min_tiles = (uint32_t)std::atoll(e);
-        if (const char *e = std::getenv("RSREG_SCHED_AT")) c.at_launch = std::atoi(e);
-        c.f4 = std::min(std::max(c.f4, 0.0), 1.0);
-        c.f2 = std::min(std::max(c.f2, 0.0), 1.0 - c.f4);   // (every tile at most once: up to 4 workgroups per tile)
-        return c;
-    }();
-    return cfg;
+    const Tunables &t = tunables();
+    SchedCfg c;
+    c.on = t.sched;
+    c.f4 = t.sched_f4;
+    c.f2 = t.sched_f2;
+    c.min_tiles = t.sched_min_tiles;
+    c.at_launch = t.sched_at;
+    return c;
 }
+
+constexpr int kSchedKeepFor = 8;   // alignments a tile schedule serves before a launch is timed again
 
 struct SchedBufs {
     uint32_t *items, *cost, *done, *keys, *keys_alt, *vals, *vals_alt;
@@ -1141,7 +1131,8 @@ struct SchedBufs {
 SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
 {
     uint32_t *p = ctx->d_sched.as<uint32_t>();
-    const size_t t = n_tiles;
+    (void)n_tiles;
+    const size_t t = ctx->sched_cap_tiles;   // (capacity, not this source's tiles: the arrays stay put from one alignment to the next)
     return SchedBufs{p, p + 4 * t, p + 6 * t, p + 7 * t, p + 8 * t, p + 9 * t, p + 10 * t};
 }
 
@@ -1308,20 +1299,25 @@ int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
-    static const bool xcd = !(std::getenv("RSREG_SCHED_XCD") && std::getenv("RSREG_SCHED_XCD")[0] == '0');
+    const bool xcd = tunables().sched_xcd;
     if (xcd) {
         n4 -= n4 % 8u;   // (an eighth of the splits to every run)
         n2 -= n2 % 8u;
-        static const uint32_t deal = std::getenv("RSREG_SCHED_XCD_DEAL") ? (uint32_t)std::atoi(std::getenv("RSREG_SCHED_XCD_DEAL")) : 32u;
+        const uint32_t deal = tunables().sched_xcd_deal;
         k_sched_build_xcd<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, n_tiles + 3 * n4 + n2, deal, sb.items, sb.done);
     } else {
         k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, sb.items, sb.done);
     }
     RSREG_HIP(ctx, hipGetLastError());
     ctx->icp.sched_items = n_tiles + 3 * n4 + n2;
-    if (std::getenv("RSREG_SCHED_VERBOSE"))
+    ctx->sched_keep_items = ctx->icp.sched_items;   // (kept for the alignments to come: launch_fused)
+    ctx->sched_keep_tiles = n_tiles;
+    ctx->sched_keep_age = 0;
+#ifdef RSREG_DIAG
+    if (tunables().sched_verbose)
         std::fprintf(stderr, "[rsreg] tile schedule: %u tiles, %u searched by 4 lanes per query, %u by 2, %u workgroups\n", n_tiles, n4, n2,
                      ctx->icp.sched_items);
+#endif
     ctx->icp.sched_ready = true;
     return RSREG_OK;
 }
@@ -1336,7 +1332,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     // the first launch of an alignment over the dense index reads the source itself, applies the guess and starts without
     // seeds: k_restart_source's work, one launch and a pass over the working copy saved (never with a schedule in
     // place: that is built from a launch of this alignment)
-    static const bool restart_apart = std::getenv("RSREG_RESTART_APART") && std::getenv("RSREG_RESTART_APART")[0] == '1';
+    const bool restart_apart = tunables().restart_apart;
     const bool restart_here = s.restart_pending && ctx->grid.dense && !s.sched_ready && !s.pending_transform && !restart_apart;
     if (restart_here) {
         s.restart_pending = false;
@@ -1349,12 +1345,17 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
         const GridDev g = grid_dev(ctx, s.prm.max_correspondence_distance);
         if (ctx->grid.dense) {
             unsigned long long *wt = wave_times_ptr(ctx, n);
-            static const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
             // (the search beyond ring 1 comes in two forms; each instantiation carries only the one its grid uses)
-            const bool blocks = ctx->grid.max_ring <= 4 && !std::getenv("RSREG_FAR_ROWS");
+            const bool blocks = ctx->grid.max_ring <= 4 && !tunables().far_rows;
+#ifdef RSREG_DIAG
+            const bool light = tunables().wave_times_light;
             auto kern = wt ? (light ? (blocks ? k_icp_fused_dense<2, 1> : k_icp_fused_dense<2, 2>)
                                     : (blocks ? k_icp_fused_dense<1, 1> : k_icp_fused_dense<1, 2>))
                            : (blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>);
+#else
+            const bool light = false;
+            auto kern = blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>;
+#endif
             const SchedCfg cfg = sched_cfg();
             const uint32_t n_tiles = reduce_blocks(n);
             const bool sched_ok = cfg.on && (!wt || light) && n_tiles >= cfg.min_tiles && n_tiles < (1u << 24);
@@ -1366,9 +1367,22 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 sc.done = sb.done;
                 sc.pos = ctx->d_corr_pos.as<int>();
                 sc.d2 = ctx->d_corr_d2.as<float>();
+                // The schedule of an earlier alignment of this context serves this one too, from the launch that would otherwise
+                // be timed: the long tiles sit on the same (near, densely sampled) surfaces from one frame to the next, a schedule is
+                // an order of work and never wrong, and the timed launch runs unscheduled (140 against 93 us at 10^6 points).
+                // Carried for at most kSchedKeepFor alignments and only to a source of about as many tiles; RSREG_SCHED_KEEP=0: never.
+                if (!s.sched_ready && !restart_here && s.fused_launches >= cfg.at_launch && ctx->sched_keep_items && tunables().sched_keep &&
+                    ctx->sched_keep_age < kSchedKeepFor && n_tiles + n_tiles / 8 >= ctx->sched_keep_tiles && ctx->sched_keep_tiles + ctx->sched_keep_tiles / 8 >= n_tiles) {
+                    s.sched_ready = true;
+                    s.sched_carried = true;
+                    s.sched_items = ctx->sched_keep_items + (n_tiles > ctx->sched_keep_tiles ? n_tiles - ctx->sched_keep_tiles : 0u);
+                    ++ctx->sched_keep_age;
+                }
                 if (s.sched_ready) {
                     sc.items = sb.items;
                     grid = s.sched_items;
+                    sc.n_items = s.sched_carried ? ctx->sched_keep_items : grid;
+                    sc.first_extra = ctx->sched_keep_tiles;
                 } else if (s.fused_launches == cfg.at_launch) {
                     sc.cost = sb.cost;
                 }
@@ -1384,6 +1398,7 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 if (rc) return rc;
             }
             s.fused_launches++;
+            if (sc.items) s.n_sched_launches++;
         }
         else
             k_icp_fused<<<reduce_blocks(n), kTile, 0, ctx->stream>>>(
@@ -1586,6 +1601,7 @@ int rsreg_device_count(int *count)
 
 int rsreg_ctx_create(int device_id, void *stream, rsreg_ctx **out)
 {
+    rsreg::tunables_refresh();   // (the switches of csrc/tunables.hpp: as the environment has them now)
     if (!out) return RSREG_ERR_INVALID_ARG;
     *out = nullptr;
     int n = 0;
@@ -1935,7 +1951,8 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         ctx->host_timing.aligned_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (const char *sd_path = std::getenv("RSREG_DUMP_SEED")) {   // dev: the position every query matched last, and the queries
+#ifdef RSREG_DIAG
+    if (const char *sd_path = tunables().dump_seed) {   // dev: the position every query matched last, and the queries
         const size_t nq = ctx->n_work;
         std::vector<int> h(nq);
         std::vector<float> hq(nq * 4);
@@ -1951,9 +1968,9 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
             std::fclose(f);
         }
     }
-    if (const char *wt_path = std::getenv("RSREG_WAVE_TIMES")) {
+    if (const char *wt_path = tunables().wave_times) {
         if (ctx->grid.dense == 1 && ctx->n_work) {
-            const bool light = std::getenv("RSREG_WAVE_TIMES_LIGHT") != nullptr;
+            const bool light = tunables().wave_times_light;
             const size_t nw = light ? (size_t)(ctx->icp.sched_ready ? ctx->icp.sched_items : reduce_blocks(ctx->n_work)) * kTileWaves
                                     : (ctx->n_work + 63) / 64;
             std::vector<unsigned long long> h(16 * nw + (light ? 0 : (ctx->n_work + 1) / 2));   // wave records, then a uint32 of step counts per lane
@@ -1964,6 +1981,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
             }
         }
     }
+#endif
     if (result) {
         std::memset(result, 0, sizeof(*result));
         std::memcpy(result->transform, s.final_t.m, 64);
@@ -1974,9 +1992,11 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         result->mse = s.cur_mse;
         std::memcpy(result->sums_last, s.sums_last, sizeof(s.sums_last));
         result->n_nn_launches = s.n_nn_launches;
+        result->n_scheduled_launches = s.n_sched_launches;
         if (ctx->profiling) {
             result->ms_nn = sum_events(ctx, ctx->ev_nn);
-            if (std::getenv("RSREG_DUMP_NN_MS")) {   // dev: duration of every search launch of this call
+#ifdef RSREG_DIAG
+            if (tunables().dump_nn_ms) {   // diagnostic builds: duration of every search launch of this call
                 std::fprintf(stderr, "[rsreg] search launches (us):");
                 for (auto &p : ctx->ev_nn) {
                     float t = 0;
@@ -1985,6 +2005,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
                 }
                 std::fprintf(stderr, "\n");
             }
+#endif
             result->ms_reduce = sum_events(ctx, ctx->ev_reduce);
             if (ctx->ev_reduce.empty())   // fused pipelines: everything between two consecutive search kernels
                 for (size_t k = 0; k + 1 < ctx->ev_nn.size(); ++k) {
@@ -2049,7 +2070,11 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
 {
     if (!ctx || !info) return RSREG_ERR_INVALID_ARG;
     if (!ctx->have_target) return RSREG_ERR_NO_TARGET;
-    static const bool want_max = std::getenv("RSREG_GRID_STATS") != nullptr;   // a 16M-entry table scan: only on request
+#ifdef RSREG_DIAG
+    const bool want_max = tunables().grid_stats;   // (diagnostic builds: a pass over the occupied cells, only on request)
+#else
+    const bool want_max = false;
+#endif
     if (want_max && ctx->grid.dense == 1 && ctx->grid_info.max_points_per_cell == 0 && ctx->grid.n_points > 0) {
         const size_t total = (size_t)(ctx->grid.dims[0] + 2) * (ctx->grid.dims[1] + 2) * (ctx->grid.dims[2] + 2);
         uint32_t *d = ctx->d_misc.as<uint32_t>() + 20;

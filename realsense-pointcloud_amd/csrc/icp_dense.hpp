@@ -821,6 +821,11 @@ struct TileSched {
     int *pos;                // per query: where the parts of a split tile leave their matches
     float *d2;
     uint32_t n_tiles;        // slabs of `partials`
+    // A schedule carried over from an earlier alignment of this context (icp.hip: launch_fused) was built for another source:
+    // workgroups [0, n_items) take its items -- those of tiles this source does not have do nothing --, the workgroups
+    // behind them the tiles it did not know, first_extra + 0, 1, ..., unsplit.  (A schedule of this alignment's own: n_items =
+    // the grid, no extras.)
+    uint32_t n_items, first_extra;
 };
 
 // device-wide visible accesses for what the parts of a split tile hand to each other inside one launch
@@ -915,9 +920,10 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
                                                            int *seed, unsigned long long *wave_times, const IcpDevState *dev,
                                                            TileSched sched)
 {
-    const uint32_t item = sched.items ? sched.items[blockIdx.x] : blockIdx.x;
+    const uint32_t item = sched.items ? (blockIdx.x < sched.n_items ? sched.items[blockIdx.x] : sched.first_extra + (blockIdx.x - sched.n_items)) : blockIdx.x;
     if (item == 0xffffffffu) return;   // (a workgroup the schedule has nothing for)
     const uint32_t tile = item & 0xffffffu, lg = (item >> 28) & 3u;
+    if (tile >= sched.n_tiles) return;   // (a carried schedule's tile that this source does not have)
     const uint32_t i = tile * kTile + threadIdx.x;
     if (dev && !restart) {   // device-resident loop: the increment comes from the previous k_icp_solve
         T = dev->t_inc;

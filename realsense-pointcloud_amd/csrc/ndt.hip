@@ -166,7 +166,7 @@ int derivative_pass_pp(NdtRun &r, NdtPassParams &pp, bool store_trans)
         (void)hipEventRecord(e0, ctx->stream);
     }
     double *h = ctx->h_ndt.as<double>();
-    const bool watch = !ctx->comm && !ctx->profiling && !getenv("RSREG_NDT_NO_WATCH");
+    const bool watch = !ctx->comm && !ctx->profiling && tunables().ndt_watch;
     volatile uint64_t *flag = reinterpret_cast<volatile uint64_t *>(h + kNdtFlagSlot);
     const uint64_t seq = ++ctx->ndt_seq;
     *flag = 0;
@@ -249,17 +249,18 @@ bool line_search_fits(rsreg_ctx *ctx)
     return f > 0;
 }
 
-// computeStepLengthMT (More-Thuente): the state machine of ndt_math.hpp.  On one GPU all the passes of the search run in
-// ONE launch (k_ndt_line_search, which advances the machine itself); with a communicator, with profiling on, when the
-// workgroups of that launch do not fit the device together, or with RSREG_NDT_HOST_LS=1 the host advances it, a launch
-// pair and a wait per pass.  Both ways run the same source on the same sums in the same order: the same bits.
+// computeStepLengthMT (More-Thuente): the state machine of ndt_math.hpp, advanced by the host, a launch pair and a wait per
+// pass.  RSREG_NDT_RESIDENT_LS=1 (one GPU, no profiling): all the passes of the search in ONE launch (k_ndt_line_search,
+// which advances the machine itself) -- the same source on the same sums in the same order, the same bits
+// (tests/test_ndt_gpu.py), and measured no faster: a hand-over between workgroups of different XCDs costs what a kernel
+// boundary costs, so it is not the default.
 int step_length(NdtRun &r, const double *x, double *dir, double step_init, double step_max, double step_min,
                 double &score, double *grad, double *hess, double &a_out)
 {
     rsreg_ctx *ctx = r.ctx;
     NdtLs ls;
     ndt_ls_begin(ls, x, dir, step_init, step_max, step_min, score, grad, hess);
-    static const bool host_only = std::getenv("RSREG_NDT_HOST_LS") && std::getenv("RSREG_NDT_HOST_LS")[0] == '1';
+    const bool host_only = !tunables().ndt_resident_ls;
     bool resident = ls.phase != kNdtLsDone && !host_only && !ctx->comm && !ctx->profiling && !ctx->ndt_ls_failed && line_search_fits(ctx);
     if (resident) {
         RSREG_HIP(ctx, ctx->d_ndt_ctl.reserve(sizeof(NdtLsCtl) + 64));

@@ -512,29 +512,45 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_line_search(const float4 *src
                 __hip_atomic_fetch_add(&ctl->reduced, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            // the controller: the 28 sums through the state machine, then the next pass -- or the outcome
+        if (blockIdx.x == 0 && wave == 0) {
+            // the controller (workgroup 0's first wave): the 28 sums through the state machine, then the next pass -- or the
+            // outcome.  Its lanes fetch the sums and send the next pass's parameters side by side (one thread doing either word
+            // by word waits for every trip to memory in turn); lane 0 alone runs the state machine.
             uint32_t spin = 0;
-            while (ndt_load32(&ctl->reduced) < (uint32_t)kNdtAcc * pass && ++spin < kNdtLsSpins) __builtin_amdgcn_s_sleep(1);
+            if (lane == 0)
+                while (ndt_load32(&ctl->reduced) < (uint32_t)kNdtAcc * pass && ++spin < kNdtLsSpins) __builtin_amdgcn_s_sleep(1);
+            spin = __shfl(spin, 0);
             if (spin >= kNdtLsSpins) {
-                atomicExch(&ctl->error, 1u);
-                ndt_store64(&ctl->release, kNdtLsStop);
+                if (lane == 0) { atomicExch(&ctl->error, 1u); ndt_store64(&ctl->release, kNdtLsStop); }
             } else {
-                for (int k = 0; k < kNdtAcc; ++k) s_sums[k] = __longlong_as_double((long long)ndt_load64(&ctl->out[k]));
-                ndt_ls_consume(s_ls, s_sums);
-                if (s_ls.phase != kNdtLsDone) {
-                    ndt_fill_pass(s_pp, s_ls);   // (d1, d2, r2, n_vox stay)
+                if (lane < kNdtAcc) s_sums[lane] = __longlong_as_double((long long)ndt_load64(&ctl->out[lane]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int done = 0;
+                if (lane == 0) {
+                    ndt_ls_consume(s_ls, s_sums);
+                    done = s_ls.phase == kNdtLsDone ? 1 : 0;
+                    if (!done) ndt_fill_pass(s_pp, s_ls);   // (d1, d2, r2, n_vox stay)
+                }
+                done = __shfl(done, 0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (!done) {
                     const unsigned long long *l = reinterpret_cast<const unsigned long long *>(&s_pp);
-                    for (uint32_t w = 0; w < sizeof(NdtPassParams) / 8; ++w) ndt_store64(reinterpret_cast<unsigned long long *>(&ctl->pp) + w, l[w]);
+                    for (uint32_t w = lane; w < sizeof(NdtPassParams) / 8; w += 64u) ndt_store64(reinterpret_cast<unsigned long long *>(&ctl->pp) + w, l[w]);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    ndt_store64(&ctl->release, (unsigned long long)pass + 1ull);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) ndt_store64(&ctl->release, (unsigned long long)pass + 1ull);
                 } else {
                     const unsigned long long *l = reinterpret_cast<const unsigned long long *>(&s_ls);
                     unsigned long long *h = reinterpret_cast<unsigned long long *>(host_out);
-                    for (uint32_t w = 0; w < sizeof(NdtLs) / 8; ++w) h[w] = l[w];
+                    for (uint32_t w = lane; w < sizeof(NdtLs) / 8; w += 64u) h[w] = l[w];
                     __threadfence_system();
-                    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ndt_store64(&ctl->release, kNdtLsStop);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        ndt_store64(&ctl->release, kNdtLsStop);
+                    }
                 }
             }
         }

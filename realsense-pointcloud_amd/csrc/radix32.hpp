@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "osort.hpp"
+#include "tunables.hpp"
 
 namespace rsreg {
 
@@ -30,8 +31,7 @@ inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit)
 // Every sort of 32-bit keys is the library's own (RSREG_ROCPRIM_SORT=1: rocPRIM's public radix_sort_pairs instead, for A/B runs).
 inline bool radix32_pays(size_t n, unsigned bits)
 {
-    static const bool off = std::getenv("RSREG_ROCPRIM_SORT") && std::getenv("RSREG_ROCPRIM_SORT")[0] == '1';
-    return !off && bits > 0 && bits <= 32 && n < (1ull << 30);
+    return !tunables().rocprim_sort && bits > 0 && bits <= 32 && n < (1ull << 30);
 }
 
 __device__ __forceinline__ void radix32_clear(uint32_t *scratch, uint32_t words, uint32_t t, uint32_t threads) { osort_clear(scratch, words, t, threads); }

@@ -17,6 +17,7 @@
 
 #include "../../include/rsreg.h"
 #include "host_linalg.hpp"
+#include "tunables.hpp"
 #include "workers.hpp"
 
 namespace rsreg {
@@ -54,10 +55,7 @@ struct CloudPool {
     };
     std::vector<Slot> slots;
     size_t held = 0;
-    size_t limit = [] {
-        const char *e = std::getenv("RSREG_CLOUD_POOL_MB");
-        return (size_t)(e ? std::max(0ll, std::atoll(e)) : 4096ll) << 20;
-    }();
+    size_t limit = (size_t)tunables().cloud_pool_mb << 20;
 };
 
 struct PinnedBuf {
@@ -128,9 +126,11 @@ struct IcpState {
     bool restart_pending = false;    // d_cur = guess * d_src (and "no seeds") not done yet: ensure_restarted / launch_fused
     double ms_nn = 0, ms_reduce = 0, ms_transform = 0;
     int n_nn_launches = 0;
+    int n_sched_launches = 0;      // ... of them launched from a tile schedule
     int fused_launches = 0;        // fused dense launches of this alignment so far
     bool sched_ready = false;      // d_sched holds a tile schedule for this alignment
     uint32_t sched_items = 0;      // workgroups of a scheduled launch
+    bool sched_carried = false;    // ... whose schedule an earlier alignment of the context built
 };
 
 }  // namespace rsreg
@@ -155,6 +155,9 @@ struct rsreg_ctx {
     rsreg::DevBuf d_dense;        // dense mode: uint32[(nx+2)(ny+2)(nz+2)+1] first sorted point of EVERY cell, followed by one uint32 per cell: occupancy of its 27-cell neighbourhood
     rsreg::DevBuf d_pos_of;       // dense mode: uint32 per target record, its position in d_tgt_sorted
     rsreg::DevBuf d_sched;        // tile schedule of the fused dense kernel: items (4 per tile) | wave costs | done counters | sort scratch
+    uint32_t sched_cap_tiles = 0;        // tiles the buffer was laid out for (the arrays' offsets)
+    uint32_t sched_keep_items = 0, sched_keep_tiles = 0;   // the last schedule built in it: workgroups, tiles of its source (0: none)
+    int sched_keep_age = 0;              // alignments it has served since
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     rsreg::DevBuf d_cnt;          // counting build (cellsort.hpp): points per table slot, all zero between builds

@@ -1,0 +1,127 @@
+// tunables.hpp — every switch of the library the environment can set, parsed in one place (not where it is used).
+//
+// Product switches choose between mechanisms that give the same results (an A/B run, a fallback forced on for the parity
+// suite): they are documented in INTEGRATION.md.  Diagnostic switches (dumps, per-wave clock stamps, timing-only kernels)
+// exist only in builds with -DRSREG_DIAG (RSREG_CXXFLAGS=-DRSREG_DIAG; `python -c "import rsreg_amd.lib as l; print(l.build_diag())"`):
+// the shipped library has no switch that writes a file or changes a result.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+namespace rsreg {
+
+struct Tunables {
+    // ---- target index
+    double cell_cap = 0.014;               // RSREG_CELL_CAP: metres; a few D435i pixel pitches at 1-2 m (swept on MI355X: DESIGN.md §5)
+    long long dense_max_cells = 1ll << 28; // RSREG_DENSE_MAX_CELLS (RSREG_FORCE_HASH=1: 0): 1 GiB of cell starts at most (out of 288 GB)
+    bool keys64 = false;                   // RSREG_KEYS64=1: 64-bit sort keys whatever the grid
+    bool full_table = false;               // RSREG_FULL_TABLE=1: the sort-based build writes every table entry
+    bool far_rows = false;                 // RSREG_FAR_ROWS: the row search beyond ring 1 for every gate (default: only unbounded / wide gates)
+    bool wide_cells = true;                // RSREG_NO_WIDE_CELLS=1: cells never larger than the gate
+    bool adaptive_cell = true;             // RSREG_NO_ADAPTIVE_CELL=1: the brick-hash build never refines its cell size
+    bool box_cache = true;                 // RSREG_NO_BOX_CACHE=1: a cloud handle's bounding box is measured by every build / load
+    bool count_sort = true;                // RSREG_COUNT_SORT=0: the index by sorting (k_dense_keys, radix sort, k_dense_compact) instead of counting (cellsort.hpp)
+    bool scan_apart = false;               // RSREG_SCAN_APART=1: sort-based build: flag, scan, scatter as three launches
+    bool rocprim_sort = false;             // RSREG_ROCPRIM_SORT=1: rocPRIM's radix_sort_pairs instead of osort.hpp
+    // ---- source
+    bool sort_small = false;               // RSREG_SORT_SMALL=1: sources of <= 65 536 points are put into spatial order too
+    size_t plain_source_max = 65536;       // RSREG_PLAIN_SOURCE_MAX
+    int morton_bits = 23;                  // RSREG_MORTON_BITS: bits of the source's Morton keys (+ the invalid bit: three digit passes)
+    bool worker = true;                    // RSREG_NO_WORKER=1: the source load's host side on the caller's thread
+    bool seed = true;                      // RSREG_NO_SEED=1: searches never start from the previous iteration's match
+    bool restart_apart = false;            // RSREG_RESTART_APART=1: guess * source as a launch of its own
+    bool scan_target = true;               // RSREG_NO_SCAN: an index even for a handful of source points
+    // ---- tile schedule of the fused search kernel
+    bool sched = true;                     // RSREG_SCHED=0
+    double sched_f4 = 0.0, sched_f2 = 0.10;   // RSREG_SCHED_F4 / _F2: fractions of the tiles searched by 4 / 2 lanes per query
+    uint32_t sched_min_tiles = 1024;       // RSREG_SCHED_MIN_TILES
+    int sched_at = 1;                      // RSREG_SCHED_AT: the launch that is timed
+    bool sched_xcd = true;                 // RSREG_SCHED_XCD=0
+    uint32_t sched_xcd_deal = 32;          // RSREG_SCHED_XCD_DEAL
+    bool sched_keep = true;                // RSREG_SCHED_KEEP=0: every alignment times a launch of its own and builds its own schedule
+    // ---- clouds, NDT
+    long long cloud_pool_mb = 4096;        // RSREG_CLOUD_POOL_MB
+    bool upload_wait_staged = false;       // RSREG_UPLOAD_WAIT_STAGED=1
+    bool ndt_watch = true;                 // RSREG_NDT_NO_WATCH: hipStreamSynchronize instead of watching the stamped pass number
+    bool ndt_resident_ls = false;          // RSREG_NDT_RESIDENT_LS=1: all the passes of a line search in one launch (k_ndt_line_search; same bits, not faster: DESIGN.md §5e)
+#ifdef RSREG_DIAG
+    const char *dump_seed = nullptr, *wave_times = nullptr, *edge_dump = nullptr;   // RSREG_DUMP_SEED, RSREG_WAVE_TIMES, RSREG_EDGE_DUMP: files
+    bool wave_times_light = false, dump_nn_ms = false, sched_verbose = false, grid_stats = false;
+    uint32_t debug_skip = 0;               // RSREG_DEBUG_SKIP: results WRONG (timing experiments)
+#endif
+};
+
+inline Tunables tunables_from_environment()
+{
+    Tunables v;
+    auto on = [](const char *n) { const char *e = std::getenv(n); return e && e[0] == '1'; };
+    auto off = [](const char *n) { const char *e = std::getenv(n); return e && e[0] == '0'; };
+    auto set = [](const char *n) { return std::getenv(n) != nullptr; };
+    if (const char *e = std::getenv("RSREG_CELL_CAP")) { const double c = std::atof(e); if (c > 0) v.cell_cap = c; }
+    if (const char *e = std::getenv("RSREG_DENSE_MAX_CELLS")) v.dense_max_cells = std::atoll(e);
+    if (on("RSREG_FORCE_HASH")) v.dense_max_cells = 0;
+    v.keys64 = on("RSREG_KEYS64");
+    v.full_table = on("RSREG_FULL_TABLE");
+    v.far_rows = set("RSREG_FAR_ROWS");
+    v.wide_cells = !on("RSREG_NO_WIDE_CELLS");
+    v.adaptive_cell = !on("RSREG_NO_ADAPTIVE_CELL");
+    v.box_cache = !on("RSREG_NO_BOX_CACHE");
+    v.count_sort = !off("RSREG_COUNT_SORT");
+    v.scan_apart = on("RSREG_SCAN_APART");
+    v.rocprim_sort = on("RSREG_ROCPRIM_SORT");
+    v.sort_small = on("RSREG_SORT_SMALL");
+    if (const char *e = std::getenv("RSREG_PLAIN_SOURCE_MAX")) v.plain_source_max = (size_t)std::atoll(e);
+    if (const char *e = std::getenv("RSREG_MORTON_BITS")) v.morton_bits = std::max(6, std::min(31, std::atoi(e)));
+    v.worker = !on("RSREG_NO_WORKER");
+    v.seed = !on("RSREG_NO_SEED");
+    v.restart_apart = on("RSREG_RESTART_APART");
+    v.scan_target = !set("RSREG_NO_SCAN");
+    v.sched = !off("RSREG_SCHED");
+    if (const char *e = std::getenv("RSREG_SCHED_F4")) v.sched_f4 = std::atof(e);
+    if (const char *e = std::getenv("RSREG_SCHED_F2")) v.sched_f2 = std::atof(e);
+    if (const char *e = std::getenv("RSREG_SCHED_MIN_TILES")) v.sched_min_tiles = (uint32_t)std::atoll(e);
+    if (const char *e = std::getenv("RSREG_SCHED_AT")) v.sched_at = std::atoi(e);
+    v.sched_f4 = std::min(std::max(v.sched_f4, 0.0), 1.0);
+    v.sched_f2 = std::min(std::max(v.sched_f2, 0.0), 1.0 - v.sched_f4);   // (every tile at most once: up to 4 workgroups per tile)
+    v.sched_xcd = !off("RSREG_SCHED_XCD");
+    if (const char *e = std::getenv("RSREG_SCHED_XCD_DEAL")) v.sched_xcd_deal = (uint32_t)std::atoi(e);
+    v.sched_keep = !off("RSREG_SCHED_KEEP");
+    if (const char *e = std::getenv("RSREG_CLOUD_POOL_MB")) v.cloud_pool_mb = std::max(0ll, std::atoll(e));
+    v.upload_wait_staged = on("RSREG_UPLOAD_WAIT_STAGED");
+    v.ndt_watch = !set("RSREG_NDT_NO_WATCH");
+    v.ndt_resident_ls = on("RSREG_NDT_RESIDENT_LS");
+#ifdef RSREG_DIAG
+    v.dump_seed = std::getenv("RSREG_DUMP_SEED");
+    v.wave_times = std::getenv("RSREG_WAVE_TIMES");
+    v.edge_dump = std::getenv("RSREG_EDGE_DUMP");
+    v.wave_times_light = set("RSREG_WAVE_TIMES_LIGHT");
+    v.dump_nn_ms = set("RSREG_DUMP_NN_MS");
+    v.sched_verbose = set("RSREG_SCHED_VERBOSE");
+    v.grid_stats = set("RSREG_GRID_STATS");
+    if (const char *e = std::getenv("RSREG_DEBUG_SKIP")) v.debug_skip = (uint32_t)std::atoi(e);
+#endif
+    return v;
+}
+
+inline Tunables &tunables_storage()
+{
+    static Tunables t = tunables_from_environment();
+    return t;
+}
+
+// the switches as the environment had them when the process first asked -- or when a context was last created
+// (rsreg_ctx_create looks again, so that one process can compare settings context by context; nothing is written when the
+// environment has not changed, so contexts at work on other threads are not disturbed)
+inline const Tunables &tunables() { return tunables_storage(); }
+
+inline void tunables_refresh()
+{
+    const Tunables now = tunables_from_environment();
+    Tunables &cur = tunables_storage();
+    if (std::memcmp(&now, &cur, sizeof(Tunables)) != 0) cur = now;
+}
+
+}  // namespace rsreg

@@ -9,7 +9,11 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SO_PATH = os.environ.get("RSREG_SO") or os.path.join(_HERE, "librsreg.so")   # (RSREG_SO: dev, an experiment build of the library)
+# RSREG_DIAG=1 (dev tools: per-launch times, wave stamps, dumps): the diagnostic build of the library, librsreg_diag.so, compiled
+# with -DRSREG_DIAG -- the shipped librsreg.so has no switch that writes a file or changes a result (csrc/tunables.hpp).
+# RSREG_SO (dev): an experiment build of the library.
+DIAG = os.environ.get("RSREG_DIAG", "") == "1"
+SO_PATH = os.environ.get("RSREG_SO") or os.path.join(_HERE, "librsreg_diag.so" if DIAG else "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip", "edges.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
@@ -66,7 +70,7 @@ class IcpResult(C.Structure):
         ("iterations", C.c_int32), ("reserved0", C.c_int32), ("n_correspondences", C.c_uint64),
         ("mse", C.c_double), ("sums_last", C.c_double * NUM_SUMS), ("ms_total", C.c_double),
         ("ms_nn", C.c_double), ("ms_reduce", C.c_double), ("ms_transform", C.c_double),
-        ("n_nn_launches", C.c_int32), ("reserved1", C.c_int32), ("ms_allreduce", C.c_double),
+        ("n_nn_launches", C.c_int32), ("n_scheduled_launches", C.c_int32), ("ms_allreduce", C.c_double),
     ]
 
 
@@ -95,7 +99,7 @@ class HostTiming(C.Structure):
 def hipcc_command(out=SO_PATH):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    extra = os.environ.get("RSREG_CXXFLAGS", "").split()   # (dev: -D switches of experiment builds)
+    extra = (["-DRSREG_DIAG"] if DIAG else []) + os.environ.get("RSREG_CXXFLAGS", "").split()   # (dev: -D switches of experiment builds)
     return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
             "-Wno-unused-result", *extra, *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"]
 
@@ -109,8 +113,11 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def _flags():
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+DIAG_SO_PATH = os.path.join(_HERE, "librsreg_diag.so")
+
+
+def _flags(diag=DIAG):
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", *(["-DRSREG_DIAG"] if diag else []),
             *os.environ.get("RSREG_CXXFLAGS", "").split()]   # (dev: -D switches of experiment builds)
 
 
@@ -120,12 +127,14 @@ def build(force=False, verbose=False, out=SO_PATH, obj_dir=None):
     of its wall time, and an edit of one file recompiles that file only."""
     if not force and out == SO_PATH and not needs_build():
         return SO_PATH
+    if out == SO_PATH and os.environ.get("RSREG_SO"):
+        raise RuntimeError("RSREG_SO names a library that is missing or older than the sources: build it where it came from")
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj_dir = obj_dir or os.path.join(CSRC, "_obj" + ("" if out == SO_PATH else "_" + os.path.splitext(os.path.basename(out))[0]))
     os.makedirs(obj_dir, exist_ok=True)
-    flags = _flags()
+    flags = _flags(DIAG or out == DIAG_SO_PATH)
     stamp = os.path.join(obj_dir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     hdrs = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(ROOT, "include", "rsreg.h"), os.path.join(ROOT, "include", "rsreg", "lzf.hpp")]
@@ -151,6 +160,17 @@ def build(force=False, verbose=False, out=SO_PATH, obj_dir=None):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout[-4000:])
     return out
+
+
+def build_diag(force=False):
+    """The diagnostic build (-DRSREG_DIAG: dumps, per-wave stamps, per-launch times) next to the shipped library: what the dev
+    tools and the two tests that read a dump load (RSREG_DIAG=1 in a process's environment makes lib() load it)."""
+    if not force and os.path.exists(DIAG_SO_PATH):
+        t = os.path.getmtime(DIAG_SO_PATH)
+        deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "rsreg.h")]
+        if not any(os.path.getmtime(d) > t for d in deps if os.path.exists(d)):
+            return DIAG_SO_PATH
+    return build(force=True, out=DIAG_SO_PATH)
 
 
 _lib = None

@@ -195,3 +195,29 @@ def test_ndt_edge_cases(api, rs):
     n = _ndt(api, bad, pts)                # collinear target: eigenvalue floor keeps it usable
     n.align()
     assert np.isfinite(n.getFinalTransformation()).all()
+
+
+def test_line_search_in_one_launch_gives_the_same_bits(api, rs, monkeypatch):
+    """RSREG_NDT_RESIDENT_LS=1: all the derivative passes of a More-Thuente line search in one launch (k_ndt_line_search: 512
+    resident workgroups, grid-wide counts, the state machine of csrc/ndt_math.hpp advanced on the device) against the default,
+    a launch pair and a wait per pass (ndt_edge_based_registration.hpp:38-43,86-92).  Same sums in the same order through the
+    same source: the same transform, score and pass count, bit for bit."""
+    tgt, src = rs.synth.render_frame(0, "50k", "parity"), rs.synth.render_frame(1, "50k", "parity")
+    guess = rs.synth.small_transform(0.4, (0.01, -0.005, 0.008)).astype(np.float32)
+
+    def run():
+        n = api.NormalDistributionsTransform(api.Context(0))   # (a context looks at the environment when it is created)
+        n.params = api.ndt_params(reference=True)
+        n.setInputSource(src)
+        n.setInputTarget(tgt)
+        out = n.align(guess)
+        r = n.result
+        return (bytes(r.transform), r.score, r.iterations, r.n_derivative_passes, r.converged, np.stack([out.points[k] for k in "xyz"]).tobytes())
+
+    monkeypatch.delenv("RSREG_NDT_RESIDENT_LS", raising=False)
+    base = run()
+    monkeypatch.setenv("RSREG_NDT_RESIDENT_LS", "1")
+    for _ in range(3):
+        assert run() == base
+    monkeypatch.delenv("RSREG_NDT_RESIDENT_LS")
+    assert base[3] > 3   # several passes: a line search did run

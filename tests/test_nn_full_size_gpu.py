@@ -1,6 +1,7 @@
 """The 1 M bench pair at full size: every match of the last fused search launch against scipy's cKDTree (an exact
-search that shares nothing with the engine).  `RSREG_DUMP_SEED` makes `rsreg_icp_align` write the position every
-query matched, the queries themselves and the sorted target records to a file when it ends."""
+search that shares nothing with the engine).  `RSREG_DUMP_SEED` makes the diagnostic build's
+`rsreg_icp_align` write the position every query matched, the queries themselves and the sorted target records to a file
+when it ends."""
 import os
 
 import numpy as np
@@ -19,27 +20,49 @@ def api(rs):
     return a
 
 
+CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import rsreg_amd
+from rsreg_amd import api, synth
+tgt, src = synth.render_frame(0, "N1M", "bench"), synth.render_frame(1, "N1M", "bench")
+guess = synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+icp = api.IterativeClosestPoint(api.Context(0))
+icp.params = api.icp_params(max_iterations=4, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=%(gate)r)
+icp.setInputSource(src)
+icp.setInputTarget(tgt)
+icp.align(guess)
+gi = icp.grid_info()
+print("RESULT", gi.index_kind, int(gi.n_source_distinct), int(icp.result.n_scheduled_launches))
+'''
+
+
 @pytest.mark.parametrize("sched", ["default schedule", "every tile split", "unscheduled"])
-def test_matches_of_the_1m_pair_against_ckdtree(api, rs, monkeypatch, tmp_path, sched):
+def test_matches_of_the_1m_pair_against_ckdtree(api, rs, tmp_path, sched):
+    """The dump is a diagnostic (csrc/tunables.hpp: the shipped library writes no file): the alignment runs in a child
+    process on the diagnostic build of the same sources (RSREG_DIAG=1 -> librsreg_diag.so, the product kernel's own
+    instantiation), the matches are checked here."""
+    import subprocess
+    import sys
+    from rsreg_amd import lib
+    lib.build_diag()
     gate = 0.05
     path = str(tmp_path / "seed.bin")
-    monkeypatch.setenv("RSREG_DUMP_SEED", path)
+    env = dict(os.environ, RSREG_DIAG="1", RSREG_DUMP_SEED=path)
+    env.pop("RSREG_SO", None)
     if sched == "unscheduled":
-        monkeypatch.setenv("RSREG_SCHED", "0")
+        env["RSREG_SCHED"] = "0"
     elif sched == "every tile split":
-        monkeypatch.setenv("RSREG_SCHED_MIN_TILES", "1")
-        monkeypatch.setenv("RSREG_SCHED_F4", "0.5")
-        monkeypatch.setenv("RSREG_SCHED_F2", "0.5")
-    tgt, src = rs.synth.render_frame(0, "N1M", "bench"), rs.synth.render_frame(1, "N1M", "bench")
-    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
-    icp = api.IterativeClosestPoint(api.Context(0))
-    icp.params = api.icp_params(max_iterations=4, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=gate)
-    icp.setInputSource(src)
-    icp.setInputTarget(tgt)
-    icp.align(guess)
-    if icp.grid_info().index_kind != 1:
+        env.update(RSREG_SCHED_MIN_TILES="1", RSREG_SCHED_F4="0.5", RSREG_SCHED_F2="0.5")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": root, "gate": gate}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    kind, n, n_sched = [int(v) for v in [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()[1:]]
+    if kind != 1:
         pytest.skip("the dump belongs to the dense-table search")
-    n = int(icp.grid_info().n_source_distinct)
+    assert (n_sched > 0) == (sched != "unscheduled")
     raw = np.fromfile(path, dtype=np.int32)
     seed = raw[:n]
     q = raw[n:5 * n].view(np.float32).reshape(n, 4)

@@ -8,6 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["RSREG_DUMP_NN_MS"] = "1"
+os.environ["RSREG_DIAG"] = "1"   # (per-launch times, wave stamps and dumps are the diagnostic build's: librsreg_diag.so, csrc/tunables.hpp)
 import rsreg_amd  # noqa: E402,F401
 from rsreg_amd import api, synth  # noqa: E402
 

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
+os.environ["RSREG_DIAG"] = "1"   # (per-launch times, wave stamps and dumps are the diagnostic build's: librsreg_diag.so, csrc/tunables.hpp)
     import rsreg_amd  # noqa: F401
     from rsreg_amd import api, synth
     tgt, src = synth.render_frame(0, "N1M", "bench"), synth.render_frame(1, "N1M", "bench")

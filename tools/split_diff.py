@@ -1,6 +1,7 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+os.environ["RSREG_DIAG"] = "1"   # (per-launch times, wave stamps and dumps are the diagnostic build's: librsreg_diag.so, csrc/tunables.hpp)
 import rsreg_amd
 from rsreg_amd import api, synth
 size = sys.argv[1]

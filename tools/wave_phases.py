@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 path = os.path.join(tempfile.gettempdir(), "rsreg_wave_times.bin")
 os.environ["RSREG_WAVE_TIMES"] = path
+os.environ["RSREG_DIAG"] = "1"   # (per-launch times, wave stamps and dumps are the diagnostic build's: librsreg_diag.so, csrc/tunables.hpp)
 import rsreg_amd  # noqa: E402
 from rsreg_amd import api, synth  # noqa: E402
 

@@ -278,9 +278,18 @@ __global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, 
         const int dz = r / 3, dy = r % 3;   // the (y, z) offset, as seen from the cell whose word is written
         const int row = slot - ((dz - 1) * sxy + (dy - 1) * sx);
         const int sh = dz * 9 + dy * 3;
-        atomicOr(&nbr[row], own << sh);
-        if (owns_right) atomicOr(&nbr[row + 1], right << sh);
-        if (owns_left) atomicOr(&nbr[row - 1], left << sh);
+        // the words of row - 1, row, row + 1 are neighbours in memory: the one that shares an aligned 8-byte pair with
+        // `row` goes out with it in ONE 64-bit atomic (a lone cell -- an edge cloud is lines in space -- 18 atomics instead of 27)
+        const uint32_t w_own = own << sh, w_right = owns_right ? right << sh : 0u, w_left = owns_left ? left << sh : 0u;
+        if (reinterpret_cast<uintptr_t>(nbr + row) & 4u) {   // (row - 1, row) is the aligned pair
+            if (w_left) atomicOr(reinterpret_cast<unsigned long long *>(nbr + row - 1), (unsigned long long)w_left | (unsigned long long)w_own << 32);
+            else atomicOr(&nbr[row], w_own);
+            if (w_right) atomicOr(&nbr[row + 1], w_right);
+        } else {         // (row, row + 1)
+            if (w_right) atomicOr(reinterpret_cast<unsigned long long *>(nbr + row), (unsigned long long)w_own | (unsigned long long)w_right << 32);
+            else atomicOr(&nbr[row], w_own);
+            if (w_left) atomicOr(&nbr[row - 1], w_left);
+        }
     }
 }
 

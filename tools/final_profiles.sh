@@ -2,7 +2,7 @@
 # The round's committed measurements in one gpurun call (MI355X box): bench line, kernel statistics, PMC passes (HBM traffic,
 # SQ counters), step breakdown, reference mode, wave timeline, scheme times.  usage: tools/final_profiles.sh <tag, e.g. r04>
 # Everything lands under gpurun_out/<tag>_final/; copy what is to be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_final; mkdir -p $O
 export TMPDIR=/tmp
 step() { echo "[final_profiles] $1 ($(date +%T))"; }
@@ -15,7 +15,7 @@ cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench.csv
 step "traffic"
 (cd /tmp && timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1)
 (cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1)
-python tools/make_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json "round 4" > $O/traffic.log 2>&1; tail -2 $O/traffic.log
+python tools/make_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json "round 5" > $O/traffic.log 2>&1; tail -2 $O/traffic.log
 step "SQ counters"
 : > $O/pmc_sq_counters.txt
 k=0
@@ -32,6 +32,9 @@ step "launch times, wave timeline"
 for s in N1M N300 50k; do echo "== $s" >> $O/launch_times.txt; timeout -k 10 200 python tools/iter_times.py $s 30 2 2>&1 | grep -v amdgpu.ids | cut -c1-330 >> $O/launch_times.txt; done
 for s in 125k; do echo "== 125 k points (400 x 313)" >> $O/launch_times.txt; timeout -k 10 200 python tools/iter_times.py 400x313 30 2 2>&1 | grep -v amdgpu.ids | cut -c1-330 >> $O/launch_times.txt; done
 RSREG_WAVE_TIMELINE_JSON=$O/wave_timeline.json timeout -k 10 300 python tools/wave_timeline.py N1M 30 > $O/wave_timeline_n1m.txt 2>&1
+step "index build and source load, kernel by kernel"
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace -d $O/kb -o b -- python3 $GRAFT_REPO_ROOT/tools/build_kernels.py N1M 20 > $O/kb.log 2>&1)
+python tools/kstats.py $O/kb > $O/build_kernels.txt 2>&1 < /dev/null; head -24 $O/build_kernels.txt
 step "step breakdown, reference mode"
 for s in N1M N300 50k; do
   timeout -k 10 200 python tools/step_breakdown.py $s 30 source-first 2>&1 | grep -v amdgpu.ids >> $O/step_breakdown.txt
@@ -39,6 +42,8 @@ for s in N1M N300 50k; do
 done
 echo "== python tools/cpp_pair_time.py: the same pair through tools/cpp/pair_time.cpp, a C++ caller of the C ABI (no Python between the calls)" >> $O/reference_mode.txt
 timeout -k 10 300 python tools/cpp_pair_time.py 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
+echo "== python tools/cpp_pair_time.py --host: the literal call surface, host clouds in, 4x4 + aligned cloud out (rsreg_ctx_host_timing's breakdown inside)" >> $O/reference_mode.txt
+timeout -k 10 300 python tools/cpp_pair_time.py N1M N300 50k --host 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 timeout -k 10 200 python tools/small_align.py 300 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 timeout -k 10 200 python tools/small_ndt.py 100 2>&1 | grep -v amdgpu.ids >> $O/reference_mode.txt
 cat $O/step_breakdown.txt $O/reference_mode.txt
@@ -49,5 +54,5 @@ step "other workloads"
 timeout -k 10 300 python bench.py --workload chain --steps 5 --warmup 1 > $O/bench_chain_n1.json 2> $O/bench_chain.err; cut -c1-300 $O/bench_chain_n1.json
 timeout -k 10 600 python tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; cut -c1-250 $O/bench_configs.jsonl
 step "clean up"
-rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq? $O/ab
+rm -rf $O/kt $O/kb $O/pmc_fetch $O/pmc_write $O/pmc_sq? $O/ab
 ls -la $O

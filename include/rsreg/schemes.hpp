@@ -59,6 +59,21 @@ class RegistrationScheme {
     // (DeviceCloud::download_async), so the merged cloud is complete when the loop ends instead of one 157 MB download
     // after it (16 frames of 307 k points: 4 ms on the link).  false: one download at the end.  Same records either way.
     bool stream_result = true;
+    // engine extra (device-resident loops): milliseconds since registration() began at which the set-up before the frame
+    // loop was done ([0]), every frame's pass through the loop ended ([1] .. [n-1]), and the merged cloud was complete on
+    // the host (the last entry) -- the per-frame table of tools/cpp_scheme_times.py (RSREG_SCHEME_FRAMES=1)
+    std::vector<double> frame_clock_ms;
+
+  protected:
+    void clock_start()
+    {
+        clock0_ = std::chrono::steady_clock::now();
+        frame_clock_ms.clear();
+    }
+    void clock_mark() { frame_clock_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0_).count()); }
+
+  private:
+    std::chrono::steady_clock::time_point clock0_;
 };
 
 class TwoPhaseRegistrationScheme : public RegistrationScheme {
@@ -169,6 +184,7 @@ class IncrementalICP : public RegistrationScheme {
   private:
     rgb_point_cloud_pointer registration_device(std::vector<rgb_point_cloud_pointer> &clouds)
     {
+        clock_start();
         ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
@@ -188,7 +204,8 @@ class IncrementalICP : public RegistrationScheme {
         }
         for (size_t k = 1; k < std::min<size_t>(kFilters + 1, n); ++k) voxel.filter_async(frames[k % kRing], reduced_of[k % (kFilters + 1)]);
         size_t merged_frames = 0;
-        for (size_t k = 1; k < n; ++k) {
+        clock_mark();
+        for (size_t k = 1; k < n; ++k, clock_mark()) {
             rgb_device_cloud &frame = frames[k % kRing], &reduced = reduced_of[k % (kFilters + 1)];
             // (frame k + kUploads takes the buffer of frame k - 1, the filtered frame k + kFilters that of frame k - 1)
             if (k + kUploads < n) frames[(k + kUploads) % kRing].upload_deferred(*clouds[k + kUploads]);
@@ -206,6 +223,7 @@ class IncrementalICP : public RegistrationScheme {
         // the caller's frame 0 has become the merged cloud (incremental_icp.hpp:40,64)
         if (!result) model.download(*clouds[0]);
         else if (merged_frames) result->finish(*clouds[0]);
+        clock_mark();
         return clouds[0];
     }
     rgb_point_cloud_pointer registration_host(std::vector<rgb_point_cloud_pointer> &clouds)
@@ -317,6 +335,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     rgb_point_cloud_pointer global_registration_device(PairList *pairs, std::vector<rgb_point_cloud_pointer> *frames)
     {
         const size_t n_frames = pairs ? pairs->size() : frames->size();
+        clock_start();
         say_header();
         if (use_imu) assert(n_frames == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;
@@ -351,7 +370,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         if (byproducts_on()) save_edge(0, target);   // (the reference writes all edge-k.pcd before the loop; the files are the same)
         float acc_rads = 0.f;
         frame_transforms.clear();
-        for (size_t k = 1; k < n_frames; ++k) {
+        clock_mark();
+        for (size_t k = 1; k < n_frames; ++k, clock_mark()) {
             rgb_device_cloud &full = fulls[k % 3], &features = features_of[k & 1], &reduced = reduced_of[k & 1];
             if (pairs) {
                 features.upload(*(*pairs)[k].first);
@@ -392,6 +412,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         auto out = std::make_shared<rgb_point_cloud>();
         if (result) result->finish(*out);
         else merged.download(*out);
+        clock_mark();
         out->width = (uint32_t)out->size();   // `*merged = *merged + ...`: an unorganized cloud whatever came in
         out->height = 1;
         return out;

@@ -46,24 +46,47 @@ int main(int argc, char **argv)
             const bool host_loop_t = std::getenv("RSREG_SCHEME_HOST_LOOP") && std::getenv("RSREG_SCHEME_HOST_LOOP")[0] == '1';
             const auto t0 = std::chrono::steady_clock::now();
             size_t merged = 0;
+            std::vector<double> frame_clock;
+            // the clock stops when registration() has returned the merged cloud; letting go of that cloud (157 MB) and of the
+            // scheme object afterwards is the caller's business and is reported beside it
+            rgb_point_cloud_pointer kept;
+            double ms = 0;
+            auto stop = [&] { ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
             if (mode == "incremental") {
                 IncrementalICP s;
                 s.device_resident = !host_loop_t;
                 s.stream_result = stream;
-                merged = s.registration(fresh)->size();
+                kept = s.registration(fresh);
+                stop();
+                frame_clock = s.frame_clock_ms;
             } else if (mode == "icp_edge") {
                 ICPEdgeBasedRegistration s(-0.0261799f);
                 s.device_resident = !host_loop_t;
                 s.stream_result = stream;
-                merged = s.registration(fresh)->size();
+                kept = s.registration(fresh);
+                stop();
+                frame_clock = s.frame_clock_ms;
             } else if (mode == "ndt_edge") {
                 NDTEdgeBasedRegistration s(-0.0261799f);
                 s.device_resident = !host_loop_t;
                 s.stream_result = stream;
-                merged = s.registration(fresh)->size();
+                kept = s.registration(fresh);
+                stop();
+                frame_clock = s.frame_clock_ms;
             }
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            std::fprintf(stderr, "%s run %d: %.2f ms, %zu frames, merged %zu points\n", mode.c_str(), rep, ms, clouds.size(), merged);
+            const double ms_scheme_gone = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            merged = kept ? kept->size() : 0;
+            kept.reset();
+            fresh.clear();
+            const double ms_all_gone = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "%s run %d: %.2f ms, %zu frames, merged %zu points (then: scheme object destroyed + %.2f ms, clouds released + %.2f ms)\n",
+                         mode.c_str(), rep, ms, clouds.size(), merged, ms_scheme_gone - ms, ms_all_gone - ms_scheme_gone);
+            // RSREG_SCHEME_FRAMES=1: where the run's time went, frame by frame (schemes.hpp: frame_clock_ms)
+            if (std::getenv("RSREG_SCHEME_FRAMES") && !frame_clock.empty()) {
+                std::fprintf(stderr, "%s run %d frames: set-up %.2f |", mode.c_str(), rep, frame_clock[0]);
+                for (size_t k = 1; k + 1 < frame_clock.size(); ++k) std::fprintf(stderr, " %.2f", frame_clock[k] - frame_clock[k - 1]);
+                std::fprintf(stderr, " | merged cloud complete + %.2f\n", frame_clock.back() - frame_clock[frame_clock.size() - 2]);
+            }
         }
         FILE *f = std::fopen((prefix + ".txt").c_str(), "w");
         rgb_point_cloud_pointer out;

@@ -26,7 +26,9 @@ for name, make in (("IncrementalICP", lambda b: schemes.IncrementalICP(backend=b
                    ("NDTEdgeBasedRegistration", lambda b: schemes.NDTEdgeBasedRegistration(rads=-np.deg2rad(0.15), backend=b))):
     for bname, backend in (("device clouds", schemes.HipDeviceBackend), ("host clouds", schemes.HipBackend)):
         best = 1e9
+        out = None
         for rep in range(3):
+            out = None   # (the previous run's 157 MB go back outside the clock)
             fr = copy_frames()
             s = make(backend())
             s.stream_result = os.environ.get("RSREG_SCHEME_NO_STREAM", "0") != "1"

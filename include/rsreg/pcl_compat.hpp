@@ -122,12 +122,27 @@ template <typename PointT> inline PointVector<PointT> uninitialized_points(size_
 {
     static_assert(std::is_trivially_copyable<PointT>::value && std::is_trivially_destructible<PointT>::value,
                   "records that may stay unconstructed must be plain data");
+#if defined(__GLIBCXX__)
+    // libstdc++: the storage is reserved and the end pointer moved: no per-record call at all (the portable path below still
+    // goes through the allocator's construct() once per record -- 1 ms of doing nothing for a merged cloud of 4.9 M points)
+    struct Open : PointVector<PointT> {
+        void grow_unconstructed(size_t m)
+        {
+            this->reserve(m);
+            this->_M_impl._M_finish = this->_M_impl._M_start + m;
+        }
+    };
+    PointVector<PointT> v;
+    static_cast<Open &>(v).grow_unconstructed(n);
+    return v;
+#else
     struct Guard {
         bool before = detail::skip_point_init();
         Guard() { detail::skip_point_init() = true; }
         ~Guard() { detail::skip_point_init() = before; }
     } guard;
     return PointVector<PointT>(n);
+#endif
 }
 
 // ---- pcl::PointCloud<PointT>

@@ -7,16 +7,14 @@
 // gray image float((r + g + b) / 3) of the organized cloud -- the normals, the depth discontinuities
 // and the curvature edges never reach the returned cloud, so they are not computed here.
 //
-// Stages (each pixel one thread; float operations un-fused and in PCL's order, file built with
-// -ffp-contract=off):  gray + 3x3 Gaussian (clamped borders)  ->  Sobel x / y, magnitude, direction
-// class  ->  non-maximum suppression on the interior  ->  hysteresis as connected components
-// (8-neighbourhood union-find; a component is kept if it holds a pixel >= the high threshold:
-// the set PCL's recursive tracing reaches, independent of its visiting order)  ->  ordered
-// compaction of the edge points' records.
+// Stages (float operations un-fused and in PCL's order, file built with -ffp-contract=off):  gray + 3x3 Gaussian
+// (clamped borders)  ->  Sobel x / y, magnitude, direction class  ->  non-maximum suppression on the interior  ->
+// hysteresis as connected components (8-neighbourhood union-find; a component is kept if it holds a pixel >= the high
+// threshold: the set PCL's recursive tracing reaches, independent of its visiting order)  ->  ordered compaction of the
+// edge points' records.  Four launches: k_edge_tile (everything up to the components inside a 32 x 32 tile, through
+// LDS), k_edge_cc_borders (the joins across tile edges), k_edge_cc_roots, k_edge_compact (flag, scan and gather).
 #include <cstring>
 #include <string.h>
-
-#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -24,6 +22,7 @@
 #include <vector>
 
 #include "records.hpp"
+#include "compact.hpp"
 
 using namespace rsreg;
 
@@ -45,6 +44,7 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
+#ifdef RSREG_DIAG   // the three image stages as launches of their own: only for the stage-by-stage dump (RSREG_EDGE_DUMP); the product runs k_edge_tile
 // gray image, then pcl::Convolution with the 3x3 Gaussian: correlation, borders clamped, float sum over kernel rows then columns
 __global__ __launch_bounds__(kBlock) void k_edge_smooth(const char *rec, size_t stride, int w, int h, Kernel3 kg, float *sm)
 {
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_nms(const float *mag, const uin
     mx[p] = out;
     label[p] = out != 0.0f ? p : -1;
 }
+#endif
 
 __device__ __forceinline__ int cc_find(const int *label, int i)
 {
@@ -185,14 +186,82 @@ __device__ __forceinline__ void cc_union_lds(int *label, int a, int b)
     }
 }
 
-// one workgroup per tile, one pixel per thread; label[p] = the smallest pixel index of p's component inside its tile
-__global__ __launch_bounds__(kCcTile * kCcTile) void k_edge_cc_tiles(const float *mx, int w, int h, int tiles_x, int *label)
+// Gray image, 3x3 Gaussian, Sobel, direction classes, non-maximum suppression and the components inside the tile -- one
+// workgroup per tile of 32 x 32 pixels, one pixel per thread, the stages handed on through LDS with the halo each needs
+// (gray 38 x 38, smoothed 36 x 36, magnitude and direction 34 x 34).  The same operations in the same order as
+// pcl::Convolution / pcl::Edge (see the stage kernels above, which the dump build still has): a value outside the image
+// is the value at the clamped coordinate, stage by stage, so an LDS entry stands for "the pixel its coordinate clamps to".
+// Four launches, three image-sized round trips through HBM and a separate label pass less than the staged form.
+// mx[p]: the kept magnitude or 0; label[p] = the smallest pixel index of p's component inside its tile, -1 if not kept;
+// strong[p] = 0 (k_edge_cc_roots marks the roots).  Workgroup 0 also clears `clear_words` words for k_edge_compact.
+constexpr int kEtG = kCcTile + 6, kEtS = kCcTile + 4, kEtM = kCcTile + 2;
+__global__ __launch_bounds__(kCcTile * kCcTile) void k_edge_tile(const char *rec, size_t stride, int w, int h, int tiles_x, Kernel3 kg, float t_low,
+                                                                 float *mx, int *label, uint32_t *strong, uint32_t *clear, uint32_t clear_words)
 {
+    __shared__ float s_g[kEtG][kEtG], s_s[kEtS][kEtS], s_m[kEtM][kEtM];
+    __shared__ uint8_t s_d[kEtM][kEtM];
     __shared__ int lab[kCcTile * kCcTile];   // local index ly * 32 + lx: ordered like the pixel index inside the tile
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0)
+        for (uint32_t k = (uint32_t)t; k < clear_words; k += kCcTile * kCcTile) clear[k] = 0u;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x0 = tx * kCcTile, y0 = ty * kCcTile;
-    const int t = threadIdx.x, lx = t % kCcTile, ly = t / kCcTile, x = x0 + lx, y = y0 + ly;
-    const bool kept = x < w && y < h && mx[y * w + x] != 0.0f;
+    for (int e = t; e < kEtG * kEtG; e += kCcTile * kCcTile) {
+        const int r = e / kEtG, c = e - r * kEtG;
+        const int gi = clampi(y0 - 3 + r, h - 1), gj = clampi(x0 - 3 + c, w - 1);
+        const uint32_t col = *reinterpret_cast<const uint32_t *>(rec + (size_t)(gi * w + gj) * stride + 16);   // b g r a
+        s_g[r][c] = (float)(((int)((col >> 16) & 255u) + (int)((col >> 8) & 255u) + (int)(col & 255u)) / 3);
+    }
+    __syncthreads();
+    for (int e = t; e < kEtS * kEtS; e += kCcTile * kCcTile) {
+        const int r = e / kEtS, c = e - r * kEtS;
+        const int ci = clampi(y0 - 2 + r, h - 1), cj = clampi(x0 - 2 + c, w - 1);   // the pixel this entry stands for
+        float s = 0.0f;
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc)
+                s = __fadd_rn(s, __fmul_rn(kg.k[kr * 3 + kc], s_g[clampi(ci + kr - 1, h - 1) - (y0 - 3)][clampi(cj + kc - 1, w - 1) - (x0 - 3)]));
+        s_s[r][c] = s;
+    }
+    __syncthreads();
+    for (int e = t; e < kEtM * kEtM; e += kCcTile * kCcTile) {
+        const int r = e / kEtM, c = e - r * kEtM;
+        const int ci = clampi(y0 - 1 + r, h - 1), cj = clampi(x0 - 1 + c, w - 1);
+        const float kx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, ky[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1};
+        float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                const float v = s_s[clampi(ci + kr - 1, h - 1) - (y0 - 2)][clampi(cj + kc - 1, w - 1) - (x0 - 2)];
+                gx = __fadd_rn(gx, __fmul_rn(kx[kr * 3 + kc], v));
+                gy = __fadd_rn(gy, __fmul_rn(ky[kr * 3 + kc], v));
+            }
+        s_m[r][c] = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
+        // (the angle as the correctly rounded float of atan2, classes as pcl::Edge::discretizeAngles: see k_edge_sobel)
+        const float angle = __fmul_rn((float)atan2((double)gy, (double)gx), 57.29578f);
+        uint8_t d = 255;
+        if (((angle <= 22.5f) && (angle >= -22.5f)) || (angle >= 157.5f) || (angle <= -157.5f)) d = 0;
+        else if (((angle > 22.5f) && (angle < 67.5f)) || ((angle < -112.5f) && (angle > -157.5f))) d = 1;
+        else if (((angle >= 67.5f) && (angle <= 112.5f)) || ((angle <= -67.5f) && (angle >= -112.5f))) d = 2;
+        else if (((angle > 112.5f) && (angle < 157.5f)) || ((angle < -22.5f) && (angle > -67.5f))) d = 3;
+        s_d[r][c] = d;
+    }
+    __syncthreads();
+    const int lx = t % kCcTile, ly = t / kCcTile, x = x0 + lx, y = y0 + ly;
+    const bool in_image = x < w && y < h;
+    float out = 0.0f;
+    if (in_image && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {   // pcl::Edge::suppressNonMaxima: interior pixels only
+        const float m = s_m[ly + 1][lx + 1];
+        const uint8_t d = s_d[ly + 1][lx + 1];
+        if (!(m < t_low) && d != 255) {
+            // the two neighbours along the gradient: (j-1, j+1) / (i-1 j-1, i+1 j+1) / (i-1, i+1) / (i-1 j+1, i+1 j-1)
+            const int dy = d == 0 ? 0 : 1, dx = d == 0 ? 1 : (d == 1 ? 1 : (d == 2 ? 0 : -1));
+            if (m >= s_m[ly + 1 - dy][lx + 1 - dx] && m >= s_m[ly + 1 + dy][lx + 1 + dx]) out = m;
+        }
+    }
+    const bool kept = out != 0.0f;
     lab[t] = kept ? t : -1;
     __syncthreads();
     if (kept) {   // (a kept pixel's entry only ever moves to a smaller kept index: never negative)
@@ -204,9 +273,16 @@ __global__ __launch_bounds__(kCcTile * kCcTile) void k_edge_cc_tiles(const float
         }
     }
     __syncthreads();
-    if (kept) {
-        const int r = cc_find_lds(lab, t);
-        label[y * w + x] = (y0 + r / kCcTile) * w + x0 + r % kCcTile;
+    if (in_image) {
+        const int p = y * w + x;
+        int l = -1;
+        if (kept) {
+            const int r = cc_find_lds(lab, t);
+            l = (y0 + r / kCcTile) * w + x0 + r % kCcTile;
+        }
+        mx[p] = out;
+        label[p] = l;
+        strong[p] = 0u;
     }
 }
 
@@ -244,25 +320,45 @@ __global__ __launch_bounds__(kBlock) void k_edge_cc_roots(const float *mx, int n
     __builtin_nontemporal_store(r, &label[p]);   // (a pixel's label only ever points at a smaller index of its own component)
 }
 
-__global__ __launch_bounds__(kBlock) void k_edge_flags(const float *mx, const int *label, const uint32_t *strong, int n, uint32_t *flag)
+// pcl::copyPointCloud(cloud, indices, out): the records of the pixels whose component is strong, in index order -- flag,
+// scan and gather in one launch (compact.hpp: a workgroup flags 4 096 pixels, scans them, learns what lies in front of it
+// through the decoupled look-back and copies its records); the last workgroup leaves the number of edge points in a
+// pinned host word (no copy queued).  `state` / `ticket`: zero at the start (k_edge_tile clears them).
+__global__ __launch_bounds__(kCompactBlock) void k_edge_compact(const char *rec, size_t stride, int n, const float *mx, const int *label,
+                                                                const uint32_t *strong, char *out, int32_t *indices, unsigned long long *state,
+                                                                uint32_t *ticket, uint32_t *host_count)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    uint32_t f = 0;
-    if (mx[p] != 0.0f) f = strong[cc_find(label, p)];
-    flag[p] = f;
-}
-
-// pcl::copyPointCloud(cloud, indices, out): the edge points' records, in index order
-__global__ __launch_bounds__(kBlock) void k_edge_gather(const char *rec, size_t stride, int n, const uint32_t *flag, const uint32_t *pos,
-                                                        char *out, int32_t *indices)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || !flag[p]) return;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(rec + (size_t)p * stride);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)pos[p] * stride);
-    for (uint32_t k = 0; k < stride / 4; ++k) dst[k] = src[k];
-    if (indices) indices[pos[p]] = p;
+    __shared__ uint32_t s_bid;
+    __shared__ unsigned long long s_wave[kCompactBlock / 64];
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int i0 = (int)((bid * kCompactBlock + threadIdx.x) * kCompactItems);
+    uint32_t f[kCompactItems];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < (int)kCompactItems; ++j) {
+        const int p = i0 + j;
+        f[j] = 0u;
+        if (p < n && mx[p] != 0.0f) f[j] = strong[cc_find(label, p)];
+        mine += f[j];
+    }
+    unsigned long long total;
+    unsigned long long run = compact_block_scan(mine, s_wave, total);
+    const unsigned long long before = compact_lookback(state, bid, total, &s_excl);
+    run += before;
+    if (bid == gridDim.x - 1 && threadIdx.x == 0) *host_count = (uint32_t)(before + total);
+#pragma unroll
+    for (int j = 0; j < (int)kCompactItems; ++j) {
+        if (!f[j]) continue;
+        const int p = i0 + j;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rec + (size_t)p * stride);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)run * stride);
+        for (uint32_t k = 0; k < stride / 4; ++k) dst[k] = src[k];
+        if (indices) indices[run] = p;
+        ++run;
+    }
 }
 
 }  // namespace
@@ -281,24 +377,20 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     const bool side = side_set >= 0;
     rsreg_ctx::SideSet &ss = ctx->side_sets[side ? side_set : 0];
     hipStream_t st = side ? ss.stream : ctx->stream;
-    DevBuf &b_keys = side ? ss.keys : ctx->d_keys, &b_keys_alt = side ? ss.keys_alt : ctx->d_keys_alt, &b_vals = side ? ss.vals : ctx->d_vals,
-           &b_flags = side ? ss.flags : ctx->d_flags, &b_scan = side ? ss.scan : ctx->d_scan, &b_vals_alt = side ? ss.vals_alt : ctx->d_vals_alt,
-           &b_dir = side ? ss.cent : ctx->d_brick, &b_out = side ? ss.out : ctx->d_vox_out, &b_tmp = side ? ss.tmp : ctx->d_tmp;
+    DevBuf &b_keys_alt = side ? ss.keys_alt : ctx->d_keys_alt, &b_vals = side ? ss.vals : ctx->d_vals, &b_flags = side ? ss.flags : ctx->d_flags,
+           &b_vals_alt = side ? ss.vals_alt : ctx->d_vals_alt, &b_out = side ? ss.out : ctx->d_vox_out;
     PinnedBuf &b_host = side ? ss.host : ctx->h_sums;
     const int w = (int)width, h = (int)height, N = (int)n;
-    RSREG_HIP(ctx, b_keys.reserve(n * 8));       // smoothed | magnitude
+    const CompactPlan cplan = compact_plan(n, 0);   // the look-back words and the ticket of the compaction at the end
     RSREG_HIP(ctx, b_keys_alt.reserve(n * 8));   // maxima | labels
     RSREG_HIP(ctx, b_vals.reserve(n * 4));       // strong flags per root
-    RSREG_HIP(ctx, b_flags.reserve(n * 4 + 16));
-    RSREG_HIP(ctx, b_scan.reserve(n * 4 + 16));
+    RSREG_HIP(ctx, b_flags.reserve((size_t)cplan.end * 4 + 16));
     RSREG_HIP(ctx, b_vals_alt.reserve(n * 4));   // indices of the edge points
-    RSREG_HIP(ctx, b_dir.reserve(n + 16));       // direction classes
     RSREG_HIP(ctx, b_out.reserve(n * stride));
     RSREG_HIP(ctx, b_host.reserve(2048));
-    float *sm = b_keys.as<float>(), *mag = sm + n, *mx = b_keys_alt.as<float>();
+    float *mx = b_keys_alt.as<float>();
     int *label = reinterpret_cast<int *>(mx + n);
-    uint32_t *strong = b_vals.as<uint32_t>(), *flag = b_flags.as<uint32_t>(), *pos = b_scan.as<uint32_t>();
-    uint8_t *dir = b_dir.as<uint8_t>();
+    uint32_t *strong = b_vals.as<uint32_t>();
     // pcl::kernel::gaussianKernel(size 3, sigma 1): exp of -(i^2 + j^2) / (2 sigma^2) as a float, normalised by the float
     // sum.  (PCL calls expf at run time -- libm-dependent in the last ulp; here the correctly rounded float: exp in
     // double, rounded once, the same on every platform and in the checker.)
@@ -313,31 +405,27 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
     for (int i = 0; i < 9; ++i) kg.k[i] /= sum;
     const float t_low = 40.0f, t_high = 100.0f;   // OrganizedEdgeFromRGB: th_rgb_canny_low_ / _high_ (never changed by the reference)
     const uint32_t nb = div_up((uint32_t)N, kBlock);
-    k_edge_smooth<<<nb, kBlock, 0, st>>>(d_rec, stride, w, h, kg, sm);
+    const int tiles_x = (w + kCcTile - 1) / kCcTile, tiles_y = (h + kCcTile - 1) / kCcTile;
+    uint32_t *scr = b_flags.as<uint32_t>();   // (the compaction's words: cleared by the tile kernel)
+    uint32_t *hb = b_host.as<uint32_t>() + 200;
+    k_edge_tile<<<(uint32_t)(tiles_x * tiles_y), kCcTile * kCcTile, 0, st>>>(d_rec, stride, w, h, tiles_x, kg, t_low, mx, label, strong, scr, cplan.end);
     RSREG_HIP(ctx, hipGetLastError());
-    k_edge_sobel<<<nb, kBlock, 0, st>>>(sm, w, h, mag, dir);
+    k_edge_cc_borders<<<(uint32_t)((tiles_x * tiles_y * kCcEdge + kBlock - 1) / kBlock), kBlock, 0, st>>>(mx, w, h, tiles_x, tiles_x * tiles_y, label);
     RSREG_HIP(ctx, hipGetLastError());
-    k_edge_nms<<<nb, kBlock, 0, st>>>(mag, dir, w, h, t_low, mx, label, strong);
-    RSREG_HIP(ctx, hipGetLastError());
-    {
-        const int tiles_x = (w + kCcTile - 1) / kCcTile, tiles_y = (h + kCcTile - 1) / kCcTile;
-        k_edge_cc_tiles<<<(uint32_t)(tiles_x * tiles_y), kCcTile * kCcTile, 0, st>>>(mx, w, h, tiles_x, label);
-        RSREG_HIP(ctx, hipGetLastError());
-        k_edge_cc_borders<<<(uint32_t)((tiles_x * tiles_y * kCcEdge + kBlock - 1) / kBlock), kBlock, 0, st>>>(mx, w, h, tiles_x, tiles_x * tiles_y, label);
-        RSREG_HIP(ctx, hipGetLastError());
-    }
     k_edge_cc_roots<<<nb, kBlock, 0, st>>>(mx, N, t_high, label, strong);
     RSREG_HIP(ctx, hipGetLastError());
-    k_edge_flags<<<nb, kBlock, 0, st>>>(mx, label, strong, N, flag);
-    RSREG_HIP(ctx, hipGetLastError());
-    size_t scan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, b_tmp.reserve(scan_bytes + 256));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(b_tmp.ptr, scan_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), st));
-    k_edge_gather<<<nb, kBlock, 0, st>>>(d_rec, stride, N, flag, pos, b_out.as<char>(), b_vals_alt.as<int32_t>());
+    k_edge_compact<<<cplan.blocks, kCompactBlock, 0, st>>>(d_rec, stride, N, mx, label, strong, b_out.as<char>(), b_vals_alt.as<int32_t>(),
+                                                           reinterpret_cast<unsigned long long *>(scr + cplan.off_state), scr + cplan.off_ticket, hb);
     RSREG_HIP(ctx, hipGetLastError());
 #ifdef RSREG_DIAG
     if (const char *dump = rsreg::tunables().edge_dump) {   // diagnostic builds: the stage images, for a stage-by-stage comparison
+        DevBuf &b_keys = side ? ss.keys : ctx->d_keys, &b_dir = side ? ss.cent : ctx->d_brick;
+        RSREG_HIP(ctx, b_keys.reserve(n * 8));       // smoothed | magnitude
+        RSREG_HIP(ctx, b_dir.reserve(n + 16));       // direction classes
+        float *sm = b_keys.as<float>(), *mag = sm + n;
+        uint8_t *dir = b_dir.as<uint8_t>();
+        k_edge_smooth<<<nb, kBlock, 0, st>>>(d_rec, stride, w, h, kg, sm);
+        k_edge_sobel<<<nb, kBlock, 0, st>>>(sm, w, h, mag, dir);
         std::vector<float> hbuf(n * 3);
         std::vector<uint8_t> hdir(n);
         (void)hipMemcpyAsync(hbuf.data(), sm, n * 4, hipMemcpyDeviceToHost, st);
@@ -352,11 +440,8 @@ int edge_features_device(rsreg_ctx *ctx, const char *d_rec, size_t stride, uint3
         }
     }
 #endif
-    uint32_t *hb = b_host.as<uint32_t>() + 200;
-    RSREG_HIP(ctx, hipMemcpyAsync(hb, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    RSREG_HIP(ctx, hipMemcpyAsync(hb + 1, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
     RSREG_HIP(ctx, hipStreamSynchronize(st));
-    *n_out = hb[0] + hb[1];
+    *n_out = hb[0];
     return RSREG_OK;
 }
 

@@ -1330,8 +1330,8 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     const IcpDevState *dev = device_loop ? ctx->d_icp_state.as<IcpDevState>() : nullptr;
     const double gate2 = s.prm.max_correspondence_distance * s.prm.max_correspondence_distance;
     // the first launch of an alignment over the dense index reads the source itself, applies the guess and starts without
-    // seeds: k_restart_source's work, one launch and a pass over the working copy saved (never with a schedule in
-    // place: that is built from a launch of this alignment)
+    // seeds: k_restart_source's work, one launch and a pass over the working copy saved (never with a schedule of this
+    // alignment's own in place: that is built from one of its launches; a carried one may serve it, below)
     const bool restart_apart = tunables().restart_apart;
     const bool restart_here = s.restart_pending && ctx->grid.dense && !s.sched_ready && !s.pending_transform && !restart_apart;
     if (restart_here) {
@@ -1367,11 +1367,11 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 sc.done = sb.done;
                 sc.pos = ctx->d_corr_pos.as<int>();
                 sc.d2 = ctx->d_corr_d2.as<float>();
-                // The schedule of an earlier alignment of this context serves this one too, from the launch that would otherwise
-                // be timed: the long tiles sit on the same (near, densely sampled) surfaces from one frame to the next, a schedule is
+                // The schedule of an earlier alignment of this context serves this one too, from its first launch (or from the one
+                // that would otherwise be timed, when the first is a launch of k_restart_source's kind apart): the long tiles sit on the same (near, densely sampled) surfaces from one frame to the next, a schedule is
                 // an order of work and never wrong, and the timed launch runs unscheduled (140 against 93 us at 10^6 points).
                 // Carried for at most kSchedKeepFor alignments and only to a source of about as many tiles; RSREG_SCHED_KEEP=0: never.
-                if (!s.sched_ready && !restart_here && s.fused_launches >= cfg.at_launch && ctx->sched_keep_items && tunables().sched_keep &&
+                if (!s.sched_ready && (restart_here || s.fused_launches >= cfg.at_launch) && ctx->sched_keep_items && tunables().sched_keep &&
                     ctx->sched_keep_age < kSchedKeepFor && n_tiles + n_tiles / 8 >= ctx->sched_keep_tiles && ctx->sched_keep_tiles + ctx->sched_keep_tiles / 8 >= n_tiles) {
                     s.sched_ready = true;
                     s.sched_carried = true;

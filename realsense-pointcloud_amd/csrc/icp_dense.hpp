@@ -862,30 +862,36 @@ __device__ __forceinline__ float4 coherent_load(const float4 *p)
 // One part of a split tile: 128 >> lg queries, 2^lg lanes each.  Returns true in the workgroup that finishes
 // the tile last (it then adds the tile's sums up from what all parts have left in sched.pos / sched.d2 / cur).
 template <int kFar>
-__device__ __forceinline__ bool fused_dense_split_part(float4 *cur, uint32_t n, const Mat34 &T, int apply_t, const DenseDev &g, double gate2,
-                                                       int *seed, const TileSched &sched, uint32_t tile, uint32_t part, uint32_t lg)
+__device__ __forceinline__ bool fused_dense_split_part(float4 *cur, const float4 *restart, const uint32_t *first, uint32_t n, const Mat34 &T, int apply_t,
+                                                       const DenseDev &g, double gate2, int *seed, const TileSched &sched, uint32_t tile, uint32_t part,
+                                                       uint32_t lg)
 {
     const DSplit sp{lg, threadIdx.x & ((1u << lg) - 1u)};
     const uint32_t i = tile * kTile + part * (kTile >> lg) + (threadIdx.x >> lg);
     if (i < n) {
-        float4 q = cur[i];
+        // (restart: the first launch of an alignment under a schedule carried over from an earlier one -- the query is the
+        // source point itself under the guess, the working copy is written whatever the point, no seed: as on the ordinary path)
+        float4 q = restart ? restart[i] : cur[i];
         int pos = -1;
         float d2 = 0.0f;
         if (q.w != 0.0f) {
+            if (restart) q.w = source_weight(first, i);
             if (apply_t) {
                 const float3 t = xform(T, q.x, q.y, q.z);
                 q = make_float4(t.x, t.y, t.z, q.w);
             }
-            const int seed_in = seed ? seed[i] : -1;
+            const int seed_in = (seed && !restart) ? seed[i] : -1;
             const Best b = nn_query_dense<false, kFar>(g, q.x, q.y, q.z, seed_in, nullptr, sp);
             if (sp.sub == 0) {
-                if (apply_t) coherent_store(&cur[i], q);
-                if (seed && b.pos != seed_in) seed[i] = b.pos;
+                if (apply_t || restart) coherent_store(&cur[i], q);
+                if (seed && (restart || b.pos != seed_in)) seed[i] = b.pos;
             }
             if (b.pos >= 0 && !((double)b.d2 > gate2)) {
                 pos = b.pos;
                 d2 = b.d2;
             }
+        } else if (restart && sp.sub == 0) {
+            coherent_store(&cur[i], q);
         }
         if (sp.sub == 0) {
             coherent_store(reinterpret_cast<uint32_t *>(sched.pos) + i, (uint32_t)pos);
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(kTile, kDiag == 1 ? 4 : 8) void k_icp_fused_dense(f
     float d2 = 0.0f;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lg != 0) {
-        if (!fused_dense_split_part<kFar>(cur, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
+        if (!fused_dense_split_part<kFar>(cur, restart, first, n, T, apply_t, g, gate2, seed, sched, tile, (item >> 24) & 15u, lg)) {
             if (kDiag == 2 && (threadIdx.x & 63) == 0) light_stamp(wave_times, t_start, lg, item);
             return;
         }

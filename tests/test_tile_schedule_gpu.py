@@ -168,3 +168,39 @@ def test_random_scenes_split_equals_unsplit(api, rs, monkeypatch):
             got, _ = _run(api, sc, tc, pipeline, 4, gate)
             out.append(got)
         assert out[0] == out[1] == out[2] == out[3], (it, kind, nt, ns, gate)
+
+
+def test_carried_schedule_serves_the_first_launch(api, rs, monkeypatch):
+    """A schedule built in one alignment serves the next alignments of the same context from their FIRST launch -- the
+    unseeded one that reads the source itself --, also for a source with fewer tiles than the schedule knows (its items
+    for the missing tiles do nothing) and for one with more (the extra tiles run unsplit behind): same bits as fresh,
+    unscheduled contexts."""
+    tgt, src = rs.synth.render_frame(0, "N300", "bench"), rs.synth.render_frame(1, "N300", "bench")
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    n = len(src)
+    more = np.empty(n + 7001, src.points.dtype)   # more records than the schedule's source had (frame 2's points behind frame 1's)
+    more[:n] = src.points
+    more[n:] = rs.synth.render_frame(2, "N300", "bench").points[:7001]
+    sources = [src,
+               rs.PointCloud(src.points[: n - 9000].copy(), width=n - 9000, height=1, is_dense=False),     # fewer tiles
+               rs.PointCloud(more, width=n + 7001, height=1, is_dense=False),
+               rs.synth.render_frame(2, "N300", "bench")]
+    monkeypatch.setenv("RSREG_SCHED", "0")
+    base = [_run(api, s, tgt, 2, 4, 0.05, guess)[0] for s in sources]
+    monkeypatch.setenv("RSREG_SCHED", "1")
+    icp = api.IterativeClosestPoint(api.Context(0))
+    icp.params = api.icp_params(max_iterations=4, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=0.05)
+    icp.setInputTarget(tgt)
+    for k, s in enumerate(sources):
+        icp.setInputSource(s)
+        out = icp.align(guess)
+        r = icp.result
+        if icp.grid_info().index_kind != 1:
+            pytest.skip("the schedule belongs to the dense-table search")
+        got = (bytes(r.transform), bytes(r.sums_last), r.n_correspondences, r.iterations, r.state, r.converged, r.mse,
+               np.stack([out.points[c] for c in "xyz"]).tobytes())
+        assert got == base[k], k
+        if k == 0:
+            assert 0 < r.n_scheduled_launches < r.n_nn_launches    # built in this alignment: its first launches run unscheduled
+        else:
+            assert r.n_scheduled_launches == r.n_nn_launches, (k, r.n_scheduled_launches, r.n_nn_launches)

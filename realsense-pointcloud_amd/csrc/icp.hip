@@ -731,12 +731,31 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             const bool start_in_out = own_sort && plan.ends_in_first;
             uint32_t *keys_a = start_in_out ? keys2 : keys, *vals_a = start_in_out ? perm : vals;
             uint32_t *keys_b = start_in_out ? keys : keys2, *vals_b = start_in_out ? vals : perm;
-            k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys_a, vals_a,
-                                                           own_sort ? ctx->d_stmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
+            // the library's own sort over more than one workgroup's worth of pairs: its digit histograms are counted by the keys
+            // kernel (two sets of counts in turn: the kernel clears the one the NEXT load will use, so no memset is queued;
+            // a new buffer, or a load that did not get to its end, starts from one)
+            const bool hist_on_the_way = own_sort && n > kOsTile;
+            uint32_t *hist_now = nullptr;
+            if (hist_on_the_way) {
+                constexpr size_t set = kOsMaxPasses * kOsDigits;
+                const bool fresh = !ctx->d_shist.ptr;
+                RSREG_HIP(ctx, ctx->d_shist.reserve(2 * set * 4));
+                if (fresh || ctx->shist_dirty) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_shist.ptr, 0, 2 * set * 4, st));
+                ctx->shist_dirty = true;
+                hist_now = ctx->d_shist.as<uint32_t>() + (ctx->shist_flip ? set : 0);
+                uint32_t *hist_next = ctx->d_shist.as<uint32_t>() + (ctx->shist_flip ? 0 : set);
+                ctx->shist_flip = !ctx->shist_flip;
+                k_source_keys_hist<<<div_up((uint32_t)n, kOsHistBlock * kSkItems), kOsHistBlock, 0, st>>>(
+                    d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys_a, vals_a, ctx->d_stmp.as<uint32_t>(), plan.words,
+                    sort_bits, plan.passes, hist_now, hist_next);
+            } else {
+                k_source_keys<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1u << (sort_bits - 1u), mb, keys_a, vals_a,
+                                                               own_sort ? ctx->d_stmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
+            }
             RSREG_HIP(ctx, hipGetLastError());
             if (own_sort) {
                 bool in_first = false;
-                RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_stmp.as<uint32_t>(), keys_a, keys_b, vals_a, vals_b, n, 0, sort_bits, st, &in_first));
+                RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_stmp.as<uint32_t>(), keys_a, keys_b, vals_a, vals_b, n, 0, sort_bits, st, &in_first, hist_now));
                 if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
             } else {
                 RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
@@ -763,6 +782,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
                                                ctx->d_src.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
+        ctx->shist_dirty = false;   // (everything of this load is queued: the counts' two sets are where the next load expects them)
     }
     return RSREG_OK;
 }
@@ -1657,7 +1677,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_ctl, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
-                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_scan_keys, &ctx->d_cnt, &ctx->d_arrived};
+                      &ctx->d_sflags, &ctx->d_sscan, &ctx->d_stmp, &ctx->d_smisc, &ctx->d_shist, &ctx->d_scan_keys, &ctx->d_cnt, &ctx->d_arrived};
     if (ctx->stream_h2d) { (void)hipStreamSynchronize(ctx->stream_h2d); (void)hipStreamDestroy(ctx->stream_h2d); }
     ctx->h_stage_src.release();
     ctx->h_stage_tgt.release();

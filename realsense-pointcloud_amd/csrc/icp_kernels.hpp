@@ -369,6 +369,46 @@ __global__ __launch_bounds__(kBlock) void k_source_keys(const char *raw, size_t 
     vals[i] = i;
 }
 
+// k_source_keys for 32-bit keys that the library's own sort takes next, with that sort's digit histograms counted on the
+// way (what k_os_hist would read the keys again for: one launch and a pass over the keys less on the source's chain, which
+// is the longer one of a pair since the target's index is built by counting).  `hist`: passes x 256 counts, zero on entry;
+// `hist_next`: the set the NEXT load will count into, cleared here (the two take turns: icp.hip, load_source_queue).
+constexpr unsigned kSkItems = 4;
+__global__ __launch_bounds__(kOsHistBlock) void k_source_keys_hist(const char *raw, size_t stride, uint32_t n, float ox, float oy, float oz, float inv_cell,
+                                                                   uint32_t invalid_key, MortonBits bits, uint32_t *keys, uint32_t *vals, uint32_t *sort_scratch,
+                                                                   uint32_t sort_scratch_words, uint32_t end_bit, uint32_t passes, uint32_t *hist,
+                                                                   uint32_t *hist_next)
+{
+    __shared__ uint32_t s_h[kOsMaxPasses * kOsDigits];
+    const uint32_t t = blockIdx.x * kOsHistBlock + threadIdx.x, threads = gridDim.x * kOsHistBlock;
+    radix32_clear(sort_scratch, sort_scratch_words, t, threads);   // (look-back words and tickets of the passes: nobody reads them before this kernel is done)
+    for (uint32_t k = t; k < kOsMaxPasses * kOsDigits; k += threads) hist_next[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < passes * kOsDigits; k += kOsHistBlock) s_h[k] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kOsHistBlock * kSkItems;
+#pragma unroll
+    for (uint32_t j = 0; j < kSkItems; ++j) {
+        const uint32_t i = base + j * kOsHistBlock + threadIdx.x;
+        if (i >= n) break;
+        const float *p = rec_xyz(raw, stride, i);
+        const float x = p[0], y = p[1], z = p[2];
+        uint32_t key = invalid_key;   // one bit above every Morton code: non-finite points sort last
+        if (finite3(x, y, z)) {
+            const unsigned cx = (unsigned)cell_coord(x, ox, inv_cell), cy = (unsigned)cell_coord(y, oy, inv_cell), cz = (unsigned)cell_coord(z, oz, inv_cell);
+            key = (uint32_t)morton_mixed(min(cx, (1u << bits.x) - 1u), min(cy, (1u << bits.y) - 1u), min(cz, (1u << bits.z) - 1u), bits);
+        }
+        keys[i] = key;
+        vals[i] = i;
+        for (uint32_t q = 0; q < passes; ++q) {
+            const uint32_t bit = q * kOsBits, nb = min(kOsBits, end_bit - bit);
+            atomicAdd(&s_h[q * kOsDigits + ((key >> bit) & ((1u << nb) - 1u))], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < passes * kOsDigits; k += kOsHistBlock)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
+}
+
 // src[j] = {xyz of original point perm[j], valid}; cur = copy
 // keys + keep (both or neither): also flags the sorted point j that is not an exact copy of its predecessor (same Morton
 // key, same xyz; invalid points are never merged: they carry weight 0 anyway), from the predecessor's own record

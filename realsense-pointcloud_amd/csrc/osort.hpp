@@ -279,8 +279,10 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
 // whether osort_pairs leaves the result in the pair it started from
 inline bool osort_ends_in_first(const OsortPlan &p, size_t n) { return n == 0 || p.passes == 0 || (n > kOsTile && p.passes % 2 == 0); }
 
+// `hist_ready`: the digit histograms (passes x 256 counts from begin_bit on, as k_os_hist leaves them) if the kernel that wrote the
+// keys has counted them on its way (k_source_keys_hist): no histogram launch then; nullptr: k_os_hist counts them in the scratch block.
 inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-                              unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first)
+                              unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first, const uint32_t *hist_ready = nullptr)
 {
     *in_first = true;
     if (n == 0 || p.passes == 0) return hipSuccess;
@@ -292,13 +294,14 @@ inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, uint32_t *k
         *in_first = false;
         return hipGetLastError();
     }
-    k_os_hist<0><<<p.hist_blocks, kOsHistBlock, 0, st>>>(keys_a, (uint32_t)n, begin_bit, end_bit, p.passes, scratch + p.off_hist);
+    const uint32_t *hist = hist_ready ? hist_ready : scratch + p.off_hist;
+    if (!hist_ready) k_os_hist<0><<<p.hist_blocks, kOsHistBlock, 0, st>>>(keys_a, (uint32_t)n, begin_bit, end_bit, p.passes, scratch + p.off_hist);
     bool from_a = true;
     unsigned bit = begin_bit;
     for (uint32_t pass = 0; pass < p.passes; ++pass, bit += kOsBits) {
         const uint32_t bits = std::min(kOsBits, end_bit - bit);
         k_os_pass<0><<<p.blocks, kOsBlock, 0, st>>>(from_a ? keys_a : keys_b, from_a ? keys_b : keys_a, from_a ? vals_a : vals_b, from_a ? vals_b : vals_a,
-                                                    (uint32_t)n, scratch + p.off_hist + pass * kOsDigits, scratch + p.off_state + (size_t)pass * p.blocks * kOsDigits,
+                                                    (uint32_t)n, hist + pass * kOsDigits, scratch + p.off_state + (size_t)pass * p.blocks * kOsDigits,
                                                     scratch + p.off_ticket + pass, bit, bits);
         from_a = !from_a;
     }

@@ -37,9 +37,9 @@ inline bool radix32_pays(size_t n, unsigned bits)
 __device__ __forceinline__ void radix32_clear(uint32_t *scratch, uint32_t words, uint32_t t, uint32_t threads) { osort_clear(scratch, words, t, threads); }
 
 inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-                                     unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first)
+                                     unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first, const uint32_t *hist_ready = nullptr)
 {
-    return osort_pairs(p, scratch, keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, st, in_first);
+    return osort_pairs(p, scratch, keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, st, in_first, hist_ready);
 }
 
 }  // namespace rsreg

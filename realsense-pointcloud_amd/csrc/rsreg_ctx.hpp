@@ -183,6 +183,8 @@ struct rsreg_ctx {
     // everything of a pending source load has been queued on stream_src (so that ev_src_done is the event of THIS load)
     int source_enqueued() { return src_worker ? src_worker->wait() : 0; }
     rsreg::DevBuf d_skeys, d_skeys_alt, d_svals, d_sflags, d_sscan, d_stmp, d_smisc;   // its scratch (the target build has its own)
+    rsreg::DevBuf d_shist;        // two sets of digit histograms of the source's sort, used in turn (k_source_keys_hist); the worker's
+    bool shist_flip = false, shist_dirty = false;
     rsreg::PinnedBuf h_smisc;
     rsreg::DevBuf d_src_all;      // float4 {x,y,z,valid} of every source point, spatially sorted
     rsreg::DevBuf d_uniq_of;      // uint32: sorted position -> distinct point id

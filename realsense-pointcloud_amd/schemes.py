@@ -10,6 +10,11 @@ RGB-Canny edge points of the organized frame) unless a ``feature_fn`` is plugged
 The numeric building blocks are injectable (``backend``): the default and only backend in
 this package is the HIP engine; tests/ plug a CPU checker into the very same scheme logic to
 compare results.
+
+This mirror is SYNCHRONOUS: one step after the other, in the reference's order.  The pipelining of the frame loops (frames
+uploaded, filtered and their features extracted ahead; the merged cloud streamed to the host) lives in ONE place, the C++
+host layer (include/rsreg/schemes.hpp); what it must not change -- the records and the transforms -- is what
+tests/test_schemes_gpu.py compares between the two.
 """
 import math
 
@@ -79,9 +84,6 @@ class HipBackend:
     def upload(self, cloud):
         return cloud
 
-    def prefetch(self, cloud):
-        return cloud
-
     def download(self, cloud):
         return cloud
 
@@ -103,66 +105,11 @@ class HipDeviceBackend(HipBackend):
             return cloud
         return self.api.DeviceCloud(cloud, self.ctx or self.api.default_context())
 
-    def prefetch(self, cloud):
-        """upload() whose PCIe copy runs beside the GPU's work on the frame before (one frame ahead in the frame loops)"""
-        if isinstance(cloud, self.api.DeviceCloud):
-            return cloud
-        return self.api.DeviceCloud(ctx=self.ctx or self.api.default_context()).upload_deferred(cloud)   # (the caller's frames stay put)
-
     def download(self, cloud):
         return cloud.download()
 
-    def edge_features_async(self, cloud):
-        """edge_features() of a DeviceCloud queued beside whatever the caller does next (None: not on this cloud)"""
-        return self.api.extract_edge_features_async(cloud) if isinstance(cloud, self.api.DeviceCloud) else None
-
-    def result_stream(self, frames):
-        """the merged cloud of `frames` (host clouds; frame 0 first) as a _StreamedResult, or None"""
-        if len(frames) < 2:
-            return None
-        return _StreamedResult(self.ctx or self.api.default_context(), frames[0], sum(len(f) for f in frames))
-
     def concat_front(self, new, target):
-        # in place: the handle then knows it grew by len(new) records in front, and the index the refining ICP has just used
-        # is updated instead of rebuilt when the next frame's coarse aligner sets the grown cloud as its target
-        return target.prepend(new)
-
-
-class _StreamedResult:
-    """The merged cloud a scheme returns, filled while its frame loop runs (detail::StreamedResult of
-    include/rsreg/schemes.hpp): frame 0 is copied on the host by a thread of its own, every later frame's moved points
-    arrive by DeviceCloud.download_async behind the work that made them."""
-
-    def __init__(self, ctx, frame0, capacity):
-        import threading
-        self.ctx = ctx
-        self.out = np.empty(capacity, frame0.points.dtype)
-        self.n, self.dense, self.pending = len(frame0), bool(frame0.is_dense), False
-        self.copy0 = threading.Thread(target=np.copyto, args=(self.out[:self.n], frame0.points))
-        self.copy0.start()
-
-    def append(self, moved):
-        got = moved.download_async(self.out, self.n)
-        self.pending = True
-        self.n += got
-        self.dense = self.dense and moved.info()[4]
-
-    def settle(self):
-        """nothing writes to `out` any more (also the way out of a frame loop that raised)"""
-        self.copy0.join()
-        if self.pending:
-            self.pending = False
-            self.ctx.wait_downloads()
-
-    def finish(self):
-        self.settle()
-        return PointCloud(self.out[:self.n], width=self.n, height=1, is_dense=self.dense)
-
-
-def _host_frames(clouds):
-    """the host clouds of a frame list if every frame is one (else None: nothing to stream into)"""
-    clouds = list(clouds)
-    return clouds if all(isinstance(c, PointCloud) for c in clouds) else None
+        return target.prepend(new)   # (in place: one copy of `new` in front, the handle keeps its buffer)
 
 
 def _assign(dst, src):
@@ -175,18 +122,9 @@ class RegistrationScheme:
     # True: the reference's progress lines on stdout, text for text (types.hpp:35-41, icp_edge_based_registration.hpp:27-32,
     # 94-96,103-104,110,113,122,127, ndt_edge_based_registration.hpp:24-29,82-84,91-93,98,101,110,114)
     verbose = False
-    # device-resident frame loop only: every frame's moved points go to the host while the next frames are aligned, so the
-    # merged cloud is complete when the loop ends instead of one download after it (16 frames of 307 k points: 157 MB, 4 ms
-    # on the link).  False: one download at the end.  Same records either way.
-    stream_result = True
 
     def __init__(self, backend=None):
         self.backend = backend or HipDeviceBackend()
-
-    def _result_stream(self, frames):
-        make = getattr(self.backend, "result_stream", None)
-        frames = _host_frames(frames) if (self.stream_result and make) else None
-        return make(frames) if frames else None
 
     def _say(self, text, end="\n"):
         if self.verbose:
@@ -223,57 +161,21 @@ class TwoPhaseRegistrationScheme(RegistrationScheme):
 
 
 class _FramePairs:
-    """The (features, frame) pairs of types.hpp:30-43, made when the frame loop gets to them: frame k + 1 is on the
-    PCIe link while frame k is being aligned, and its features are extracted when it is first asked for."""
+    """The (features, frame) pairs of types.hpp:30-43, made when the frame loop gets to them: a frame goes to the GPU once
+    (backend.upload) and its features are extracted there."""
 
     def __init__(self, scheme, clouds):
         self.scheme, self.clouds = scheme, clouds
-        self.frames = {}
         self.pairs = {}
-        self.reduced = {}
-
-    def _prepare(self, k, voxel):
-        """features of frame k extracted and voxel-filtered by the backend's side worker (nothing of them depends on the
-        registration of the frames before: types.hpp:30-43 extracts all features first); False: not with this backend"""
-        if k in self.reduced or k in self.pairs:
-            return k in self.reduced
-        make = getattr(self.scheme.backend, "edge_features_async", None)
-        f = self._frame(k)
-        feats = make(f) if make and not self.scheme.feature_fn and hasattr(voxel, "filter_async") else None
-        if feats is None:
-            return False
-        voxel.setInputCloud(feats)
-        self.pairs[k] = (feats, f)
-        self.reduced[k] = voxel.filter_async()
-        return True
-
-    def prepared(self, k, voxel):
-        """the voxel-filtered features of frame k, with those of frame k + 1 queued and frame k + 2 on the PCIe link
-        (None: this backend prepares nothing ahead)"""
-        if not self._prepare(k, voxel):
-            return None
-        for j in (k + 1, k + 2):
-            if j < len(self.clouds):
-                self._frame(j)
-        if k + 1 < len(self.clouds):
-            self._prepare(k + 1, voxel)
-        return self.reduced.pop(k)
 
     def __len__(self):
         return len(self.clouds)
-
-    def _frame(self, k):
-        if k not in self.frames:
-            self.frames[k] = self.scheme.backend.prefetch(self.clouds[k])
-        return self.frames[k]
 
     def __getitem__(self, k):
         if k < 0:
             k += len(self.clouds)
         if k not in self.pairs:
-            f = self._frame(k)
-            if k + 1 < len(self.clouds):
-                self._frame(k + 1)
+            f = self.scheme.backend.upload(self.clouds[k])
             self.pairs[k] = (self.scheme.extract_features(f), f)
         return self.pairs[k]
 
@@ -287,47 +189,22 @@ class IncrementalICP(RegistrationScheme):
         voxel = b.voxel()                 # leaf never set -> PCL's 1 m default
         icp = b.icp()
         model = b.upload(clouds[0])       # frame 0 IS the model: it grows (incremental_icp.hpp:40,64)
-        n = len(clouds)
-        # four frames ahead on the PCIe link, three frames ahead in the voxel filter (the 1 m filter is one wave adding floats
-        # one after the other, 0.4 ms a frame: three of them run side by side, each on a stream of its own, under the
-        # alignments of the frames before)
-        n_filters, n_uploads = 3, 4
-        frames = {k: b.prefetch(clouds[k]) for k in range(1, min(n_uploads + 1, n))}
-
-        def start_filter(k):
-            voxel.setInputCloud(frames[k])
-            return voxel.filter_async() if hasattr(voxel, "filter_async") and not isinstance(frames[k], PointCloud) else voxel.filter()
-
-        ahead = isinstance(b, HipDeviceBackend)       # (host clouds: nothing runs ahead, a frame is filtered when its turn comes)
-        reduced_of = {k: start_filter(k) for k in range(1, min(n_filters + 1, n))} if ahead else {}
         self.transforms = []
         self.merged_frames = []           # indices of the frames whose alignment converged (the others are skipped)
-        result = self._result_stream(clouds)
-        try:
-            for k in range(1, n):
-                if k + n_uploads < n:
-                    frames[k + n_uploads] = b.prefetch(clouds[k + n_uploads])
-                if ahead and k + n_filters < n:
-                    reduced_of[k + n_filters] = start_filter(k + n_filters)
-                reduced = reduced_of.pop(k) if ahead else start_filter(k)
-                frame = frames.pop(k)
-                icp.setInputSource(reduced)
-                icp.setInputTarget(model)
-                icp.align()
-                if not icp.hasConverged():
-                    continue
-                moved = b.transform(frame, icp.getFinalTransformation())
-                model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
-                if result:
-                    result.append(moved)     # on its way to the host while the next frame is aligned
-                self.transforms.append(icp.getFinalTransformation())
-                self.merged_frames.append(k)
-        finally:
-            if result:
-                result.settle()
+        for k in range(1, len(clouds)):
+            frame = b.upload(clouds[k])
+            voxel.setInputCloud(frame)
+            reduced = voxel.filter()
+            icp.setInputSource(reduced)
+            icp.setInputTarget(model)
+            icp.align()
+            if not icp.hasConverged():
+                continue
+            moved = b.transform(frame, icp.getFinalTransformation())
+            model = model.append(moved) if hasattr(model, "append") else b.concat(model, moved)
+            self.transforms.append(icp.getFinalTransformation())
+            self.merged_frames.append(k)
         # the caller's frame 0 has become the merged cloud
-        if result:
-            return _assign(clouds[0], result.finish()) if self.merged_frames else clouds[0]
         return _assign(clouds[0], b.download(model))
 
 
@@ -359,15 +236,6 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         raise NotImplementedError
 
     def global_registration(self, pairs):
-        # the merged cloud goes to the host frame by frame when the frames came from there
-        result = self._result_stream(pairs.clouds if isinstance(pairs, _FramePairs) else [p[1] for p in pairs])
-        try:
-            return self._global_registration(pairs, result)
-        finally:
-            if result:
-                result.settle()
-
-    def _global_registration(self, pairs, result):
         b = self.backend
         self._say("[PCL] Performing edge-based registration with %s initial rotation guesses..." % ("dynamic" if self.use_imu else "static"))
         by = self.write_byproducts and self.has_byproducts
@@ -378,7 +246,7 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             icp.reuse_target_index = True    # the coarse ICP of the ICP scheme has just built the index of the same target
         voxel = b.voxel((0.01, 0.01, 0.01))
         coarse = self._coarse()
-        merged = b.upload(pairs[0][1])             # (the whole merged cloud only without `result`)
+        merged = b.upload(pairs[0][1])
         voxel.setInputCloud(b.upload(pairs[0][0]))
         target = voxel.filter()                    # frame-0 features: filtered in place, then grown
         if by:
@@ -386,10 +254,8 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
         acc = np.float32(0.0)
         self.frame_transforms = []
         for k in range(1, len(pairs)):
-            reduced = pairs.prepared(k, voxel) if isinstance(pairs, _FramePairs) else None
-            if reduced is None:
-                voxel.setInputCloud(b.upload(pairs[k][0]))
-                reduced = voxel.filter()
+            voxel.setInputCloud(b.upload(pairs[k][0]))
+            reduced = voxel.filter()
             if by:
                 self._save("edge-%d.pcd" % k, pairs[k][0])
             if self.use_imu:
@@ -416,17 +282,14 @@ class _EdgeBased(TwoPhaseRegistrationScheme):
             moved = b.transform(b.upload(pairs[k][1]), t_coarse)
             moved = b.transform(moved, icp.getFinalTransformation())
             target = b.concat_front(refined, target) if hasattr(b, "concat_front") else b.concat(refined, target)     # new points first
-            if result:
-                result.append(moved)               # `*global = *global + *transformed`: on its way to the host already
-            else:
-                merged = b.concat(merged, moved)
+            merged = b.concat(merged, moved)
             self.frame_transforms.append((t_coarse, icp.getFinalTransformation()))
         if isinstance(pairs[0][0], PointCloud):
             _assign(pairs[0][0], b.download(target))   # the caller's frame-0 feature cloud has become the grown target
         if by:
             self._save("edge_cloud.pcd", target)
         self._say("[PCL] Done")
-        out = result.finish() if result else b.download(merged)
+        out = b.download(merged)
         return PointCloud(out.points, width=len(out), height=1, is_dense=out.is_dense)
 
 

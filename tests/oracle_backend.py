@@ -86,9 +86,6 @@ class OracleBackend:
     def upload(self, cloud):
         return cloud
 
-    def prefetch(self, cloud):
-        return cloud
-
     def download(self, cloud):
         return cloud
 

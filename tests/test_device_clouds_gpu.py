@@ -91,14 +91,13 @@ def test_schemes_device_loop_equals_host_loop(api, rs, kind):
     from rsreg_amd import schemes
     frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(3)]
     res = []
-    # host clouds; cloud handles with the merged cloud streamed to the host frame by frame (default); ... downloaded once
-    for backend, stream in ((schemes.HipBackend(), True), (schemes.HipDeviceBackend(), True), (schemes.HipDeviceBackend(), False)):
+    # host clouds; cloud handles (the frame loop resident in HBM)
+    for backend in (schemes.HipBackend(), schemes.HipDeviceBackend()):
         if kind == "incremental":
             s = schemes.IncrementalICP(backend=backend)
         else:
             cls = schemes.ICPEdgeBasedRegistration if kind == "icp_edge" else schemes.NDTEdgeBasedRegistration
             s = cls(rads=-0.0261799, backend=backend)
-        s.stream_result = stream
         clouds = [f.copy() for f in frames]
         merged = s.registration(clouds)
         tr = s.transforms if kind == "incremental" else [t for pair in s.frame_transforms for t in pair]

@@ -49,10 +49,18 @@ timeout -k 10 200 python tools/small_ndt.py 100 2>&1 | grep -v amdgpu.ids >> $O/
 cat $O/step_breakdown.txt $O/reference_mode.txt
 step "schemes"
 RSREG_SCHEME_REPS=3 timeout -k 10 900 bash tools/ab_schemes.sh $O/ab cur=realsense-pointcloud_amd > $O/cpp_scheme_times.txt 2>&1; cat $O/cpp_scheme_times.txt
+echo "== RSREG_SCHEME_FRAMES=1 RSREG_SCHEME_REPS=4 python tools/cpp_scheme_times.py N300 16: ms until the loop starts | every frame's pass through the loop | until the merged cloud is complete on the host" >> $O/cpp_scheme_times.txt
+RSREG_SCHEME_FRAMES=1 RSREG_SCHEME_REPS=4 timeout -k 10 300 python tools/cpp_scheme_times.py N300 16 2>&1 | grep "device clouds" | grep -v "finish:" | cut -c1-330 >> $O/cpp_scheme_times.txt
+for m in incremental icp_edge ndt_edge; do
+  timeout -k 10 300 bash tools/trace_scheme.sh gpurun_out/${TAG}_final/trace_$m $m > $O/trace_$m.log 2>&1 < /dev/null   # (a path relative to the repository)
+  echo "== $m (tools/trace_scheme.sh: rocprofv3 --hip-runtime-trace --kernel-trace of tests/cpp/scheme_runner.cpp, 16 x 307 k frames)" >> $O/scheme_kernel_stats.txt
+  cat $O/trace_$m/summary.txt >> $O/scheme_kernel_stats.txt
+done
+head -12 $O/scheme_kernel_stats.txt
 timeout -k 10 300 python tools/scheme_times.py N300 16 2>&1 | grep -v amdgpu.ids > $O/scheme_times.txt; tail -8 $O/scheme_times.txt
 step "other workloads"
 timeout -k 10 300 python bench.py --workload chain --steps 5 --warmup 1 > $O/bench_chain_n1.json 2> $O/bench_chain.err; cut -c1-300 $O/bench_chain_n1.json
 timeout -k 10 600 python tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err; cut -c1-250 $O/bench_configs.jsonl
 step "clean up"
-rm -rf $O/kt $O/kb $O/pmc_fetch $O/pmc_write $O/pmc_sq? $O/ab
+rm -rf $O/kt $O/kb $O/pmc_fetch $O/pmc_write $O/pmc_sq? $O/ab $O/trace_*/sequence.txt
 ls -la $O

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Dev probe: wall time of the three registration schemes end to end (frames on the host in, merged cloud on the
-host out), device-resident frame loop against host clouds (GPU only)."""
+"""Dev probe: wall time of the three registration schemes through the Python mirror (synchronous: the pipelined frame loops are
+the C++ host layer's, tools/cpp_scheme_times.py), frames on the host in, merged cloud on the host out, device-resident frame loop
+against host clouds (GPU only)."""
 import os
 import sys
 import time
@@ -31,7 +32,6 @@ for name, make in (("IncrementalICP", lambda b: schemes.IncrementalICP(backend=b
             out = None   # (the previous run's 157 MB go back outside the clock)
             fr = copy_frames()
             s = make(backend())
-            s.stream_result = os.environ.get("RSREG_SCHEME_NO_STREAM", "0") != "1"
             t = time.perf_counter()
             out = s.registration(fr)
             best = min(best, time.perf_counter() - t)

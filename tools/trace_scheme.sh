@@ -31,6 +31,18 @@ def short(n):
     return n.split('(')[0][:50]
 launches = [i for i, r in enumerate(api) if r['Function'] == 'hipLaunchKernel']
 per_run = len(launches) // 3
+# summary.txt: launches per run (the runner does the scheme three times: two timed repetitions and the one whose result it writes),
+# and the kernels of all three by total time
+import collections as _c
+tot, cnt = _c.Counter(), _c.Counter()
+for r in ker:
+    nm = short(r['Kernel_Name'])
+    tot[nm] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    cnt[nm] += 1
+with open(O + "/summary.txt", "w") as f:
+    f.write("kernel launches: %d in three runs = %d per run; %.2f ms of kernels per run\n" % (len(ker), len(ker) // 3, sum(tot.values()) / 3e3))
+    for nm, t in tot.most_common(28):
+        f.write("  %-52s %5d launches per run %9.1f us per run (%.1f us each)\n" % (nm, cnt[nm] // 3, t / 3, t / cnt[nm]))
 start, end = launches[-per_run * 9 // 16], launches[-per_run * 6 // 16]   # about three frames of the last run
 t0 = int(api[start]['Start_Timestamp'])
 quiet = ('hipGetLastError', 'hipGetStreamDeviceId', 'hipGetDevicePropertiesR0600', 'hipDeviceGetAttribute', 'hipSetDevice', 'hipGetDevice')

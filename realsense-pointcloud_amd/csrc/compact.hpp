@@ -8,8 +8,8 @@
 // workgroup (the two running counts and a status, so a word is complete the moment it is visible: no fence), and
 // scatters.  Workgroups number themselves by a ticket, so a workgroup only ever waits for workgroups that are already
 // running.  The words and the ticket must be zero when the kernel starts: the kernel in front of the sort clears them on
-// its way with the sort's own state (radix32.hpp).  The block scan and the look-back are here; the kernel that uses them is
-// k_dense_compact (icp_dense.hpp).  (The same form for the source load's tail was measured and is level with rocPRIM's
+// its way with the sort's own state (radix32.hpp).  The block scan and the look-back are here; the kernels that use them are
+// k_dense_compact (icp_dense.hpp: the sort-based index build) and k_edge_compact (edges.hip: the edge points' records).  (The same form for the source load's tail was measured and is level with rocPRIM's
 // scan there: profiles/r04_experiments/README.md.)
 #pragma once
 

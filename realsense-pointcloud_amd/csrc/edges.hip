@@ -92,30 +92,6 @@ __global__ __launch_bounds__(kBlock) void k_edge_sobel(const float *sm, int w, i
     else if (((angle > 112.5f) && (angle < 157.5f)) || ((angle < -22.5f) && (angle > -67.5f))) d = 3;
     dir[p] = d;
 }
-
-// pcl::Edge::suppressNonMaxima: interior pixels at or above the low threshold that are no smaller than
-// their two neighbours along the gradient keep their magnitude, everything else is 0.
-// label[p] = p for a kept pixel (its own component to start with), -1 otherwise.
-// strong[p] = 0: no component is strong yet (k_edge_cc_roots marks the roots; no launch of a memset in between).
-__global__ __launch_bounds__(kBlock) void k_edge_nms(const float *mag, const uint8_t *dir, int w, int h, float t_low, float *mx, int *label,
-                                                     uint32_t *strong)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= w * h) return;
-    strong[p] = 0u;
-    const int i = p / w, j = p - i * w;
-    float out = 0.0f;
-    if (i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
-        const float m = mag[p];
-        const uint8_t d = dir[p];
-        if (!(m < t_low) && d != 255) {
-            const int o = d == 0 ? 1 : (d == 1 ? w + 1 : (d == 2 ? w : w - 1));   // (j-1, j+1) / (i-1 j-1, i+1 j+1) / (i-1, i+1) / (i-1 j+1, i+1 j-1)
-            if (m >= mag[p - o] && m >= mag[p + o]) out = m;
-        }
-    }
-    mx[p] = out;
-    label[p] = out != 0.0f ? p : -1;
-}
 #endif
 
 __device__ __forceinline__ int cc_find(const int *label, int i)
@@ -238,8 +214,10 @@ __global__ __launch_bounds__(kCcTile * kCcTile) void k_edge_tile(const char *rec
                 gx = __fadd_rn(gx, __fmul_rn(kx[kr * 3 + kc], v));
                 gy = __fadd_rn(gy, __fmul_rn(ky[kr * 3 + kc], v));
             }
-        s_m[r][c] = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
-        // (the angle as the correctly rounded float of atan2, classes as pcl::Edge::discretizeAngles: see k_edge_sobel)
+        s_m[r][c] = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));   // (sqrtf is correctly rounded under hipcc's default; __fsqrt_rn is the 1-ulp native one)
+        // the angle as the correctly rounded float of atan2 (PCL's atan2f is libm-dependent in its last ulp: the double-precision
+        // result rounded once is what a correctly rounded atan2f returns, on every platform), in degrees like pcl::rad2deg(float);
+        // classes as pcl::Edge::discretizeAngles: 0 / 1 / 2 / 3 = 0 / 45 / 90 / 135 degrees, 255 = none of them (a NaN direction)
         const float angle = __fmul_rn((float)atan2((double)gy, (double)gx), 57.29578f);
         uint8_t d = 255;
         if (((angle <= 22.5f) && (angle >= -22.5f)) || (angle >= 157.5f) || (angle <= -157.5f)) d = 0;

@@ -417,3 +417,35 @@ print(h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         out[no_worker] = r.stdout.strip().splitlines()[-1]
     assert out["0"] == out["1"] and len(out["0"]) == 64
+
+
+@pytest.mark.gpu
+def test_sources_of_every_size_through_one_context(rs):
+    """The source load takes different paths by size -- the caller's order (<= 65 536 points), one workgroup's sort
+    (never for a source: it is below the plain limit), the library's radix sort with its digit histograms counted by the keys
+    kernel into one of two sets used in turn -- and a context sees them in any order: every alignment must give the bits a
+    fresh context gives."""
+    from rsreg_amd import api
+    tgt = rs.synth.render_frame(0, "N300", "bench")
+    guess = rs.synth.small_transform(1.0, (0.008, -0.004, 0.006)).astype(np.float32)
+    big_a, big_b = rs.synth.render_frame(1, "N300", "bench"), rs.synth.render_frame(2, "N300", "bench")
+    mid = rs.PointCloud(big_a.points[::7].copy(), width=len(big_a.points[::7]), height=1, is_dense=False)     # 43 886: plain
+    small = rs.PointCloud(big_b.points[::100].copy(), width=len(big_b.points[::100]), height=1, is_dense=False)
+    edge = rs.PointCloud(big_a.points[:70000].copy(), width=70000, height=1, is_dense=False)                    # just above the plain limit
+    order = [big_a, mid, big_b, small, edge, big_a, edge, big_b, big_b]
+
+    def run(icp, src):
+        icp.setInputSource(src)
+        out = icp.align(guess)
+        r = icp.result
+        return (bytes(r.transform), bytes(r.sums_last), r.n_correspondences, r.iterations, np.stack([out.points[c] for c in "xyz"]).tobytes())
+
+    def fresh():
+        icp = api.IterativeClosestPoint(api.Context(0))
+        icp.params = api.icp_params(max_iterations=3, criteria_mode=1, pipeline_mode=2, max_correspondence_distance=0.03)
+        icp.setInputTarget(tgt)
+        return icp
+
+    one = fresh()
+    for k, src in enumerate(order):
+        assert run(one, src) == run(fresh(), src), k

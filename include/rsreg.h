@@ -399,6 +399,7 @@ typedef struct rsreg_grid_info {
     uint32_t n_source_distinct; /* distinct source points the iterations work on (0: no source) */
     uint64_t index_bytes;       /* HBM bytes of the index: sorted points + tables           */
 } rsreg_grid_info;
+/* (waits for an index build that rsreg_icp_set_target* has queued and not waited for: the two counts come with it) */
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
 
 /* Where the HOST-pointer entry points (rsreg_icp_set_source, rsreg_icp_set_target, rsreg_icp_align with aligned_out: the

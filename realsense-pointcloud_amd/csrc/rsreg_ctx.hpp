@@ -166,6 +166,12 @@ struct rsreg_ctx {
     size_t cnt_zero_cap = 0;
     bool cnt_flip = false;        // which of the two sets of per-span totals the next counting build fills
     bool cnt_dirty = false;       // a counting build is under way (or did not finish): the counts are not known to be zero
+    // The two counts a counting build ends with (occupied cells, records in the sorted array) lie in pinned words; nothing the
+    // searches do needs them on the host (they bound the record array by the number of finite points), so set_target does
+    // not wait for the build: whoever wants the counts, or has just waited for the stream anyway, takes them over (icp.hip:
+    // target_counts).
+    bool counts_pending = false;
+    size_t counts_total = 0, counts_n = 0;   // (table entries and input points of that build: for index_bytes)
     size_t n_target_raw = 0;
 
     // ---- ICP source
@@ -179,6 +185,7 @@ struct rsreg_ctx {
     hipStream_t stream_src = nullptr;
     hipEvent_t ev_src_done = nullptr, ev_main = nullptr;
     bool src_pending = false;
+    bool src_on_worker = false;   // ... and its launches are being queued by the context's worker thread right now
     rsreg::SourceWorker *src_worker = nullptr;   // (created with the first source load; RSREG_NO_WORKER=1: never, the load runs on the caller's thread)
     // everything of a pending source load has been queued on stream_src (so that ev_src_done is the event of THIS load)
     int source_enqueued() { return src_worker ? src_worker->wait() : 0; }

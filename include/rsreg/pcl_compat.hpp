@@ -122,8 +122,8 @@ template <typename PointT> inline PointVector<PointT> uninitialized_points(size_
 {
     static_assert(std::is_trivially_copyable<PointT>::value && std::is_trivially_destructible<PointT>::value,
                   "records that may stay unconstructed must be plain data");
-#if defined(__GLIBCXX__)
-    // libstdc++: the storage is reserved and the end pointer moved: no per-record call at all (the portable path below still
+#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(_GLIBCXX_SANITIZE_VECTOR)
+    // libstdc++ (not its debug mode, nor with annotated containers): the storage is reserved and the end pointer moved: no per-record call at all (the portable path below still
     // goes through the allocator's construct() once per record -- 1 ms of doing nothing for a merged cloud of 4.9 M points)
     struct Open : PointVector<PointT> {
         void grow_unconstructed(size_t m)

@@ -41,6 +41,9 @@ def parse():
                     help="0 staged kernels, 1 fused kernel + host 3x3 solve per iteration, 2 fused kernel + device-resident loop")
     ap.add_argument("--shard-block", type=int, default=256, help="N > 1: source points per block, blocks dealt round-robin to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the warm-up and the timed headline steps (no pipeline-1, from-identity, events-in-all-steps, host-buffer or "
+                         "reference-mode legs, no CPU baseline): what rocprofv3 is pointed at, so that its per-kernel means are the headline's")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: take the multi-rank code path (process group, native RCCL transport, all-reduce per iteration) "
                          "even with one rank, e.g. under `torch.distributed.run --nproc-per-node 1`")
@@ -59,7 +62,10 @@ def parse():
     ap.add_argument("--workload", default="pair", choices=["pair", "chain"],
                     help="pair: ONE 1M pair, source sharded over the ranks (configs[1]/[3], the headline line); "
                          "chain: 2 x N frames of 300k points as consecutive pairs, one pair per GPU at a time (configs[4])")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.headline_only:
+        a.no_cpu_baseline = True
+    return a
 
 
 def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
@@ -496,7 +502,7 @@ def main():
         gb = 116.0 * n_tgt / (ms_build / max(n_event_steps, 1) * 1e-3) / 1e9
         out["grid_build"] = {"ms": ms_build / max(n_event_steps, 1), "algorithmic_bytes": 116 * n_tgt, "achieved": gb, "unit": "GB/s", "peak": HBM_PEAK_GBS,
                              "frac": gb / HBM_PEAK_GBS}
-    if world == 1 and a.pipeline == 2:
+    if world == 1 and a.pipeline == 2 and not a.headline_only:
         # the north star's default pipeline next to the headline: fused kernel, 136 bytes to the host and a host 3x3
         # solve per iteration (pipeline 1), without the HIP events of the roofline leg
         ctx1 = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=False)

@@ -10,11 +10,11 @@ step bench
 timeout -k 10 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err || { tail -5 $O/bench_n1.err; exit 1; }
 cut -c1-600 $O/bench_n1.json
 step "kernel stats"
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1)
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only > $O/kt.log 2>&1)
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench.csv
 step "traffic"
-(cd /tmp && timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1)
-(cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1)
+(cd /tmp && timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --headline-only > $O/pmc_fetch.log 2>&1)
+(cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --headline-only > $O/pmc_write.log 2>&1)
 python tools/make_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json "round 5" > $O/traffic.log 2>&1; tail -2 $O/traffic.log
 step "SQ counters"
 : > $O/pmc_sq_counters.txt
@@ -24,7 +24,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES
            "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64" \
            "SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_IFETCH SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL"; do
   k=$((k+1))
-  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc_sq$k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq$k.log 2>&1)
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc_sq$k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --headline-only > $O/pmc_sq$k.log 2>&1)
   python tools/pmc_summary.py $O/pmc_sq$k rsreg >> $O/pmc_sq_counters.txt 2>&1
 done
 python tools/make_issue.py $O/pmc_sq_counters.txt profiles/r03_valu_issue_microbench.txt $O/issue.json > $O/issue.log 2>&1; tail -2 $O/issue.log

@@ -35,7 +35,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {
         "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes of `python3 bench.py --steps 3 "
-               "--warmup 1 --no-cpu-baseline` (N1M pair, 30 iterations); per-launch means; KB x 1024 -> bytes; "
+               "--warmup 1 --headline-only` (N1M pair, 30 iterations; the headline's steps only); per-launch means; KB x 1024 -> bytes; "
                "gfx950 correction per MI355X_MICROARCH.md HBM section: FETCH_SIZE x 2 (exact for 16-B-per-lane "
                "coalesced reads, an upper bound for the narrower reads mixed in), WRITE_SIZE exact; "
                "Infinity-Cache hits are counted, not excluded",

@@ -606,7 +606,7 @@ def main():
             omp_s = time.perf_counter() - tc
             out["cpu_baseline_all_cores"] = {"value": float(n_src_total) * a.cpu_iterations / omp_s, "unit": "point-pairs/s",
                                              "cores": threads, "kind": "port", "seconds": omp_s}
-    if world == 1:
+    if world == 1 and not a.headline_only:
         # PCIe-inclusive rate (never `value`): the same pair handed over as HOST buffers, as the
         # reference's call surface does (clouds in host memory in, 4x4 out)
         th = time.perf_counter()

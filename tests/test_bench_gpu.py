@@ -39,6 +39,15 @@ def test_bench_json_contract():
     assert j["transform_error_vs_cpu_frobenius"] < 1e-4          # north-star bar
 
 
+def test_bench_headline_only_runs_nothing_but_the_headline():
+    """What rocprofv3 is pointed at (tools/final_profiles.sh): the warm-up and the timed steps, so that a profiler's
+    per-kernel means are the headline's -- the contract line with its roofline, none of the other legs."""
+    j = run(["bench.py", "--size", "50k", "--steps", "2", "--warmup", "1", "--headline-only"])
+    assert j["value"] > 0 and j["roofline"]["avg_launch_ms"] > 0 and j["steps"] == 2
+    for leg in ("pipeline1_ms_per_step", "convergence_from_identity", "value_with_events_in_all_steps", "host_buffers", "reference_mode", "cpu_baseline"):
+        assert leg not in j, leg
+
+
 def test_bench_multi_rank_path_with_one_rank():
     j = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
              str(29600 + os.getpid() % 300), "bench.py", "--gpus", "1", "--size", "50k", "--steps", "2", "--warmup", "1",

@@ -856,11 +856,12 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         // only, so that a schedule can be carried over to the next alignment (launch_fused); a new buffer starts from zero
         // (the done counters go back to zero by themselves) and without a schedule
         void *before = ctx->d_sched.ptr;
-        RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 11 * 4 + 256));
+        RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 15 * 4 + 256));
         if (ctx->d_sched.ptr != before) {
             RSREG_HIP(ctx, hipMemsetAsync(ctx->d_sched.ptr, 0, ctx->d_sched.cap, ctx->stream));
-            ctx->sched_cap_tiles = (uint32_t)((ctx->d_sched.cap - 256) / (11 * 4));
+            ctx->sched_cap_tiles = (uint32_t)((ctx->d_sched.cap - 256) / (15 * 4));
             ctx->sched_keep_items = 0;
+            ctx->sched_first_items = 0;
         }
     }
     RSREG_HIP(ctx, ctx->d_sums.reserve(64 * 8));
@@ -1180,7 +1181,7 @@ SchedCfg sched_cfg()
 constexpr int kSchedKeepFor = 8;   // alignments a tile schedule serves before a launch is timed again
 
 struct SchedBufs {
-    uint32_t *items, *cost, *done, *keys, *keys_alt, *vals, *vals_alt;
+    uint32_t *items, *cost, *done, *keys, *keys_alt, *vals, *vals_alt, *items_first;
 };
 
 SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
@@ -1188,7 +1189,7 @@ SchedBufs sched_bufs(const rsreg_ctx *ctx, uint32_t n_tiles)
     uint32_t *p = ctx->d_sched.as<uint32_t>();
     (void)n_tiles;
     const size_t t = ctx->sched_cap_tiles;   // (capacity, not this source's tiles: the arrays stay put from one alignment to the next)
-    return SchedBufs{p, p + 4 * t, p + 6 * t, p + 7 * t, p + 8 * t, p + 9 * t, p + 10 * t};
+    return SchedBufs{p, p + 4 * t, p + 6 * t, p + 7 * t, p + 8 * t, p + 9 * t, p + 10 * t, p + 11 * t};
 }
 
 // The whole schedule in one workgroup (7 k tiles at 10^6 points; three kernels and a device-wide radix sort of 10-bit
@@ -1348,23 +1349,32 @@ __global__ __launch_bounds__(1024) void k_sched_build_xcd(const uint32_t *cost, 
     for (uint32_t k = used + tid; k < total_items; k += 1024u) items[k] = 0xffffffffu;   // (a run shorter than its share of the splits: nothing to do)
 }
 
-int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles)
+// first: the schedule of the alignments' FIRST launches (from a timed first launch; kept beside the steady one)
+int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles, bool first = false)
 {
     const SchedCfg cfg = sched_cfg();
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
     const bool xcd = tunables().sched_xcd;
+    uint32_t *items = first ? sb.items_first : sb.items;
     if (xcd) {
         n4 -= n4 % 8u;   // (an eighth of the splits to every run)
         n2 -= n2 % 8u;
         const uint32_t deal = tunables().sched_xcd_deal;
-        k_sched_build_xcd<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, n_tiles + 3 * n4 + n2, deal, sb.items, sb.done);
+        k_sched_build_xcd<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, n_tiles + 3 * n4 + n2, deal, items, sb.done);
     } else {
-        k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, sb.items, sb.done);
+        k_sched_build<<<1, 1024, 0, st>>>(sb.cost, n_tiles, n4, n2, items, sb.done);
     }
     RSREG_HIP(ctx, hipGetLastError());
-    ctx->icp.sched_items = n_tiles + 3 * n4 + n2;
+    const uint32_t n_items = n_tiles + 3 * n4 + n2;
+    if (first) {
+        ctx->sched_first_items = n_items;
+        ctx->sched_first_tiles = n_tiles;
+        ctx->sched_first_age = 0;
+        return RSREG_OK;
+    }
+    ctx->icp.sched_items = n_items;
     ctx->sched_keep_items = ctx->icp.sched_items;   // (kept for the alignments to come: launch_fused)
     ctx->sched_keep_tiles = n_tiles;
     ctx->sched_keep_age = 0;
@@ -1422,23 +1432,42 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 sc.done = sb.done;
                 sc.pos = ctx->d_corr_pos.as<int>();
                 sc.d2 = ctx->d_corr_d2.as<float>();
-                // The schedule of an earlier alignment of this context serves this one too, from its first launch (or from the one
-                // that would otherwise be timed, when the first is a launch of k_restart_source's kind apart): the long tiles sit on the same (near, densely sampled) surfaces from one frame to the next, a schedule is
+                // The schedule of an earlier alignment of this context serves this one too, from the launch that would otherwise be
+                // timed: the long tiles sit on the same (near, densely sampled) surfaces from one frame to the next, a schedule is
                 // an order of work and never wrong, and the timed launch runs unscheduled (140 against 93 us at 10^6 points).
                 // Carried for at most kSchedKeepFor alignments and only to a source of about as many tiles; RSREG_SCHED_KEEP=0: never.
-                if (!s.sched_ready && (restart_here || s.fused_launches >= cfg.at_launch) && ctx->sched_keep_items && tunables().sched_keep &&
-                    ctx->sched_keep_age < kSchedKeepFor && n_tiles + n_tiles / 8 >= ctx->sched_keep_tiles && ctx->sched_keep_tiles + ctx->sched_keep_tiles / 8 >= n_tiles) {
+                auto fits = [&](uint32_t tiles) { return n_tiles + n_tiles / 8 >= tiles && tiles + tiles / 8 >= n_tiles; };
+                const bool keep = tunables().sched_keep;
+                bool first_sched = false, time_first = false;
+                if (restart_here && keep) {
+                    // the FIRST launch (unseeded, from the source itself under the guess: the only launch the reference's
+                    // parameters ever run) has a cost profile of its own: it is timed once and scheduled from its own
+                    // kind's costs in the alignments that follow
+                    if (ctx->sched_first_items && ctx->sched_first_age < kSchedKeepFor && fits(ctx->sched_first_tiles)) {
+                        first_sched = true;
+                        ++ctx->sched_first_age;
+                    } else {
+                        time_first = true;
+                    }
+                }
+                if (!s.sched_ready && !restart_here && s.fused_launches >= cfg.at_launch && ctx->sched_keep_items && keep &&
+                    ctx->sched_keep_age < kSchedKeepFor && fits(ctx->sched_keep_tiles)) {
                     s.sched_ready = true;
                     s.sched_carried = true;
                     s.sched_items = ctx->sched_keep_items + (n_tiles > ctx->sched_keep_tiles ? n_tiles - ctx->sched_keep_tiles : 0u);
                     ++ctx->sched_keep_age;
                 }
-                if (s.sched_ready) {
+                if (first_sched) {
+                    sc.items = sb.items_first;
+                    sc.n_items = ctx->sched_first_items;
+                    sc.first_extra = ctx->sched_first_tiles;
+                    grid = ctx->sched_first_items + (n_tiles > ctx->sched_first_tiles ? n_tiles - ctx->sched_first_tiles : 0u);
+                } else if (s.sched_ready) {
                     sc.items = sb.items;
                     grid = s.sched_items;
                     sc.n_items = s.sched_carried ? ctx->sched_keep_items : grid;
                     sc.first_extra = ctx->sched_keep_tiles;
-                } else if (s.fused_launches == cfg.at_launch) {
+                } else if (time_first || (!restart_here && s.fused_launches == cfg.at_launch)) {
                     sc.cost = sb.cost;
                 }
             }
@@ -1449,8 +1478,12 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
                 ctx->d_corr_d2.as<float>(), ctx->d_partials.as<double>(), seed_ptr(ctx), wt, dev, sc);
             RSREG_HIP(ctx, hipGetLastError());
             if (sc.cost) {
-                int rc = build_schedule(ctx, n_tiles);
+                int rc = build_schedule(ctx, n_tiles, restart_here);
                 if (rc) return rc;
+                if (restart_here && cfg.at_launch == 0) {   // (RSREG_SCHED_AT=0: the steady schedule from the first launch's costs too)
+                    rc = build_schedule(ctx, n_tiles, false);
+                    if (rc) return rc;
+                }
             }
             s.fused_launches++;
             if (sc.items) s.n_sched_launches++;

@@ -158,6 +158,10 @@ struct rsreg_ctx {
     uint32_t sched_cap_tiles = 0;        // tiles the buffer was laid out for (the arrays' offsets)
     uint32_t sched_keep_items = 0, sched_keep_tiles = 0;   // the last schedule built in it: workgroups, tiles of its source (0: none)
     int sched_keep_age = 0;              // alignments it has served since
+    // the same for the FIRST launch of an alignment (unseeded, from the source itself: another cost profile), built from a timed
+    // first launch and kept beside the steady one
+    uint32_t sched_first_items = 0, sched_first_tiles = 0;
+    int sched_first_age = 0;
     rsreg::DevBuf d_keys, d_keys_alt, d_vals, d_vals_alt, d_flags, d_scan, d_brick, d_tmp;
     rsreg::DevBuf d_misc;         // small: bbox, counters
     rsreg::DevBuf d_cnt;          // counting build (cellsort.hpp): points per table slot, all zero between builds

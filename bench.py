@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", default="N1M", choices=["50k", "N300", "N1M"])
+    ap.add_argument("--size", default=None, choices=["50k", "N300", "N1M"],
+                    help="points per cloud (default: N1M for the pair workload -- the configuration the metric is quoted on -- and N300 for the chain, configs[4])")
     ap.add_argument("--iterations", type=int, default=30)
     ap.add_argument("--max-dist", type=float, default=0.05)
     ap.add_argument("--pipeline", type=int, default=2,
@@ -62,7 +63,16 @@ def parse():
     ap.add_argument("--workload", default="pair", choices=["pair", "chain"],
                     help="pair: ONE 1M pair, source sharded over the ranks (configs[1]/[3], the headline line); "
                          "chain: 2 x N frames of 300k points as consecutive pairs, one pair per GPU at a time (configs[4])")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="chain: frames of the chain (0: 2 x N, about two pairs per GPU whatever N -- weak scaling; 16: configs[4] as written, "
+                         "its 15 pairs dealt to the ranks)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="chain: pairs registered SIDE BY SIDE on every GPU, each on a context of its own driven by its own thread "
+                         "(rsreg_amd/chain.py: ChainRegistrar; the frames are read where they lie, through raw device pointers).  "
+                         "0: the rank's pairs one after the other on one context, through cloud handles (rounds 2-5)")
     a = ap.parse_args()
+    if a.size is None and a.workload == "pair":
+        a.size = "N1M"
     if a.headline_only:
         a.no_cpu_baseline = True
     return a
@@ -78,8 +88,8 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
 
     from rsreg_amd import api, chain, lib, synth
 
-    size = "N300" if a.size == "N1M" else a.size     # the config's frame size unless another one is asked for
-    n_frames = 2 * world
+    size = a.size or "N300"     # the config's frame size unless another one is asked for
+    n_frames = a.frames if a.frames >= 2 else 2 * world
     mine = chain.pair_assignment(n_frames, rank, world)
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream, profiling=not a.no_events)
     need = sorted({k for k in mine} | {k - 1 for k in mine})
@@ -102,8 +112,25 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
         return [o.cpu().numpy() for o in outs]
 
     stats = {"ms_nn": 0.0, "launch": 0, "ms_build": 0.0}
+    registrar = shared = None
+    if a.in_flight >= 1:
+        registrar = chain.ChainRegistrar(local_rank, a.in_flight, params=prm)
+        ctx.synchronize()
+        shared = {k: chain.ChainRegistrar.share(dev[k]) for k in need}     # settled: any stream may read them from here on
+        stats_lock = __import__("threading").Lock()
+
+        def collect_pair(k, r, c):
+            g = lib.GridInfo()
+            L.rsreg_icp_grid_info(c.h, C.byref(g))
+            with stats_lock:
+                stats["ms_nn"] += r.ms_nn
+                stats["launch"] += r.n_nn_launches
+                stats["ms_build"] += g.ms_build
 
     def step(collect=False):
+        if registrar is not None:
+            local = registrar.register(shared, mine, guess, collect=collect_pair if collect else None)
+            return chain.compose_chain(chain.gather_pairs(local, n_frames, allgather), n_frames), local
         local = {}
         for k in mine:
             lib.check(L.rsreg_icp_set_target_cloud(ctx.h, dev[k - 1].h, a.max_dist), ctx.h)
@@ -117,7 +144,14 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
                 stats["ms_build"] += gi.ms_build
         return chain.compose_chain(chain.gather_pairs(local, n_frames, allgather), n_frames), local
 
+    def set_profiling(on):
+        for c in ([ctx] if registrar is None else registrar.contexts):
+            c.set_profiling(on)
+
     def sync():
+        if registrar is not None:
+            for c in registrar.contexts:
+                c.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -126,23 +160,30 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
         step()
     sync()
     every = max(1, a.event_every)
-    ctx.set_profiling(False)
+    set_profiling(False)
     t0 = time.perf_counter()
     for k in range(a.steps):
         timed = (not a.no_events) and k % every == 0     # (this step carries the per-launch HIP events: bench.py --event-every)
         if timed:
-            ctx.set_profiling(True)
+            set_profiling(True)
         poses, local = step(collect=timed)
         if timed:
-            ctx.set_profiling(False)
+            set_profiling(False)
     sync()
     elapsed = time.perf_counter() - t0
-    if not stats["launch"]:
-        L.rsreg_icp_grid_info(ctx.h, C.byref(gi))
+    L.rsreg_icp_grid_info((registrar.contexts[0] if registrar is not None else ctx).h, C.byref(gi))
     # the same step with records the handles have never measured under the SOURCE frames (re-uploaded with the clock stopped): in the
     # timed region above every handle keeps the bounding box an earlier load measured, which a stream of new frames has for its
     # targets (last pair's sources) but never for its sources
-    fresh_s, fresh_n = 0.0, min(3, a.steps)
+    fresh_s, fresh_n = 0.0, (min(3, a.steps) if registrar is None else 0)   # (raw device pointers carry no measured box: every step is "fresh")
+    seq_diff = None
+    if registrar is not None:
+        # every pair once more, alone and through the cloud handles (the path of rounds 2-5): the bits must be the same
+        keep = registrar
+        registrar = None
+        _, seq_local = step()
+        registrar = keep
+        seq_diff = float(max(np.abs(np.asarray(local[k], np.float64) - np.asarray(seq_local[k], np.float64)).max() for k in mine)) if mine else 0.0
     for _ in range(fresh_n):
         for k in mine:
             dev[k].upload(host[k])
@@ -170,9 +211,10 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "icp_chain_%dx%s_%dit_consecutive_pairs" % (n_frames, size, a.iterations), "n_frames": n_frames,
-            "points_per_frame": n_pts, "pairs": n_pairs, "iterations": a.iterations, "max_corr_dist": a.max_dist, "criteria": "fixed",
+            "points_per_frame": n_pts, "pairs": n_pairs, "in_flight": a.in_flight, "iterations": a.iterations, "max_corr_dist": a.max_dist, "criteria": "fixed",
             "sharding": "pairs (k-1, k) dealt round-robin to %d ranks, no collective on the data path; 4x4s gathered and composed on the host" % world,
-            "step": "every pair: index build + source load + %d iterations from frames resident in HBM; gather + composition of the chain" % a.iterations,
+            "step": "every pair: index build + source load + %d iterations from frames resident in HBM; gather + composition of the chain" % a.iterations +
+                    ("; %d pairs side by side per GPU, a context and a thread each (chain.ChainRegistrar)" % a.in_flight if a.in_flight >= 1 else ""),
             "deviation": "consecutive pairs instead of the reference's frame-to-model chain (incremental_icp.hpp:51-66 is sequential)",
         },
         "roofline": {"bound": "hbm", "kernel": "k_icp_fused_dense", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -180,6 +222,12 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
                      "avg_launch_ms": avg_ms, "launches": stats["launch"]},
         "chain_pose_error_vs_ground_truth_frobenius_max": float(max(np.linalg.norm(poses[k] - gt[k]) for k in range(n_frames))),
         "ms_per_step_fresh_source_frames": (fresh_s / fresh_n * 1e3) if fresh_n else None,
+        "ms_per_pair": elapsed / a.steps * 1e3 / max(1, len(mine)),
+        "pairs_on_rank0": len(mine),
+        # in flight: the per-launch HIP events of the roofline leg time launches that SHARE the GPU with other alignments' kernels
+        "roofline_note": ("launch durations measured with %d alignments in flight: they overlap, their sum exceeds the wall time" % a.in_flight)
+                         if a.in_flight > 1 else None,
+        "in_flight_vs_sequential_max_abs_diff": seq_diff,
     }
     if not a.no_cpu_baseline:
         import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product

@@ -179,7 +179,12 @@ void rsreg_ndt_params_reference(rsreg_ndt_params *p);
 /* icp.setInputTarget(cloud) + the search-structure build PCL does in initCompute()
  * (incremental_icp.hpp:58, icp_edge...hpp:79,109, ndt_edge...hpp:97).  Builds the
  * uniform-grid index over the finite target points.  The grid cell size is derived from
- * max_correspondence_distance, so that must be known here. */
+ * max_correspondence_distance, so that must be known here.
+ * The build is QUEUED on the context's stream and may not be finished when the call returns (its two counts are
+ * taken over at the next call that waits for the stream): a host buffer has been read by then (a second
+ * rsreg_icp_set_target first waits for the queued build that still reads the staged records); a DEVICE buffer
+ * (d_points) must stay alive and unchanged until the next synchronising call on the context -- rsreg_icp_align /
+ * rsreg_icp_begin, rsreg_icp_grid_info or rsreg_ctx_synchronize -- has returned. */
 int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t stride,
                          int is_dense, double max_correspondence_distance);
 int rsreg_icp_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, size_t stride,

@@ -122,9 +122,12 @@ template <typename PointT> inline PointVector<PointT> uninitialized_points(size_
 {
     static_assert(std::is_trivially_copyable<PointT>::value && std::is_trivially_destructible<PointT>::value,
                   "records that may stay unconstructed must be plain data");
-#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(_GLIBCXX_SANITIZE_VECTOR)
-    // libstdc++ (not its debug mode, nor with annotated containers): the storage is reserved and the end pointer moved: no per-record call at all (the portable path below still
-    // goes through the allocator's construct() once per record -- 1 ms of doing nothing for a merged cloud of 4.9 M points)
+#if defined(RSREG_PCL_COMPAT_FAST_UNINIT) && defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(_GLIBCXX_SANITIZE_VECTOR)
+    // OPT-IN (-DRSREG_PCL_COMPAT_FAST_UNINIT; this repository's own runners set it): libstdc++ only, not its debug mode nor
+    // annotated containers.  The storage is reserved and the end pointer moved, no per-record call at all (the portable
+    // default below goes through the allocator's construct() once per record: 1 ms of doing nothing for a merged cloud of
+    // 4.9 M points).  It reaches into libstdc++'s private _M_impl through a cast to a type the vector is not -- formally
+    // undefined behaviour, which is why an integrator's toolchain gets the portable path unless it asks.
     struct Open : PointVector<PointT> {
         void grow_unconstructed(size_t m)
         {

@@ -15,7 +15,10 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <iostream>
 #include <memory>
@@ -63,12 +66,21 @@ class RegistrationScheme {
     // loop was done ([0]), every frame's pass through the loop ended ([1] .. [n-1]), and the merged cloud was complete on
     // the host (the last entry) -- the per-frame table of tools/cpp_scheme_times.py (RSREG_SCHEME_FRAMES=1)
     std::vector<double> frame_clock_ms;
+    // engine extra (stream_result): what the end of the loop waited for, in ms -- the host copy of frame 0, the downloads still
+    // on their way -- and the host time of all download_async calls together
+    double stream_finish_ms[3] = {0, 0, 0};
 
   protected:
     void clock_start()
     {
         clock0_ = std::chrono::steady_clock::now();
         frame_clock_ms.clear();
+    }
+    template <class R> void note_finish(const R &r)
+    {
+        stream_finish_ms[0] = r.join_ms;
+        stream_finish_ms[1] = r.wait_ms;
+        stream_finish_ms[2] = r.append_ms;
     }
     void clock_mark() { frame_clock_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0_).count()); }
 
@@ -141,10 +153,9 @@ class StreamedResult {
         if (copy0_.joinable()) copy0_.join();
         const auto t1 = std::chrono::steady_clock::now();
         ctx_->wait_downloads();
-        if (std::getenv("RSREG_STREAM_VERBOSE"))
-            std::fprintf(stderr, "finish: join %.3f ms, wait %.3f ms; download_async calls took %.3f ms in all\n",
-                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), append_us_ / 1e3);
+        join_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        append_ms = append_us_ / 1e3;
         pending_ = false;
         pts_.resize(n_);
         out.points = std::move(pts_);
@@ -153,12 +164,15 @@ class StreamedResult {
         out.is_dense = dense_;
     }
 
+    // what finish() waited for: the copy of frame 0, the downloads still on their way; and the host time of all download_async calls
+    double join_ms = 0, wait_ms = 0, append_ms = 0;
+
   private:
     std::shared_ptr<Context> ctx_;
     PointVector<rgb_point> pts_;
     size_t n_;
     bool dense_, pending_ = false;
-    double append_us_ = 0;   // (host time inside download_async: RSREG_STREAM_VERBOSE)
+    double append_us_ = 0;   // (host time inside download_async)
     std::thread copy0_;
 };
 
@@ -222,7 +236,7 @@ class IncrementalICP : public RegistrationScheme {
         }
         // the caller's frame 0 has become the merged cloud (incremental_icp.hpp:40,64)
         if (!result) model.download(*clouds[0]);
-        else if (merged_frames) result->finish(*clouds[0]);
+        else if (merged_frames) { result->finish(*clouds[0]); note_finish(*result); }
         clock_mark();
         return clouds[0];
     }
@@ -248,6 +262,175 @@ class IncrementalICP : public RegistrationScheme {
         }
         return model;
     }
+};
+
+// A chain of frames registered as the INDEPENDENT consecutive pairs (k - 1, k), `in_flight` of them side by side on one GPU
+// (BASELINE configs[4]).  The reference's IncrementalICP (src/incremental_icp.hpp:51-66) is sequential by
+// definition -- frame k is aligned with everything merged before it; this class is the documented throughput restatement of that
+// loop: every pair is the same ICP (same parameters, incremental_icp.hpp:46-49, unless `params` is changed) between two raw
+// frames, and the pair transforms are composed on the host afterwards, T_0k = T_01 * ... * T_(k-1)k.
+//
+// Why side by side: one alignment leaves a third of the chip-time of every search launch to an emptying tail and ~6-11 us of
+// nothing between two dependent launches; kernels of OTHER alignments fill both.  Every pair runs on a context
+// of its own (stream, scratch, index, a queueing thread: a context is not thread-safe, different contexts are independent --
+// include/rsreg.h), reads the frames where the home context has put them (rsreg_cloud_device_ptr: any stream may read a
+// settled cloud), and gets exactly the bits it gets alone: nothing of an alignment depends on what else the GPU is doing.
+// More than three or four contexts stop paying: the streams of a process share a few hardware queues.
+class ChainRegistrar {
+  public:
+    explicit ChainRegistrar(size_t in_flight = 3, int device = 0) : device_(device)
+    {
+        rsreg_icp_params_reference(&params);
+        home_ = std::make_shared<Context>(device);
+        set_in_flight(in_flight);
+    }
+    // contexts are created once and keep their buffers from one registration() to the next
+    void set_in_flight(size_t k)
+    {
+        k = std::max<size_t>(1, k);
+        while (workers_.size() < k) workers_.push_back(std::make_shared<Context>(device_));
+        in_flight_ = k;
+    }
+    size_t in_flight() const { return in_flight_; }
+
+    rsreg_icp_params params;                    // of every pair (default: the reference's)
+    std::vector<Matrix4f> pair_transforms;      // [k]: frame k into frame k - 1 ([0]: identity)
+    std::vector<rsreg_icp_result> pair_results; // [k]: converged / state / iterations / n_correspondences of pair (k - 1, k)
+    std::vector<int> pair_context;              // [k]: which context registered pair k (engine extra, for traces)
+
+    // frames on the host in, T_0k (frame k into frame 0) out; guesses[k] (optional, one per frame, [0] unused): the initial
+    // guess of pair (k - 1, k), else the identity (incremental_icp.hpp:59).  A pair that did not converge contributes the
+    // transform ICP stopped at (the reference would skip the frame; `pair_results[k].converged` says so).
+    std::vector<Matrix4f> registration(const std::vector<rgb_point_cloud_pointer> &frames, const std::vector<Matrix4f> &guesses = {})
+    {
+        const size_t n = frames.size();
+        if (!guesses.empty() && guesses.size() != n) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: one guess per frame (the first is unused) or none");
+        while (dev_.size() < n) dev_.emplace_back(new rgb_device_cloud(home_));
+        for (size_t k = 0; k < n; ++k) dev_[k]->upload_deferred(*frames[k]);   // (the context's upload worker stages and sends them in this order)
+        std::vector<Shared> shared(n);
+        register_shared(shared, guesses, [&](size_t k) {
+            // settled = complete in HBM, waited for on the host: from here on any stream may read the records
+            shared[k].ptr = rsreg_cloud_device_ptr(dev_[k]->handle());
+            shared[k].n = frames[k]->size();
+            shared[k].dense = frames[k]->is_dense;
+            if (shared[k].n && !shared[k].ptr) throw Error(RSREG_ERR_HIP, "rsreg: a frame did not reach the device");
+        });
+        return compose();
+    }
+    // the same on frames already resident in HBM (clouds of ANY context of this device; they must stay unchanged until the call returns)
+    std::vector<Matrix4f> registration(const std::vector<const rgb_device_cloud *> &frames, const std::vector<Matrix4f> &guesses = {})
+    {
+        const size_t n = frames.size();
+        if (!guesses.empty() && guesses.size() != n) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: one guess per frame (the first is unused) or none");
+        std::vector<Shared> shared(n);
+        register_shared(shared, guesses, [&](size_t k) {
+            size_t m = 0;
+            uint32_t w = 0, h = 0;
+            bool dense = false;
+            frames[k]->info(m, w, h, dense);
+            shared[k].ptr = rsreg_cloud_device_ptr(frames[k]->handle());
+            shared[k].n = m;
+            shared[k].dense = dense;
+        });
+        return compose();
+    }
+
+  private:
+    struct Shared {
+        const void *ptr = nullptr;
+        size_t n = 0;
+        bool dense = true;
+    };
+    template <class Settle> void register_shared(std::vector<Shared> &shared, const std::vector<Matrix4f> &guesses, Settle settle)
+    {
+        const size_t n = shared.size();
+        pair_transforms.assign(n, Matrix4f::Identity());
+        pair_results.assign(n, rsreg_icp_result{});
+        pair_context.assign(n, -1);
+        if (n < 2) {
+            for (size_t k = 0; k < n; ++k) settle(k);
+            return;
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t ready = 0;            // frames [0, ready) are settled
+        bool failed = false;
+        std::atomic<size_t> next{1};
+        std::vector<std::string> errors(in_flight_);
+        auto work = [&](size_t w) {
+            rsreg_ctx *c = workers_[w]->get();
+            try {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= n) return;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return ready > k || failed; });
+                        if (failed) return;
+                    }
+                    // the source first, the reference's order (incremental_icp.hpp:57-58): it is put into the engine's order beside the target's index build
+                    check(rsreg_icp_set_source_device(c, shared[k].ptr, shared[k].n, sizeof(rgb_point), shared[k].dense), c);
+                    check(rsreg_icp_set_target_device(c, shared[k - 1].ptr, shared[k - 1].n, sizeof(rgb_point), shared[k - 1].dense,
+                                                      params.max_correspondence_distance), c);
+                    check(rsreg_icp_align(c, guesses.empty() ? nullptr : guesses[k].data(), &params, &pair_results[k], nullptr, 0), c);
+                    std::memcpy(pair_transforms[k].m, pair_results[k].transform, sizeof(pair_transforms[k].m));
+                    pair_context[k] = (int)w;
+                }
+            } catch (const std::exception &e) {
+                errors[w] = e.what();
+                std::lock_guard<std::mutex> lk(mu);
+                failed = true;
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t w = 1; w < in_flight_; ++w) th.emplace_back(work, w);
+        std::string home_error;
+        try {
+            for (size_t k = 0; k < n; ++k) {
+                settle(k);
+                std::lock_guard<std::mutex> lk(mu);
+                ready = k + 1;
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) {
+            home_error = e.what();
+            std::lock_guard<std::mutex> lk(mu);
+            failed = true;
+            cv.notify_all();
+        }
+        work(0);   // the caller's thread drives a context too
+        for (auto &t : th) t.join();
+        if (!home_error.empty()) throw Error(RSREG_ERR_HIP, home_error);
+        for (const std::string &e : errors)
+            if (!e.empty()) throw Error(RSREG_ERR_STATE, e);
+    }
+    // T_0k = T_0(k-1) * T_(k-1)k, accumulated in double (the pair transforms are float), rounded once per pose
+    std::vector<Matrix4f> compose() const
+    {
+        std::vector<Matrix4f> poses(pair_transforms.size(), Matrix4f::Identity());
+        double acc[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (size_t k = 1; k < pair_transforms.size(); ++k) {
+            double nxt[16];
+            for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 4; ++i) {
+                    double v = 0;
+                    for (int q = 0; q < 4; ++q) v += acc[q * 4 + i] * (double)pair_transforms[k].m[j * 4 + q];
+                    nxt[j * 4 + i] = v;
+                }
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = nxt[i];
+                poses[k].m[i] = (float)nxt[i];
+            }
+        }
+        return poses;
+    }
+
+    int device_;
+    size_t in_flight_ = 1;
+    std::shared_ptr<Context> home_;
+    std::vector<std::shared_ptr<Context>> workers_;
+    std::vector<std::unique_ptr<rgb_device_cloud>> dev_;
 };
 
 // Shared skeleton of the two edge-based schemes: a coarse aligner that takes an initial
@@ -410,7 +593,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         }
         say("[PCL] Done");
         auto out = std::make_shared<rgb_point_cloud>();
-        if (result) result->finish(*out);
+        if (result) { result->finish(*out); note_finish(*result); }
         else merged.download(*out);
         clock_mark();
         out->width = (uint32_t)out->size();   // `*merged = *merged + ...`: an unorganized cloud whatever came in

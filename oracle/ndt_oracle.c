@@ -413,6 +413,11 @@ int orc_ndt_derivatives(orc_ndt *o, const void *src, size_t n, size_t stride, in
 }
 
 /* More-Thuente helpers (ndt.hpp) */
+/* std::min(a, b) / std::max(a, b) as libstdc++ and libc++ define them (the FIRST operand unless the comparison says otherwise):
+ * fmin / fmax return the non-NaN operand, std::min(a, NaN) returns a and std::min(NaN, b) returns NaN -- what PCL's
+ * ndt.hpp (trialValueSelectionMT, computeStepLengthMT) does with a 0/0 trial value. */
+static double std_min(double a, double b) { return (b < a) ? b : a; }
+static double std_max(double a, double b) { return (a < b) ? b : a; }
 static double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
 static double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
 
@@ -452,8 +457,8 @@ static double trial_value_mt(double a_l, double f_l, double g_l, double a_u, dou
         double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
         double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
         double a_t_next = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
-        if (a_t > a_l) return fmin(a_t + 0.66 * (a_u - a_t), a_t_next);
-        return fmax(a_t + 0.66 * (a_u - a_t), a_t_next);
+        if (a_t > a_l) return std_min(a_t + 0.66 * (a_u - a_t), a_t_next);
+        return std_max(a_t + 0.66 * (a_u - a_t), a_t_next);
     } else {
         double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
         double w = sqrt(z * z - g_t * g_u);
@@ -492,8 +497,8 @@ static double step_length_mt(ndt_run *r, const double *x, double *step_dir, doub
     double g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
     int interval_converged = (step_max - step_min) < 0, open_interval = 1;
     double a_t = step_init;
-    a_t = fmin(a_t, step_max);
-    a_t = fmax(a_t, step_min);
+    a_t = std_min(a_t, step_max);
+    a_t = std_max(a_t, step_min);
     for (int i = 0; i < 6; i++) x_t[i] = x[i] + step_dir[i] * a_t;
     pose_to_matrix(x_t, r->final_t);
     transform_src(r->final_t, r->src, r->trans, r->n);
@@ -507,8 +512,8 @@ static double step_length_mt(ndt_run *r, const double *x, double *step_dir, doub
            !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
         if (open_interval) a_t = trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
         else a_t = trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = fmin(a_t, step_max);
-        a_t = fmax(a_t, step_min);
+        a_t = std_min(a_t, step_max);
+        a_t = std_max(a_t, step_min);
         for (int i = 0; i < 6; i++) x_t[i] = x[i] + step_dir[i] * a_t;
         pose_to_matrix(x_t, r->final_t);
         transform_src(r->final_t, r->src, r->trans, r->n);

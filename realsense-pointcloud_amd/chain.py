@@ -8,6 +8,9 @@ so they shard over ranks with no exchange on the data path -- and composes the p
 the host afterwards: T_0k = T_01 * T_12 * ... * T_(k-1)k.  That is a documented deviation from
 frame-to-model registration; the pair registrations themselves are the same ICP.
 """
+import ctypes as C
+import threading
+
 import numpy as np
 
 
@@ -45,3 +48,86 @@ def compose_chain(pairs, n_frames):
     for k in range(1, n_frames):
         out.append(out[-1] @ np.asarray(pairs[k], np.float64))
     return out
+
+
+class ChainRegistrar:
+    """Pairs (k-1, k) of frames resident in HBM, `in_flight` of them side by side on ONE GPU (the Python mirror of
+    rsreg::ChainRegistrar, include/rsreg/schemes.hpp).
+
+    One alignment leaves a third of the chip-time of every search launch to an emptying tail and a few microseconds of
+    nothing between two dependent launches; kernels of other alignments fill both.  Every pair in flight
+    runs on a context of its own (stream, scratch, index; a context is not thread-safe, different contexts are
+    independent: include/rsreg.h) driven by a thread of its own, and reads the frames where their owner has put them
+    (rsreg_cloud_device_ptr: a settled cloud may be read by any stream).  A pair gets the bits it gets alone.
+    The pairs are the same ICP as the reference's (src/incremental_icp.hpp:57-59); registering consecutive pairs
+    instead of frame-to-model is the documented restatement of configs[4] (module docstring)."""
+
+    def __init__(self, device=0, in_flight=3, params=None, contexts=None):
+        from . import api, lib
+        self._api, self._lib = api, lib
+        self.device = device
+        self.params = params if params is not None else api.icp_params(reference=True)
+        self.contexts = list(contexts) if contexts else []
+        self.in_flight = 0
+        self.set_in_flight(in_flight)
+        self.pair_context = {}
+
+    def set_in_flight(self, k):
+        k = max(1, int(k))
+        while len(self.contexts) < k:      # contexts are kept (with their buffers) from one call to the next
+            self.contexts.append(self._api.Context(self.device))
+        self.in_flight = k
+
+    @staticmethod
+    def share(cloud):
+        """(address, n, stride, is_dense) of a DeviceCloud's records, settled: complete in HBM, readable from any stream."""
+        n, stride, _w, _h, dense = cloud.info()
+        return (cloud.device_ptr, n, stride, dense)
+
+    def register(self, frames, ks, guesses=None, collect=None):
+        """frames: {k: DeviceCloud or share() tuple}; ks: the pairs (k-1, k) to register; guesses: {k: 4x4 column-major float32
+        as the ABI takes it} or None (identity, incremental_icp.hpp:59).  Returns {k: 4x4 numpy, frame k into frame k-1}.
+        collect (optional): callable(k, IcpResult, ctx) run on the worker's thread after every pair."""
+        L, lib, api = self._lib.lib(), self._lib, self._api
+        shared = {k: (f if isinstance(f, tuple) else self.share(f)) for k, f in frames.items()}
+        ks = list(ks)
+        out, errors = {}, []
+        it = iter(ks)
+        lock = threading.Lock()
+        prm = self.params
+
+        def work(w):
+            ctx = self.contexts[w]
+            res = lib.IcpResult()
+            try:
+                while True:
+                    with lock:
+                        k = next(it, None)
+                    if k is None or errors:
+                        return
+                    sp, sn, ss, sd = shared[k]
+                    tp, tn, ts, td = shared[k - 1]
+                    g = guesses[k] if guesses is not None else None
+                    # the source first, the reference's order: it is put into the engine's order beside the target's index build
+                    lib.check(L.rsreg_icp_set_source_device(ctx.h, C.c_void_p(sp), sn, ss, int(sd)), ctx.h)
+                    lib.check(L.rsreg_icp_set_target_device(ctx.h, C.c_void_p(tp), tn, ts, int(td), prm.max_correspondence_distance), ctx.h)
+                    lib.check(L.rsreg_icp_align(ctx.h, g.ctypes.data if g is not None else None, C.byref(prm), C.byref(res), None, 0), ctx.h)
+                    T = api._rowmajor(res.transform)
+                    if collect is not None:
+                        collect(k, res, ctx)
+                    with lock:
+                        out[k] = T
+                        self.pair_context[k] = w
+            except Exception as e:   # noqa: BLE001 -- handed to the caller's thread
+                errors.append(e)
+
+        n_workers = min(self.in_flight, max(1, len(ks)))
+        threads = [threading.Thread(target=work, args=(w,)) for w in range(1, n_workers)]
+        for t in threads:
+            t.start()
+        work(0)    # the caller's thread drives a context too
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return out

@@ -855,9 +855,11 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         // the tile schedule's arrays (items | wave costs | done counters | ...) lie at offsets that depend on the buffer's capacity
         // only, so that a schedule can be carried over to the next alignment (launch_fused); a new buffer starts from zero
         // (the done counters go back to zero by themselves) and without a schedule
+        // (a larger buffer can come back at the address of the one just freed: the capacity says whether it is a new one)
         void *before = ctx->d_sched.ptr;
+        const size_t cap_before = ctx->d_sched.cap;
         RSREG_HIP(ctx, ctx->d_sched.reserve((size_t)reduce_blocks(n) * 15 * 4 + 256));
-        if (ctx->d_sched.ptr != before) {
+        if (ctx->d_sched.ptr != before || ctx->d_sched.cap != cap_before) {
             RSREG_HIP(ctx, hipMemsetAsync(ctx->d_sched.ptr, 0, ctx->d_sched.cap, ctx->stream));
             ctx->sched_cap_tiles = (uint32_t)((ctx->d_sched.cap - 256) / (15 * 4));
             ctx->sched_keep_items = 0;
@@ -1353,6 +1355,7 @@ __global__ __launch_bounds__(1024) void k_sched_build_xcd(const uint32_t *cost, 
 int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles, bool first = false)
 {
     const SchedCfg cfg = sched_cfg();
+    if (n_tiles > ctx->sched_cap_tiles) return fail(ctx, RSREG_ERR_STATE, "tile schedule: more tiles than the schedule buffer was laid out for");
     const SchedBufs sb = sched_bufs(ctx, n_tiles);
     hipStream_t st = ctx->stream;
     uint32_t n4 = (uint32_t)(cfg.f4 * n_tiles), n2 = (uint32_t)(cfg.f2 * n_tiles);
@@ -1423,7 +1426,8 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
 #endif
             const SchedCfg cfg = sched_cfg();
             const uint32_t n_tiles = reduce_blocks(n);
-            const bool sched_ok = cfg.on && (!wt || light) && n_tiles >= cfg.min_tiles && n_tiles < (1u << 24);
+            const bool sched_ok = cfg.on && (!wt || light) && n_tiles >= cfg.min_tiles && n_tiles < (1u << 24) &&
+                                  n_tiles <= ctx->sched_cap_tiles;   // (the arrays of sched_bufs are laid out for that many tiles)
             TileSched sc{};
             sc.n_tiles = n_tiles;
             uint32_t grid = n_tiles;
@@ -1872,7 +1876,12 @@ int rsreg_icp_set_target(rsreg_ctx *ctx, const void *points, size_t n, size_t st
     if (!ctx || (n && !points) || stride < 12) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     rsreg_host_timing &ht = ctx->host_timing;
-    int rc = upload_packed(ctx, ctx->h_stage_tgt, ctx->ev_stage_tgt, ctx->d_tgt_raw, points, n, stride, ctx->stream, &ht.target_pack, &ht.target_stage_wait);
+    // a counting build that was queued and not waited for (build_dense) still reads d_tgt_raw on the main stream, and the
+    // upload stream is ordered behind nothing: a second set_target with no alignment in between would overwrite the records
+    // under k_cc_count / k_cc_scatter (a changed point re-derives another slot: a write past d_arrived).  Wait for it first.
+    int rc = target_counts(ctx, true);
+    if (rc) return rc;
+    rc = upload_packed(ctx, ctx->h_stage_tgt, ctx->ev_stage_tgt, ctx->d_tgt_raw, points, n, stride, ctx->stream, &ht.target_pack, &ht.target_stage_wait);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     rc = build_grid(ctx, ctx->d_tgt_raw.as<char>(), n, 12, max_correspondence_distance);   // (behind the upload, by the stream's order)

@@ -158,7 +158,8 @@ RSREG_HD inline double ndt_trial_value(double a_l, double f_l, double g_l, doubl
         const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
         const double a_next = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
         const double lim = a_t + 0.66 * (a_u - a_t);
-        return a_t > a_l ? (lim < a_next ? lim : a_next) : (lim > a_next ? lim : a_next);
+        // std::min(lim, a_next) / std::max(lim, a_next) in their operand order (NaN operands then select what PCL selects)
+        return a_t > a_l ? ((a_next < lim) ? a_next : lim) : ((lim < a_next) ? a_next : lim);
     }
     return ndt_cubic_min(a_u, f_u, g_u, a_t, f_t, g_t);  // case 4
 }
@@ -220,8 +221,8 @@ RSREG_HD inline void ndt_ls_begin(NdtLs &s, const double *x, double *dir, double
     s.f_u = ndt_psi_mt(s.a_u, s.phi_0, s.phi_0, d_phi_0, mu); s.g_u = ndt_dpsi_mt(d_phi_0, d_phi_0, mu);
     s.interval_converged = (step_max - step_min) < 0 ? 1 : 0;
     s.open_interval = 1;
-    const double a0 = step_init < step_max ? step_init : step_max;
-    s.a_t = a0 > step_min ? a0 : step_min;
+    const double a0 = (step_max < step_init) ? step_max : step_init;   // std::min(step_init, step_max)
+    s.a_t = (a0 < step_min) ? step_min : a0;                           // std::max(a_t, step_min)
     ndt_ls_set_trial(s);
     s.phase = kNdtLsFirst;
     s.next_mode = 0;
@@ -276,8 +277,8 @@ RSREG_HD inline void ndt_ls_consume(NdtLs &s, const double *sums)
     if (!s.interval_converged && s.step_iterations < max_step_iterations && !(s.psi_t <= 0 && s.d_phi_t <= -nu * s.d_phi_0)) {
         double a_t = s.open_interval ? ndt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.psi_t, s.d_psi_t)
                                      : ndt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.phi_t, s.d_phi_t);
-        a_t = a_t < s.step_max ? a_t : s.step_max;
-        a_t = a_t > s.step_min ? a_t : s.step_min;
+        a_t = (s.step_max < a_t) ? s.step_max : a_t;   // std::min(a_t, step_max)
+        a_t = (a_t < s.step_min) ? s.step_min : a_t;   // std::max(a_t, step_min)
         s.a_t = a_t;
         ndt_ls_set_trial(s);
         s.phase = kNdtLsTrial;

@@ -10,6 +10,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <string>
 
 namespace rsreg {
 
@@ -106,22 +109,73 @@ inline Tunables tunables_from_environment()
     return v;
 }
 
-inline Tunables &tunables_storage()
+// What the environment says about every switch above, as one string: two readings are compared by this, not by the bytes
+// of two structs (whose padding is indeterminate).
+inline std::string tunables_signature()
 {
-    static Tunables t = tunables_from_environment();
-    return t;
+    static const char *const names[] = {
+        "RSREG_CELL_CAP", "RSREG_DENSE_MAX_CELLS", "RSREG_FORCE_HASH", "RSREG_KEYS64", "RSREG_FULL_TABLE", "RSREG_FAR_ROWS", "RSREG_NO_WIDE_CELLS",
+        "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_ROCPRIM_SORT", "RSREG_SORT_SMALL",
+        "RSREG_PLAIN_SOURCE_MAX", "RSREG_MORTON_BITS", "RSREG_NO_WORKER", "RSREG_NO_SEED", "RSREG_RESTART_APART", "RSREG_NO_SCAN", "RSREG_SCHED",
+        "RSREG_SCHED_F4", "RSREG_SCHED_F2", "RSREG_SCHED_MIN_TILES", "RSREG_SCHED_AT", "RSREG_SCHED_XCD", "RSREG_SCHED_XCD_DEAL", "RSREG_SCHED_KEEP",
+        "RSREG_CLOUD_POOL_MB", "RSREG_UPLOAD_WAIT_STAGED", "RSREG_NDT_NO_WATCH", "RSREG_NDT_RESIDENT_LS", "RSREG_NDT_TWO_LAUNCHES",
+#ifdef RSREG_DIAG
+        "RSREG_DUMP_SEED", "RSREG_WAVE_TIMES", "RSREG_EDGE_DUMP", "RSREG_WAVE_TIMES_LIGHT", "RSREG_DUMP_NN_MS", "RSREG_SCHED_VERBOSE", "RSREG_GRID_STATS",
+        "RSREG_DEBUG_SKIP",
+#endif
+    };
+    std::string sig;
+    for (const char *n : names) {
+        const char *e = std::getenv(n);
+        sig += e ? e : "\x01";
+        sig += '\0';
+    }
+    return sig;
+}
+
+// The switches are published as a pointer to an immutable struct: a reader (a context's worker threads among them) holds a
+// reference to a complete set that never changes under it; a new reading is a new struct swapped in (the old ones stay
+// allocated: a few hundred bytes per change of the environment, which only A/B tools ever make).
+struct TunablesBox {
+    std::atomic<const Tunables *> cur{nullptr};
+    std::mutex mu;
+    std::string sig;
+};
+
+inline TunablesBox &tunables_box()
+{
+    static TunablesBox box;
+    return box;
 }
 
 // the switches as the environment had them when the process first asked -- or when a context was last created
-// (rsreg_ctx_create looks again, so that one process can compare settings context by context; nothing is written when the
-// environment has not changed, so contexts at work on other threads are not disturbed)
-inline const Tunables &tunables() { return tunables_storage(); }
+// (rsreg_ctx_create looks again, so that one process can compare settings run by run; nothing is published when the
+// environment has not changed.  A change applies to every context of the process from then on: set the environment
+// before the first context is created, or between runs -- not while contexts are at work)
+inline const Tunables &tunables()
+{
+    TunablesBox &b = tunables_box();
+    const Tunables *t = b.cur.load(std::memory_order_acquire);
+    if (t) return *t;
+    std::lock_guard<std::mutex> lk(b.mu);
+    t = b.cur.load(std::memory_order_relaxed);
+    if (!t) {
+        b.sig = tunables_signature();
+        t = new Tunables(tunables_from_environment());
+        b.cur.store(t, std::memory_order_release);
+    }
+    return *t;
+}
 
 inline void tunables_refresh()
 {
-    const Tunables now = tunables_from_environment();
-    Tunables &cur = tunables_storage();
-    if (std::memcmp(&now, &cur, sizeof(Tunables)) != 0) cur = now;
+    (void)tunables();
+    TunablesBox &b = tunables_box();
+    std::lock_guard<std::mutex> lk(b.mu);
+    std::string now = tunables_signature();
+    if (now == b.sig) return;
+    b.sig = std::move(now);
+    b.cur.store(new Tunables(tunables_from_environment()), std::memory_order_release);
 }
 
 }  // namespace rsreg

@@ -1,6 +1,9 @@
 // scheme_runner — drives the C++ host layer (include/rsreg/*.hpp) from the command line so
 // that the Python GPU tests can compare it with the ctypes path and the CPU checker.
-//   scheme_runner <incremental|icp_edge|ndt_edge|icp_pair|ndt_pair> <out_prefix> <a.pcd> <b.pcd> [...]
+//   scheme_runner <incremental|icp_edge|ndt_edge|icp_pair|ndt_pair|chain> <out_prefix> <a.pcd> <b.pcd> [...]
+// chain: ChainRegistrar (consecutive pairs, RSREG_CHAIN_IN_FLIGHT=<K> of them side by side, default 3; RSREG_CHAIN_ITERATIONS=<n>:
+// n fixed iterations at a 5 cm gate in the device-resident loop -- the bench's parameters -- instead of the reference's); the .txt
+// holds every pair's `converged iterations context` line and 4x4, then the composed poses; no .pcd.
 // Writes <out_prefix>.pcd (merged / aligned cloud) and <out_prefix>.txt (4x4 transforms, row-major).
 #include <chrono>
 #include <cstdio>
@@ -40,6 +43,16 @@ int main(int argc, char **argv)
         // RSREG_SCHEME_NO_STREAM=1: the merged cloud is built on the GPU and downloaded once at the end instead of being
         // streamed to the host frame by frame (schemes.hpp `stream_result`)
         const bool stream = !(std::getenv("RSREG_SCHEME_NO_STREAM") && std::getenv("RSREG_SCHEME_NO_STREAM")[0] == '1');
+        const size_t chain_in_flight = std::getenv("RSREG_CHAIN_IN_FLIGHT") ? (size_t)std::atoi(std::getenv("RSREG_CHAIN_IN_FLIGHT")) : 3;
+        const int chain_iterations = std::getenv("RSREG_CHAIN_ITERATIONS") ? std::atoi(std::getenv("RSREG_CHAIN_ITERATIONS")) : 0;
+        auto chain_parameters = [&](ChainRegistrar &c) {
+            if (chain_iterations <= 0) return;   // (the reference's: incremental_icp.hpp:46-49)
+            c.params.max_iterations = chain_iterations;
+            c.params.criteria_mode = RSREG_CRITERIA_FIXED;
+            c.params.pipeline_mode = RSREG_PIPELINE_DEVICE_LOOP;
+            c.params.max_correspondence_distance = 0.05;
+        };
+        std::unique_ptr<ChainRegistrar> chain;
         for (int rep = 0; rep < timed_reps; ++rep) {
             std::vector<rgb_point_cloud_pointer> fresh;
             for (auto &c : clouds) fresh.push_back(std::make_shared<rgb_point_cloud>(*c));
@@ -73,6 +86,14 @@ int main(int argc, char **argv)
                 kept = s.registration(fresh);
                 stop();
                 frame_clock = s.frame_clock_ms;
+            } else if (mode == "chain") {
+                // (the registrar lives across the repetitions, like a long-running caller's: run 0 pays for its contexts)
+                if (!chain) chain.reset(new ChainRegistrar(chain_in_flight));
+                chain_parameters(*chain);
+                const auto poses = chain->registration(fresh);
+                stop();
+                std::fprintf(stderr, "chain run %d: %.3f ms per pair, %zu pairs, %zu in flight\n", rep, ms / std::max<size_t>(1, poses.size() - 1), poses.size() - 1,
+                             chain->in_flight());
             }
             const double ms_scheme_gone = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             merged = kept ? kept->size() : 0;
@@ -123,6 +144,15 @@ int main(int argc, char **argv)
                 out = s.registration(clouds);
                 for (auto &p : s.frame_transforms) { dump(f, p.first); dump(f, p.second); }
             }
+        } else if (mode == "chain") {
+            if (!chain) chain.reset(new ChainRegistrar(chain_in_flight));
+            chain_parameters(*chain);
+            const auto poses = chain->registration(clouds);
+            for (size_t k = 1; k < poses.size(); ++k) {
+                std::fprintf(f, "%d %d %d\n", (int)chain->pair_results[k].converged, chain->pair_results[k].iterations, chain->pair_context[k]);
+                dump(f, chain->pair_transforms[k]);
+            }
+            for (size_t k = 0; k < poses.size(); ++k) dump(f, poses[k]);
         } else if (mode == "icp_pair") {   // incremental_icp.hpp:57-63 on one pair, reference parameters
             IterativeClosestPoint<rgb_point, rgb_point> icp;
             detail::reference_icp_parameters(icp);
@@ -149,7 +179,7 @@ int main(int argc, char **argv)
             return 2;
         }
         std::fclose(f);
-        io::savePCDFileBinary(prefix + ".pcd", *out);
+        if (out) io::savePCDFileBinary(prefix + ".pcd", *out);
     } catch (const Error &e) {
         std::fprintf(stderr, "rsreg error %d: %s\n", e.status, e.what());
         return e.status == RSREG_ERR_NO_DEVICE ? 66 : 1;

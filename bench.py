@@ -538,9 +538,21 @@ def main():
                 # the numbers that bind first, the VALU figure (an upper bound of the VALU time over the WHOLE launch: see
                 # valu_frac_while_full_upper_bound) under a name that says so
                 ri = out["roofline_issue"]
+                # The denominator that has a meaning for this kernel (no single-resource roofline binds a search of
+                # dependent gathers): a SCHEDULE bound -- the full phase at the address units' floor (every vector-memory wave-
+                # instruction at its 16-clock minimum over 256 CUs: vmem_bound_us) plus one light wave's chain of dependent round
+                # trips on an EMPTY machine as the last job (12 us: the whole 50 k launch is 31 us, profiles/r05_launch_times.txt).
+                light_wave_us = 12.0
+                ri["schedule_bound_us"] = t["vmem_bound_us"] + light_wave_us
+                ri["frac_of_schedule_bound"] = ri["schedule_bound_us"] / (avg_ms * 1e3) if avg_ms > 0 else None
+                ri["schedule_bound_terms"] = {"full_phase_at_address_unit_floor_us": t["vmem_bound_us"], "last_light_wave_alone_us": light_wave_us,
+                                              "measured_full_phase_us": w["sum_wave_time_us"] / w["slots"],
+                                              "note": "frac_of_schedule_bound = schedule_bound_us / avg_launch_us: 1.0 would be a launch whose full phase "
+                                                      "runs at the vector-memory issue floor and whose tail is one light wave"}
                 ri["valu_bound_over_launch_upper_bound"] = ri.pop("frac")
                 ri["bound"] = "vector memory issue while the wave slots are full, then an emptying tail (the VALU figure is an upper bound)"
-                lead = ("bound", "kernel", "vmem_frac_while_full", "tail_fraction", "avg_launch_us", "vmem_bound_us", "vmem_frac")
+                lead = ("bound", "kernel", "schedule_bound_us", "frac_of_schedule_bound", "vmem_frac_while_full", "tail_fraction", "avg_launch_us",
+                        "vmem_bound_us", "vmem_frac")
                 out["roofline_issue"] = {**{k: ri[k] for k in lead if k in ri}, **{k: v for k, v in ri.items() if k not in lead}}
             out["roofline"]["binding"] = "not HBM (the working set lives in the Infinity Cache): see roofline_issue (the contract's roofline stays the HBM one)"
     except Exception:  # noqa: BLE001

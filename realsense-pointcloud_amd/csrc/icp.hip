@@ -7,8 +7,6 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
-
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -21,17 +19,11 @@
 #include "icp_kernels.hpp"
 #include "icp_dense.hpp"
 #include "cellsort.hpp"
-#include "sort_cfg.hpp"
+#include "oscan.hpp"
 
 using namespace rsreg;
 
 namespace {
-
-// rocPRIM sorts up to 2^20 items by merge sort whatever the bit range asked for; the keys here have ~40
-// significant bits, and from ~10^5 items on the onesweep radix sort is the faster one (same result: both are stable)
-using RadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
-template <typename KeyT> struct RadixCfgOf { using type = RadixCfg; };
-template <> struct RadixCfgOf<uint32_t> { using type = RadixCfg32; };
 
 inline uint32_t reduce_blocks(size_t n) { return (uint32_t)std::max<size_t>((n + kTile - 1) / kTile, 1); }  // depends on n only
 
@@ -215,38 +207,32 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     if (!gp.table_sparse) RSREG_HIP(ctx, hipMemsetAsync(table, 0, (total + 2) * 4 * 2, st));
     else if (!occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(table + (total + 2), 0, (total + 2) * 4, st));
     const unsigned end_bit = (unsigned)std::min<int>((int)sizeof(KeyT) * 8, (int)xbits + id_bits);
-    size_t sort_bytes = 0, scan_bytes = 0, tscan_bytes = 0;
-    using SortCfg = typename RadixCfgOf<KeyT>::type;
-    // 32-bit keys, enough of them for the radix path: the onesweep passes driven by this library, their state cleared by the
-    // keys kernel instead of nine memsets (radix32.hpp); otherwise rocPRIM's own driver
-    const bool own_sort = sizeof(KeyT) == 4 && radix32_pays(n, end_bit);
-    const Radix32Plan plan = radix32_plan(n, 0, end_bit);
+    // the library's own radix sort (osort.hpp; 32- and 64-bit keys alike since round 6), its state cleared by the keys kernel on
+    // its way instead of by memsets
+    const Radix32Plan plan = radix32_plan<KeyT>(n, 0, end_bit);
     // ... and then flag, scan and scatter are one launch too (compact.hpp), its look-back words cleared with the sort's state
     const bool scan_apart = tunables().scan_apart;
-    const bool one_tail = own_sort && !scan_apart && nfin < 0x7fffffffu;
+    const bool one_tail = !scan_apart && nfin < 0x7fffffffu;
     const CompactPlan cplan = compact_plan(nfin, plan.words);
     const uint32_t scratch_words = one_tail ? cplan.end : plan.words;
-    if (own_sort) sort_bytes = (size_t)scratch_words * 4;
-    else RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, std::max(scan_bytes, tscan_bytes)) + 256));
+    const size_t sort_bytes = (size_t)scratch_words * 4;
+    const size_t scan_bytes = oscan_scratch_bytes<unsigned long long>(nfin), tscan_bytes = oscan_scratch_bytes<uint32_t>(total + 1);
+    // (the sort's state, then -- on the paths that scan apart -- the scans' sums behind it)
+    const size_t off_scan = (sort_bytes + 255) & ~(size_t)255;
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(off_scan + std::max(scan_bytes, tscan_bytes) + 256));
+    char *scan_scratch = ctx->d_tmp.as<char>() + off_scan;
     // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
-    const bool start_in_out = own_sort && plan.ends_in_first;
+    const bool start_in_out = plan.ends_in_first;
     k_dense_keys<KeyT><<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, xbits, start_in_out ? keys2 : keys,
-                                                                       start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
-                                                                       own_sort ? scratch_words : 0u, occ_on_the_way ? table + (total + 2) : nullptr,
+                                                                       start_in_out ? vals2 : vals, ctx->d_tmp.as<uint32_t>(), scratch_words,
+                                                                       occ_on_the_way ? table + (total + 2) : nullptr,
                                                                        occ_on_the_way ? (uint32_t)(total + 2) : 0u);
     RSREG_HIP(ctx, hipGetLastError());
-    if (own_sort) {
-        if constexpr (sizeof(KeyT) == 4) {
-            bool in_first = false;
-            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
-                                              start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, end_bit, st, &in_first));
-            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
-        }
-    } else {
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs<SortCfg>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, end_bit, st));
+    {
+        bool in_first = false;
+        RSREG_HIP(ctx, radix32_sort_pairs<KeyT>(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                                start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, end_bit, st, &in_first));
+        if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
     }
     const uint32_t nbf = div_up(nfin, kBlock);
     if (one_tail) {
@@ -259,7 +245,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
     } else {
         k_dense_flag<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags);
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, flags, scan, 0ull, (size_t)nfin, rocprim::plus<unsigned long long>(), st));
+        RSREG_HIP(ctx, (oscan<unsigned long long>(flags, scan, (size_t)nfin, 0ull, scan_scratch, st)));
         k_dense_scatter<KeyT><<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, xbits, flags, scan, ctx->d_tgt_sorted.as<float4>(),
                                                       ctx->d_pos_of.as<uint32_t>(), cellslot, cellpos, d_misc + 8, h_misc + 8,
                                                       gp.table_sparse ? table : nullptr);
@@ -269,7 +255,7 @@ int build_dense_keyed(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride
         k_dense_counts<<<nbf, kBlock, 0, st>>>(cellslot, cellpos, d_misc + 8, table);
         RSREG_HIP(ctx, hipGetLastError());
         // counts -> first sorted point of every cell (in place), entry [total] = number of points
-        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, tscan_bytes, table, table, 0u, total + 1, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, (oscan<uint32_t>(table, table, total + 1, 0u, scan_scratch, st)));
     }
     // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
     k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, d_misc + 8, g.sx, g.sxy, table + (total + 2));
@@ -547,20 +533,25 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
     k_cell_keys<<<nb, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, keys, vals);
     RSREG_HIP(ctx, hipGetLastError());
-    size_t tmp_bytes = 0;
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
-    size_t scan_bytes = 0;
+    // the library's own radix sort over all 64 key bits (osort.hpp), its state cleared by a memset in front; then three scans (oscan.hpp)
     uint32_t *keep = ctx->d_flags.as<uint32_t>(), *cstart = keep + n, *bstart = cstart + n;
     uint32_t *pos = ctx->d_scan.as<uint32_t>(), *cid = pos + n, *bid = cid + n;
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
-    RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 64, st));
+    const size_t sort_bytes = (size_t)osort_plan<unsigned long long>(n, 0, 64).words * 4, scan_bytes = oscan_scratch_bytes<uint32_t>(nfin);
+    RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
+    {
+        bool in_first = false;
+        RSREG_HIP(ctx, osort_pairs_cleared<unsigned long long>(ctx->d_tmp.as<uint32_t>(), keys, keys2, vals, vals2, n, 0, 64, st, &in_first));
+        if (in_first) {   // (keys2 / vals2 below: the sorted pairs, wherever the passes have left them)
+            std::swap(keys, keys2);
+            std::swap(vals, vals2);
+        }
+    }
     const uint32_t nbf = div_up(nfin, kBlock);
     k_flag_runs<<<nbf, kBlock, 0, st>>>(keys2, vals2, d_pts, stride, nfin, keep, cstart, bstart);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, keep, pos, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, cstart, cid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, bstart, bid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, (oscan<uint32_t>(keep, pos, (size_t)nfin, 0u, ctx->d_tmp.ptr, st)));
+    RSREG_HIP(ctx, (oscan<uint32_t>(cstart, cid, (size_t)nfin, 0u, ctx->d_tmp.ptr, st)));
+    RSREG_HIP(ctx, (oscan<uint32_t>(bstart, bid, (size_t)nfin, 0u, ctx->d_tmp.ptr, st)));
     // brick staging arrays: key[nfin+1] u64 | mask[nfin+1] u64 | base[nfin+1] u32
     auto *brickkey = ctx->d_brick.as<unsigned long long>();
     auto *brickmask = brickkey + (nfin + 1);
@@ -748,19 +739,20 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
         uint32_t *perm = ctx->d_perm.as<uint32_t>();
         uint32_t *keep = ctx->d_sflags.as<uint32_t>(), *pos = ctx->d_sscan.as<uint32_t>();
         const uint32_t nb = div_up((uint32_t)n, kBlock);
-        size_t sort_bytes = 0, scan_bytes = 0;
-        RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+        size_t sort_bytes = 0;
+        // (the sort's state at the head of d_stmp, the scan's sums behind it: the scan starts when the sort is done, but its
+        // launches are queued before that)
+        const size_t scan_bytes = oscan_scratch_bytes<uint32_t>(n);
         if (narrow) {
             auto *keys = ctx->d_skeys.as<uint32_t>();
             auto *keys2 = ctx->d_skeys_alt.as<uint32_t>();
             const unsigned sort_bits = (unsigned)(mb.x + mb.y + mb.z) + 1u;
-            const bool own_sort = radix32_pays(n, sort_bits);   // (radix32.hpp: the sort's state is cleared by the keys kernel, no memsets)
+            constexpr bool own_sort = true;   // (osort.hpp: the sort's state is cleared by the keys kernel, no memsets)
             const Radix32Plan plan = radix32_plan(n, 0, sort_bits);
-            if (own_sort) sort_bytes = (size_t)plan.words * 4;
-            else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            sort_bytes = (size_t)plan.words * 4;
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
             // (an even number of passes ends in the pair it started from: the keys are then written where the result belongs)
-            const bool start_in_out = own_sort && plan.ends_in_first;
+            const bool start_in_out = plan.ends_in_first;
             uint32_t *keys_a = start_in_out ? keys2 : keys, *vals_a = start_in_out ? perm : vals;
             uint32_t *keys_b = start_in_out ? keys : keys2, *vals_b = start_in_out ? vals : perm;
             // the library's own sort over more than one workgroup's worth of pairs: its digit histograms are counted by the keys
@@ -769,7 +761,7 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             const bool hist_on_the_way = own_sort && n > kOsTile;
             uint32_t *hist_now = nullptr;
             if (hist_on_the_way) {
-                constexpr size_t set = kOsMaxPasses * kOsDigits;
+                constexpr size_t set = OsKey<uint32_t>::max_passes * kOsDigits;
                 const bool fresh = !ctx->d_shist.ptr;
                 RSREG_HIP(ctx, ctx->d_shist.reserve(2 * set * 4));
                 if (fresh || ctx->shist_dirty) RSREG_HIP(ctx, hipMemsetAsync(ctx->d_shist.ptr, 0, 2 * set * 4, st));
@@ -785,12 +777,10 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
                                                                own_sort ? ctx->d_stmp.as<uint32_t>() : nullptr, own_sort ? plan.words : 0u);
             }
             RSREG_HIP(ctx, hipGetLastError());
-            if (own_sort) {
+            {
                 bool in_first = false;
-                RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_stmp.as<uint32_t>(), keys_a, keys_b, vals_a, vals_b, n, 0, sort_bits, st, &in_first, hist_now));
-                if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
-            } else {
-                RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+                RSREG_HIP(ctx, radix32_sort_pairs<uint32_t>(plan, ctx->d_stmp.as<uint32_t>(), keys_a, keys_b, vals_a, vals_b, n, 0, sort_bits, st, &in_first, hist_now));
+                if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
             }
             k_gather_source<uint32_t><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
             RSREG_HIP(ctx, hipGetLastError());
@@ -800,15 +790,23 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             // the sort only has to look at the bits the Morton codes of this extent can set (+ the invalid bit)
             const int axis_bits = axis_bits_of(extent, (double)cell);
             const unsigned sort_bits = 3u * (unsigned)axis_bits + 1u;
-            k_source_keys<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), mb, keys, vals, nullptr, 0u);
-            RSREG_HIP(ctx, hipGetLastError());
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(nullptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            const Radix32Plan plan = radix32_plan<unsigned long long>(n, 0, sort_bits);
+            sort_bytes = (size_t)plan.words * 4;
             RSREG_HIP(ctx, ctx->d_stmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg>(ctx->d_stmp.ptr, sort_bytes, keys, keys2, vals, perm, n, 0, sort_bits, st));
+            const bool start_in_out = plan.ends_in_first;   // (as above: the sorted pairs must end in (keys2, perm))
+            k_source_keys<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, 1ull << (3 * axis_bits), mb,
+                                                                     start_in_out ? keys2 : keys, start_in_out ? perm : vals, ctx->d_stmp.as<uint32_t>(), plan.words);
+            RSREG_HIP(ctx, hipGetLastError());
+            {
+                bool in_first = false;
+                RSREG_HIP(ctx, radix32_sort_pairs<unsigned long long>(plan, ctx->d_stmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                                                      start_in_out ? perm : vals, start_in_out ? vals : perm, n, 0, sort_bits, st, &in_first));
+                if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
+            }
             k_gather_source<unsigned long long><<<nb, kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, perm, ctx->d_src_all.as<float4>(), nullptr, keys2, keep);
             RSREG_HIP(ctx, hipGetLastError());
         }
-        RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_stmp.ptr, scan_bytes, keep, pos, 0u, n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, (oscan<uint32_t>(keep, pos, n, 0u, ctx->d_stmp.ptr, st)));
         k_source_unique<<<nb, kBlock, 0, st>>>(ctx->d_src_all.as<float4>(), (uint32_t)n, keep, pos, ctx->d_first.as<uint32_t>(),
                                                ctx->d_uniq_of.as<uint32_t>(), d_misc + 12, h_misc + 32,   // the number of distinct points: read at the join
                                                ctx->d_src.as<float4>());
@@ -1037,30 +1035,23 @@ int apply_filters(rsreg_ctx *ctx)
         uint32_t *ws = ctx->d_vals.as<uint32_t>(), *cum = ctx->d_vals_alt.as<uint32_t>();
         // (the distances' sort: the library's own, four digit passes that end in the pair they start from -- the keys are
         // written into the pair that makes that (keys2, order); its state is cleared by the keys kernel on its way)
-        size_t sort_bytes = 0, scan_bytes = 0;
-        const bool own_sort = radix32_pays(n, 32);
         const Radix32Plan plan = radix32_plan(n, 0, 32);
-        if (own_sort) sort_bytes = (size_t)plan.words * 4;
-        else RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));
-        RSREG_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
+        const size_t sort_bytes = (size_t)plan.words * 4, scan_bytes = oscan_scratch_bytes<uint32_t>(n);
         const size_t off_scan = (sort_bytes + 255) & ~(size_t)255;
         RSREG_HIP(ctx, ctx->d_tmp.reserve(off_scan + scan_bytes + 256));
         char *tmp = ctx->d_tmp.as<char>();
-        uint32_t *k_a = own_sort && plan.ends_in_first ? keys2 : keys, *v_a = own_sort && plan.ends_in_first ? order : vals;
+        uint32_t *k_a = plan.ends_in_first ? keys2 : keys, *v_a = plan.ends_in_first ? order : vals;
         uint32_t *k_b = k_a == keys ? keys2 : keys, *v_b = v_a == vals ? order : vals;
-        k_trim_keys<<<nb, kBlock, 0, st>>>(cw, ctx->d_corr_d2.as<float>(), n, k_a, v_a, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
-                                           own_sort ? plan.words : 0u);
+        k_trim_keys<<<nb, kBlock, 0, st>>>(cw, ctx->d_corr_d2.as<float>(), n, k_a, v_a, ctx->d_tmp.as<uint32_t>(), plan.words);
         RSREG_HIP(ctx, hipGetLastError());
-        if (own_sort) {
+        {
             bool in_first = false;
-            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 32, st, &in_first));   // stable: ties by position
-            if ((in_first ? v_a : v_b) != order) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
-        } else {
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp, sort_bytes, keys, keys2, vals, order, n, 0, 32, st));   // stable: ties by position
+            RSREG_HIP(ctx, radix32_sort_pairs<uint32_t>(plan, ctx->d_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 32, st, &in_first));   // stable: ties by position
+            if ((in_first ? v_a : v_b) != order) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
         }
         k_trim_gather<<<nb, kBlock, 0, st>>>(cw, order, n, ws);
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::inclusive_scan(tmp + off_scan, scan_bytes, ws, cum, (size_t)n, rocprim::plus<uint32_t>(), st));
+        RSREG_HIP(ctx, (oscan<uint32_t, true>(ws, cum, (size_t)n, 0u, tmp + off_scan, st)));
         k_trim_apply<<<nb, kBlock, 0, st>>>(order, ws, cum, n, (float)s.prm.trim_overlap_ratio, cw, corr_pos);
         RSREG_HIP(ctx, hipGetLastError());
     }

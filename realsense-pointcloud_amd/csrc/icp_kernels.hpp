@@ -27,7 +27,7 @@
 
 #include "rsreg_ctx.hpp"
 #include "records.hpp"
-#include "radix32.hpp"
+#include "osort.hpp"
 #include "compact.hpp"
 
 namespace rsreg {
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(kOsHistBlock) void k_source_keys_hist(const char *r
                                                                    uint32_t sort_scratch_words, uint32_t end_bit, uint32_t passes, uint32_t *hist,
                                                                    uint32_t *hist_next)
 {
-    __shared__ uint32_t s_h[kOsMaxPasses * kOsDigits];
+    __shared__ uint32_t s_h[OsKey<uint32_t>::max_passes * kOsDigits];
     const uint32_t t = blockIdx.x * kOsHistBlock + threadIdx.x, threads = gridDim.x * kOsHistBlock;
     radix32_clear(sort_scratch, sort_scratch_words, t, threads);   // (look-back words and tickets of the passes: nobody reads them before this kernel is done)
-    for (uint32_t k = t; k < kOsMaxPasses * kOsDigits; k += threads) hist_next[k] = 0u;
+    for (uint32_t k = t; k < OsKey<uint32_t>::max_passes * kOsDigits; k += threads) hist_next[k] = 0u;
     for (uint32_t k = threadIdx.x; k < passes * kOsDigits; k += kOsHistBlock) s_h[k] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * kOsHistBlock * kSkItems;
@@ -954,11 +954,53 @@ __global__ void k_icp_solve(const double *sums, IcpDevState *st)
 
 // k_final_reduce and k_icp_solve in one launch (single-GPU device loop): the block that finishes
 // last has all 17 sums in front of it and runs the solve; `ticket` returns to 0 for the next launch
+//
+// What the solve reads of the state the previous launch left -- the stop flag, the V its Jacobi iteration starts from, the
+// composed transform, the iteration count -- is requested by thread 0 of EVERY block before the reduce (28 loads that are on
+// their way while the partials are added): the last block's solve then starts from registers instead of two more
+// dependent round trips behind the ticket.  (Written by the previous launch of this kernel: visible at the kernel boundary.)
+struct IcpSolvePrefetch {
+    int stopped, iterations;
+    Mat4f final_t;
+    double svd_v[9];
+};
+
+__device__ __forceinline__ void icp_solve_step_prefetched(const double *sums, IcpDevState *st, IcpSolvePrefetch &pf)
+{
+    if (pf.stopped) return;
+    double s[RSREG_NUM_SUMS];
+#pragma unroll
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) st->sums_last[k] = s[k] = sums[k];
+    st->ncorr = (unsigned long long)(s[0] + 0.5);
+    if ((unsigned long long)(s[0] + 0.5) < 3) {
+        st->stopped = 1;
+        st->apply = 0;
+        return;
+    }
+    Mat4f t;
+    umeyama_from_sums(s, t, pf.svd_v);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st->svd_v[i] = pf.svd_v[i];
+    st->t_inc = to_mat34(t);
+    st->apply = 1;
+    st->final_t = mul(t, pf.final_t);
+    st->iterations = pf.iterations + 1;
+    st->cur_mse = s[16] / s[0];
+}
+
 __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *partials, uint32_t nblocks, double *sums,
                                                                IcpDevState *st, unsigned int *ticket)
 {
     __shared__ double shf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    IcpSolvePrefetch pf;
+    if (threadIdx.x == 0) {
+        pf.stopped = st->stopped;
+        pf.iterations = st->iterations;
+        pf.final_t = st->final_t;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pf.svd_v[i] = st->svd_v[i];
+    }
     const double *src = partials + (size_t)blockIdx.x * nblocks;
     double v = strided_sum(src, nblocks);
     v = wave_sum(v);
@@ -975,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
             double all[RSREG_NUM_SUMS];
             for (int k = 0; k < RSREG_NUM_SUMS; ++k) all[k] = __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *ticket = 0;
-            icp_solve_step(all, st);
+            icp_solve_step_prefetched(all, st, pf);
         }
     }
 }

@@ -8,14 +8,13 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 
 #include "ndt_kernels.hpp"
-#include "sort_cfg.hpp"
+#include "oscan.hpp"
 
 using namespace rsreg;
 
@@ -442,8 +441,8 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     auto *vals = ctx->d_vals.as<uint32_t>();
     auto *vals2 = ctx->d_vals_alt.as<uint32_t>();
     uint32_t *start = ctx->d_flags.as<uint32_t>(), *sid = ctx->d_scan.as<uint32_t>(), *seg_begin = ctx->d_ndt_seg.as<uint32_t>();
-    size_t sort_bytes = 0, scan_bytes = 0;
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    size_t sort_bytes = 0;
+    const size_t scan_bytes = oscan_scratch_bytes<uint32_t>(nfin);
     // the leaf keys are < div0 * div1 * div2 (a few dozen leaves at the reference's 1 m resolution) and the key of a
     // non-finite point is that product itself: the sort looks at those bits only -- one or two radix passes where all
     // 64 bits of the key type were ten merge passes (23 launches) for a grown edge target of 5 x 10^5 points
@@ -453,39 +452,42 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     if (n_leaves < 0x7fffffffull) {
         auto *keys = ctx->d_keys.as<uint32_t>();
         auto *keys2 = ctx->d_keys_alt.as<uint32_t>();
-        // (the onesweep passes driven by this library, their state cleared by the keys kernel: radix32.hpp)
-        const bool own_sort = radix32_pays(n, key_bits);
+        // (the library's own radix sort, its state cleared by the keys kernel: osort.hpp)
         const Radix32Plan plan = radix32_plan(n, 0, key_bits);
-        if (own_sort) sort_bytes = (size_t)plan.words * 4;
-        else RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        sort_bytes = (size_t)plan.words * 4;
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        const bool start_in_out = own_sort && plan.ends_in_first;   // (an even number of passes ends in the pair it started from)
+        const bool start_in_out = plan.ends_in_first;   // (an even number of passes ends in the pair it started from)
         k_ndt_keys<uint32_t><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, (uint32_t)n_leaves, start_in_out ? keys2 : keys,
-                                                                                 start_in_out ? vals2 : vals, own_sort ? ctx->d_tmp.as<uint32_t>() : nullptr,
-                                                                                 own_sort ? plan.words : 0u);
+                                                                                 start_in_out ? vals2 : vals, ctx->d_tmp.as<uint32_t>(), plan.words);
         RSREG_HIP(ctx, hipGetLastError());
-        if (own_sort) {
+        {
             bool in_first = false;
-            RSREG_HIP(ctx, radix32_sort_pairs(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
-                                              start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, key_bits, st, &in_first));
-            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
-        } else {
-            RSREG_HIP(ctx, rocprim::radix_sort_pairs<RadixCfg32>(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+            RSREG_HIP(ctx, radix32_sort_pairs<uint32_t>(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                                        start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, key_bits, st, &in_first));
+            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
         }
         k_ndt_flag_starts<uint32_t><<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
         RSREG_HIP(ctx, hipGetLastError());
     } else {
         auto *keys = ctx->d_keys.as<unsigned long long>();
         auto *keys2 = ctx->d_keys_alt.as<unsigned long long>();
-        k_ndt_keys<unsigned long long><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, n_leaves, keys, vals, nullptr, 0u);
-        RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        const Radix32Plan plan = radix32_plan<unsigned long long>(n, 0, key_bits);
+        sort_bytes = (size_t)plan.words * 4;
         RSREG_HIP(ctx, ctx->d_tmp.reserve(std::max(sort_bytes, scan_bytes) + 256));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_tmp.ptr, sort_bytes, keys, keys2, vals, vals2, n, 0, key_bits, st));
+        const bool start_in_out = plan.ends_in_first;
+        k_ndt_keys<unsigned long long><<<div_up((uint32_t)n, kNdtBlock), kNdtBlock, 0, st>>>(d_pts, pstride, (uint32_t)n, bp, n_leaves, start_in_out ? keys2 : keys,
+                                                                                           start_in_out ? vals2 : vals, ctx->d_tmp.as<uint32_t>(), plan.words);
+        RSREG_HIP(ctx, hipGetLastError());
+        {
+            bool in_first = false;
+            RSREG_HIP(ctx, radix32_sort_pairs<unsigned long long>(plan, ctx->d_tmp.as<uint32_t>(), start_in_out ? keys2 : keys, start_in_out ? keys : keys2,
+                                                                  start_in_out ? vals2 : vals, start_in_out ? vals : vals2, n, 0, key_bits, st, &in_first));
+            if (in_first != start_in_out) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
+        }
         k_ndt_flag_starts<unsigned long long><<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(keys2, nfin, start);
         RSREG_HIP(ctx, hipGetLastError());
     }
-    RSREG_HIP(ctx, rocprim::exclusive_scan(ctx->d_tmp.ptr, scan_bytes, start, sid, 0u, (size_t)nfin, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, (oscan<uint32_t>(start, sid, (size_t)nfin, 0u, ctx->d_tmp.ptr, st)));
     k_ndt_seg_offsets<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(start, sid, nfin, seg_begin, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));

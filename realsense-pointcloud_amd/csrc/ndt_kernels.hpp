@@ -13,7 +13,7 @@
 
 #include <cfloat>
 
-#include "radix32.hpp"
+#include "osort.hpp"
 #include <cstdint>
 
 #include "records.hpp"

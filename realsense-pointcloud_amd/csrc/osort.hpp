@@ -1,5 +1,7 @@
-// osort.hpp — this library's own radix sort of (uint32 key, uint32 value) pairs: least significant digit first, 8 bits a
-// pass, stable, one sweep over the data per pass (gfx950, wave64).
+// osort.hpp — this library's own radix sort of (key, uint32 value) pairs, keys of 32 or 64 bits: least significant digit
+// first, 8 bits a pass, stable, one sweep over the data per pass (gfx950, wave64).  The only sort of the library since round 6
+// (rounds 1-5 kept rocPRIM's radix_sort_pairs for 64-bit keys and as an A/B fallback: its ~700 kernel instantiations per
+// translation unit were 100 ms of code-object loading in the first registration() of a process).
 //
 // What it sorts: the source's Morton keys (the spatial order the lanes of a search wave want), the voxel filter's hash slots
 // and emission positions, the NDT leaf keys, the trimmed rejector's distances -- 10^4 .. 10^6 pairs, 10 .. 32 key bits
@@ -16,8 +18,9 @@
 //               neighbouring threads write neighbouring addresses.
 // State (histograms, look-back words, tickets) lives in one scratch block that must be ZERO when the histogram kernel
 // starts: the kernel that writes the keys clears it on its way (osort_clear), so a sort queues no memset.
-// The passes ping-pong between the caller's two buffer pairs.  At most 4 096 pairs are sorted by ONE workgroup in one launch
-// (k_os_small: the same passes, in LDS).
+// The passes ping-pong between the caller's two buffer pairs.  At most one tile of pairs is sorted by ONE workgroup in one launch
+// (k_os_small: the same passes, in LDS).  A tile is 4 096 pairs of 32-bit keys, 2 048 of 64-bit keys (the keys of a tile sit in LDS).
+// The vocabulary of the call sites (rounds 3-5: csrc/radix32.hpp) lives at the end of this file.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,8 +31,14 @@
 
 namespace rsreg {
 
-constexpr unsigned kOsBlock = 1024, kOsItems = 4, kOsTile = kOsBlock * kOsItems, kOsBits = 8, kOsDigits = 1u << kOsBits;
-constexpr unsigned kOsHistBlock = 256, kOsHistItems = 16, kOsMaxPasses = 4;
+constexpr unsigned kOsBlock = 1024, kOsBits = 8, kOsDigits = 1u << kOsBits;
+constexpr unsigned kOsHistBlock = 256, kOsHistItems = 16;
+// per key type: pairs a thread holds (a tile = 1 024 threads x that), digit passes at most
+template <typename K> struct OsKey;
+template <> struct OsKey<uint32_t> { static constexpr unsigned items = 4, max_passes = 4; };
+template <> struct OsKey<unsigned long long> { static constexpr unsigned items = 2, max_passes = 8; };
+template <typename K> constexpr unsigned os_tile() { return kOsBlock * OsKey<K>::items; }
+constexpr unsigned kOsTile = kOsBlock * 4;   // (of 32-bit keys: what the call sites of 32-bit sorts size their buffers by)
 
 struct OsortPlan {
     uint32_t passes = 0, blocks = 0, hist_blocks = 0;
@@ -37,11 +46,11 @@ struct OsortPlan {
     uint32_t off_hist = 0, off_ticket = 0, off_state = 0;   // word offsets: passes x 256 counts | a ticket per pass | passes x blocks x 256 look-back words
 };
 
-inline OsortPlan osort_plan(size_t n, unsigned begin_bit, unsigned end_bit)
+template <typename K = uint32_t> inline OsortPlan osort_plan(size_t n, unsigned begin_bit, unsigned end_bit)
 {
     OsortPlan p;
     p.passes = (end_bit - begin_bit + kOsBits - 1) / kOsBits;
-    p.blocks = (uint32_t)((n + kOsTile - 1) / kOsTile);
+    p.blocks = (uint32_t)((n + os_tile<K>() - 1) / os_tile<K>());
     p.hist_blocks = (uint32_t)((n + kOsHistBlock * kOsHistItems - 1) / (kOsHistBlock * kOsHistItems));
     p.off_hist = 0;
     p.off_ticket = p.passes * kOsDigits;
@@ -56,10 +65,10 @@ __device__ __forceinline__ void osort_clear(uint32_t *scratch, uint32_t words, u
     for (uint32_t w = t; w < words; w += threads) scratch[w] = 0u;
 }
 
-template <int kDummy = 0>
-__global__ __launch_bounds__(kOsHistBlock) void k_os_hist(const uint32_t *keys, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t passes, uint32_t *hist)
+template <typename K>
+__global__ __launch_bounds__(kOsHistBlock) void k_os_hist(const K *keys, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t passes, uint32_t *hist)
 {
-    __shared__ uint32_t s_h[kOsMaxPasses * kOsDigits];
+    __shared__ uint32_t s_h[OsKey<K>::max_passes * kOsDigits];
     for (uint32_t k = threadIdx.x; k < passes * kOsDigits; k += kOsHistBlock) s_h[k] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * kOsHistBlock * kOsHistItems;
@@ -67,10 +76,10 @@ __global__ __launch_bounds__(kOsHistBlock) void k_os_hist(const uint32_t *keys, 
     for (uint32_t j = 0; j < kOsHistItems; ++j) {
         const uint32_t i = base + j * kOsHistBlock + threadIdx.x;
         if (i < n) {
-            const uint32_t k = keys[i];
+            const K k = keys[i];
             for (uint32_t p = 0; p < passes; ++p) {
                 const uint32_t bit = begin_bit + p * kOsBits, bits = min(kOsBits, end_bit - bit);
-                atomicAdd(&s_h[p * kOsDigits + ((k >> bit) & ((1u << bits) - 1u))], 1u);
+                atomicAdd(&s_h[p * kOsDigits + ((uint32_t)(k >> bit) & ((1u << bits) - 1u))], 1u);
             }
         }
     }
@@ -82,13 +91,14 @@ __global__ __launch_bounds__(kOsHistBlock) void k_os_hist(const uint32_t *keys, 
 // Ranks of a wave's 4 x 64 pairs among the pairs of the same digit earlier in the wave (order: round, lane), and the wave's
 // count per digit in cnt[256] (LDS, zero on entry).  The lanes holding my digit are the AND over the digit's bits of "ballot
 // of that bit, or its complement"; the first of them bumps the counter, the others sit behind it in lane order.
-__device__ __forceinline__ void os_wave_ranks(const uint32_t (&key)[kOsItems], uint32_t bit, uint32_t mask, uint32_t *cnt, uint32_t (&rank)[kOsItems])
+template <typename K, unsigned kItems>
+__device__ __forceinline__ void os_wave_ranks(const K (&key)[kItems], uint32_t bit, uint32_t mask, uint32_t *cnt, uint32_t (&rank)[kItems])
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (uint32_t r = 0; r < kOsItems; ++r) {
-        const uint32_t d = (key[r] >> bit) & mask;
+    for (uint32_t r = 0; r < kItems; ++r) {
+        const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
         unsigned long long peers = ~0ull;
 #pragma unroll
         for (uint32_t b = 0; b < kOsBits; ++b) {
@@ -110,26 +120,29 @@ __device__ __forceinline__ void os_wave_ranks(const uint32_t (&key)[kOsItems], u
 }
 
 // At most 4 096 pairs: the whole sort in one workgroup, every pass in LDS (one launch, no scratch).
-template <int kDummy = 0>
-__global__ __launch_bounds__(kOsBlock) void k_os_small(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
+template <typename K>
+__global__ __launch_bounds__(kOsBlock) void k_os_small(const K *keys_in, K *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
                                                        uint32_t begin_bit, uint32_t end_bit)
 {
+    constexpr unsigned kOsItems = OsKey<K>::items, kOsTile = os_tile<K>();
     __shared__ uint32_t s_cnt[kOsBlock / 64][kOsDigits];
-    __shared__ uint32_t s_keys[kOsTile], s_vals[kOsTile];
+    __shared__ K s_keys[kOsTile];
+    __shared__ uint32_t s_vals[kOsTile];
     __shared__ uint32_t s_start[kOsDigits], s_part[kOsDigits / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, base = wave * (kOsItems * 64u);
-    uint32_t key[kOsItems], val[kOsItems], rank[kOsItems];
+    K key[kOsItems];
+    uint32_t val[kOsItems], rank[kOsItems];
 #pragma unroll
     for (uint32_t r = 0; r < kOsItems; ++r) {
         const uint32_t i = base + r * 64u + lane;
-        key[r] = i < n ? keys_in[i] : 0xffffffffu;   // (padding: the last digit of every pass, behind every real pair)
+        key[r] = i < n ? keys_in[i] : ~(K)0;   // (padding: the last digit of every pass, behind every real pair)
         val[r] = i < n ? vals_in[i] : 0u;
     }
     for (uint32_t bit = begin_bit; bit < end_bit; bit += kOsBits) {
         const uint32_t mask = (1u << min(kOsBits, end_bit - bit)) - 1u;
         for (uint32_t k = t; k < (kOsBlock / 64) * kOsDigits; k += kOsBlock) (&s_cnt[0][0])[k] = 0u;
         __syncthreads();
-        os_wave_ranks(key, bit, mask, s_cnt[wave], rank);
+        os_wave_ranks<K, kOsItems>(key, bit, mask, s_cnt[wave], rank);
         __syncthreads();
         uint32_t total = 0, excl = 0;
         if (t < kOsDigits) {
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(kOsBlock) void k_os_small(const uint32_t *keys_in, 
         __syncthreads();
 #pragma unroll
         for (uint32_t r = 0; r < kOsItems; ++r) {
-            const uint32_t d = (key[r] >> bit) & mask;
+            const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
             const uint32_t p = s_start[d] + s_cnt[wave][d] + rank[r];
             s_keys[p] = key[r];
             s_vals[p] = val[r];
@@ -179,13 +192,15 @@ __global__ __launch_bounds__(kOsBlock) void k_os_small(const uint32_t *keys_in, 
 // look-back word of (workgroup, digit): status << 30 | count; 0 = nothing yet, 1 = the workgroup's own count, 2 = inclusive
 constexpr uint32_t kOsPartial = 1u << 30, kOsInclusive = 2u << 30, kOsValue = (1u << 30) - 1u;
 
-template <int kDummy = 0>
-__global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
+template <typename K>
+__global__ __launch_bounds__(kOsBlock) void k_os_pass(const K *keys_in, K *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
                                                       const uint32_t *hist /* this pass's 256 counts */, uint32_t *state, uint32_t *ticket, uint32_t bit,
                                                       uint32_t bits)
 {
+    constexpr unsigned kOsItems = OsKey<K>::items, kOsTile = os_tile<K>();
     __shared__ uint32_t s_cnt[kOsBlock / 64][kOsDigits];   // per wave and digit: count, then (in place) what the waves before hold
-    __shared__ uint32_t s_keys[kOsTile], s_vals[kOsTile];
+    __shared__ K s_keys[kOsTile];
+    __shared__ uint32_t s_vals[kOsTile];
     __shared__ uint32_t s_start[kOsDigits];                // first local sorted position of the digit
     __shared__ int s_gpos[kOsDigits];                      // global position of local sorted position 0 of the digit's segment, minus s_start
     __shared__ uint32_t s_part[kOsDigits / 64], s_gpart[kOsDigits / 64];
@@ -195,14 +210,15 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
     for (uint32_t k = t; k < (kOsBlock / 64) * kOsDigits; k += kOsBlock) (&s_cnt[0][0])[k] = 0u;
     __syncthreads();
     const uint32_t bid = s_bid, base = bid * kOsTile + wave * (kOsItems * 64u);
-    uint32_t key[kOsItems], val[kOsItems], rank[kOsItems];
+    K key[kOsItems];
+    uint32_t val[kOsItems], rank[kOsItems];
 #pragma unroll
     for (uint32_t r = 0; r < kOsItems; ++r) {
         const uint32_t i = base + r * 64u + lane;
-        key[r] = i < n ? keys_in[i] : 0xffffffffu;   // (padding: the last digit, behind every real pair of the last workgroup)
+        key[r] = i < n ? keys_in[i] : ~(K)0;   // (padding: the last digit, behind every real pair of the last workgroup)
         val[r] = i < n ? vals_in[i] : 0u;
     }
-    os_wave_ranks(key, bit, mask, s_cnt[wave], rank);
+    os_wave_ranks<K, kOsItems>(key, bit, mask, s_cnt[wave], rank);
     __syncthreads();
     // per digit: what the waves before hold, the workgroup's total (published at once: nobody behind waits longer than
     // that); the digits' first local positions and the first global position of every digit's segment are two exclusive
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
     // into sorted order in LDS
 #pragma unroll
     for (uint32_t r = 0; r < kOsItems; ++r) {
-        const uint32_t d = (key[r] >> bit) & mask;
+        const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
         const uint32_t p = s_start[d] + s_cnt[wave][d] + rank[r];
         s_keys[p] = key[r];
         s_vals[p] = val[r];
@@ -265,8 +281,8 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
     for (uint32_t j = 0; j < kOsItems; ++j) {
         const uint32_t p = j * kOsBlock + t;
         if (p < valid) {
-            const uint32_t k = s_keys[p];
-            const uint32_t to = (uint32_t)(s_gpos[(k >> bit) & mask] + (int)p);
+            const K k = s_keys[p];
+            const uint32_t to = (uint32_t)(s_gpos[(uint32_t)(k >> bit) & mask] + (int)p);
             keys_out[to] = k;
             vals_out[to] = s_vals[p];
         }
@@ -277,36 +293,77 @@ __global__ __launch_bounds__(kOsBlock) void k_os_pass(const uint32_t *keys_in, u
 // kernel starts and is dirty afterwards.  Returns through *in_first whether the sorted pairs lie in (keys_a, vals_a)
 // (true) or in (keys_b, vals_b); the other pair is overwritten too.
 // whether osort_pairs leaves the result in the pair it started from
-inline bool osort_ends_in_first(const OsortPlan &p, size_t n) { return n == 0 || p.passes == 0 || (n > kOsTile && p.passes % 2 == 0); }
+template <typename K = uint32_t> inline bool osort_ends_in_first(const OsortPlan &p, size_t n) { return n == 0 || p.passes == 0 || (n > os_tile<K>() && p.passes % 2 == 0); }
 
 // `hist_ready`: the digit histograms (passes x 256 counts from begin_bit on, as k_os_hist leaves them) if the kernel that wrote the
 // keys has counted them on its way (k_source_keys_hist): no histogram launch then; nullptr: k_os_hist counts them in the scratch block.
-inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
+template <typename K>
+inline hipError_t osort_pairs(const OsortPlan &p, uint32_t *scratch, K *keys_a, K *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
                               unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first, const uint32_t *hist_ready = nullptr)
 {
+    constexpr unsigned kOsTile = os_tile<K>();
     *in_first = true;
     if (n == 0 || p.passes == 0) return hipSuccess;
     // (every check before the first launch: an error return leaves nothing queued on a dirty scratch block)
-    if (p.passes > kOsMaxPasses || n >= (1ull << 30)) return hipErrorInvalidValue;
+    if (p.passes > OsKey<K>::max_passes || end_bit > sizeof(K) * 8 || n >= (1ull << 30)) return hipErrorInvalidValue;
     if (p.blocks != (uint32_t)((n + kOsTile - 1) / kOsTile)) return hipErrorInvalidValue;
     if (n <= kOsTile) {   // one workgroup, one launch; the result in the second pair
-        k_os_small<0><<<1, kOsBlock, 0, st>>>(keys_a, keys_b, vals_a, vals_b, (uint32_t)n, begin_bit, end_bit);
+        k_os_small<K><<<1, kOsBlock, 0, st>>>(keys_a, keys_b, vals_a, vals_b, (uint32_t)n, begin_bit, end_bit);
         *in_first = false;
         return hipGetLastError();
     }
     const uint32_t *hist = hist_ready ? hist_ready : scratch + p.off_hist;
-    if (!hist_ready) k_os_hist<0><<<p.hist_blocks, kOsHistBlock, 0, st>>>(keys_a, (uint32_t)n, begin_bit, end_bit, p.passes, scratch + p.off_hist);
+    if (!hist_ready) k_os_hist<K><<<p.hist_blocks, kOsHistBlock, 0, st>>>(keys_a, (uint32_t)n, begin_bit, end_bit, p.passes, scratch + p.off_hist);
     bool from_a = true;
     unsigned bit = begin_bit;
     for (uint32_t pass = 0; pass < p.passes; ++pass, bit += kOsBits) {
         const uint32_t bits = std::min(kOsBits, end_bit - bit);
-        k_os_pass<0><<<p.blocks, kOsBlock, 0, st>>>(from_a ? keys_a : keys_b, from_a ? keys_b : keys_a, from_a ? vals_a : vals_b, from_a ? vals_b : vals_a,
+        k_os_pass<K><<<p.blocks, kOsBlock, 0, st>>>(from_a ? keys_a : keys_b, from_a ? keys_b : keys_a, from_a ? vals_a : vals_b, from_a ? vals_b : vals_a,
                                                     (uint32_t)n, hist + pass * kOsDigits, scratch + p.off_state + (size_t)pass * p.blocks * kOsDigits,
                                                     scratch + p.off_ticket + pass, bit, bits);
         from_a = !from_a;
     }
     *in_first = from_a;
     return hipGetLastError();
+}
+
+// ---- the vocabulary of the call sites (rounds 3-5: csrc/radix32.hpp).  A plan: the scratch words that must be zero when the sort
+// starts (cleared by the kernel that writes the keys on its way: osort_clear), the digit passes, where the result ends.
+struct Radix32Plan : OsortPlan {
+    uint32_t places = 0;   // digit passes (an even number ends in the buffer pair it started from, unless one workgroup sorts it all)
+    bool ends_in_first = true;
+};
+
+template <typename K = uint32_t> inline Radix32Plan radix32_plan(size_t n, unsigned begin_bit, unsigned end_bit)
+{
+    Radix32Plan p;
+    static_cast<OsortPlan &>(p) = osort_plan<K>(n, begin_bit, end_bit);
+    p.places = p.passes;
+    p.ends_in_first = osort_ends_in_first<K>(p, n);
+    return p;
+}
+
+__device__ __forceinline__ void radix32_clear(uint32_t *scratch, uint32_t words, uint32_t t, uint32_t threads) { osort_clear(scratch, words, t, threads); }
+
+template <typename K>
+inline hipError_t radix32_sort_pairs(const Radix32Plan &p, uint32_t *scratch, K *keys_a, K *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
+                                     unsigned begin_bit, unsigned end_bit, hipStream_t st, bool *in_first, const uint32_t *hist_ready = nullptr)
+{
+    return osort_pairs<K>(p, scratch, keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, st, in_first, hist_ready);
+}
+
+// A sort whose keys were NOT written by a kernel of this library that clears the scratch block on its way: the block is cleared by a
+// memset in front (one fill launch).  `scratch` holds osort_plan<K>(n, begin_bit, end_bit).words words.
+template <typename K>
+inline hipError_t osort_pairs_cleared(uint32_t *scratch, K *keys_a, K *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n, unsigned begin_bit,
+                                      unsigned end_bit, hipStream_t st, bool *in_first)
+{
+    const OsortPlan p = osort_plan<K>(n, begin_bit, end_bit);
+    if (n > os_tile<K>()) {
+        const hipError_t e = hipMemsetAsync(scratch, 0, (size_t)p.words * 4, st);
+        if (e != hipSuccess) return e;
+    }
+    return osort_pairs<K>(p, scratch, keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, st, in_first);
 }
 
 }  // namespace rsreg

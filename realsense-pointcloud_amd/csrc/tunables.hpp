@@ -28,7 +28,6 @@ struct Tunables {
     bool box_cache = true;                 // RSREG_NO_BOX_CACHE=1: a cloud handle's bounding box is measured by every build / load
     bool count_sort = true;                // RSREG_COUNT_SORT=0: the index by sorting (k_dense_keys, radix sort, k_dense_compact) instead of counting (cellsort.hpp)
     bool scan_apart = false;               // RSREG_SCAN_APART=1: sort-based build: flag, scan, scatter as three launches
-    bool rocprim_sort = false;             // RSREG_ROCPRIM_SORT=1: rocPRIM's radix_sort_pairs instead of osort.hpp
     // ---- source
     bool sort_small = false;               // RSREG_SORT_SMALL=1: sources of <= 65 536 points are put into spatial order too
     size_t plain_source_max = 65536;       // RSREG_PLAIN_SOURCE_MAX
@@ -74,7 +73,6 @@ inline Tunables tunables_from_environment()
     v.box_cache = !on("RSREG_NO_BOX_CACHE");
     v.count_sort = !off("RSREG_COUNT_SORT");
     v.scan_apart = on("RSREG_SCAN_APART");
-    v.rocprim_sort = on("RSREG_ROCPRIM_SORT");
     v.sort_small = on("RSREG_SORT_SMALL");
     if (const char *e = std::getenv("RSREG_PLAIN_SOURCE_MAX")) v.plain_source_max = (size_t)std::atoll(e);
     if (const char *e = std::getenv("RSREG_MORTON_BITS")) v.morton_bits = std::max(6, std::min(31, std::atoi(e)));
@@ -115,7 +113,7 @@ inline std::string tunables_signature()
 {
     static const char *const names[] = {
         "RSREG_CELL_CAP", "RSREG_DENSE_MAX_CELLS", "RSREG_FORCE_HASH", "RSREG_KEYS64", "RSREG_FULL_TABLE", "RSREG_FAR_ROWS", "RSREG_NO_WIDE_CELLS",
-        "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_ROCPRIM_SORT", "RSREG_SORT_SMALL",
+        "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_SORT_SMALL",
         "RSREG_PLAIN_SOURCE_MAX", "RSREG_MORTON_BITS", "RSREG_NO_WORKER", "RSREG_NO_SEED", "RSREG_RESTART_APART", "RSREG_NO_SCAN", "RSREG_SCHED",
         "RSREG_SCHED_F4", "RSREG_SCHED_F2", "RSREG_SCHED_MIN_TILES", "RSREG_SCHED_AT", "RSREG_SCHED_XCD", "RSREG_SCHED_XCD_DEAL", "RSREG_SCHED_KEEP",
         "RSREG_CLOUD_POOL_MB", "RSREG_UPLOAD_WAIT_STAGED", "RSREG_NDT_NO_WATCH", "RSREG_NDT_RESIDENT_LS", "RSREG_NDT_TWO_LAUNCHES",

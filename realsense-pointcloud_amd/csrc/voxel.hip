@@ -20,14 +20,12 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
-
 #include <algorithm>
 #include <cmath>
 
 #include "rsreg_ctx.hpp"
-#include "sort_cfg.hpp"
-#include "radix32.hpp"
+#include "osort.hpp"
+#include "oscan.hpp"
 
 namespace rsreg {
 namespace {
@@ -329,41 +327,29 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     float *cent = b_cent.as<float>();
     uint32_t *stats = b_misc.as<uint32_t>() + 32;
     const uint32_t nb = div_up_u(N, kVBlock);
-    size_t sort_bytes = 0, scan_bytes = 0, sort2_bytes = 0;
-    // both sorts are the library's own (osort.hpp through radix32.hpp): the slot sort (10 bits, stable) and, further down,
-    // the sort of the runs by emission position (as many bits as n + 512 has).  Their state lies in one scratch block that
-    // the keys kernel clears on its way: [slot sort | emission sort, sized for n runs | rocPRIM's scan]
+    // both sorts are the library's own (osort.hpp): the slot sort (10 bits, stable) and, further down, the sort of the runs
+    // by emission position (as many bits as n + 512 has).  Their state lies in one scratch block that the keys kernel clears
+    // on its way: [slot sort | emission sort, sized for n runs | the scan's sums (oscan.hpp)]
     unsigned ebits = 1;
     while ((1ull << ebits) < (unsigned long long)n + kHist + 1ull) ++ebits;
-    const bool own_sort = radix32_pays(n, 10) && radix32_pays(n, ebits);
     const Radix32Plan plan = radix32_plan(n, 0, 10), plan2max = radix32_plan(n, 0, ebits);
-    if (own_sort) {
-        sort_bytes = (size_t)plan.words * 4;
-        sort2_bytes = (size_t)plan2max.words * 4;
-    } else {
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort2_bytes, ekey, ekey2, erun, order, n, 0, 32, st));
-    }
-    RSREG_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    const size_t sort_bytes = (size_t)plan.words * 4, sort2_bytes = (size_t)plan2max.words * 4, scan_bytes = oscan_scratch_bytes<uint32_t>(n);
     const size_t off_sort2 = (sort_bytes + 255) & ~(size_t)255, off_scan = (off_sort2 + sort2_bytes + 255) & ~(size_t)255;
     RSREG_HIP(ctx, b_tmp.reserve(off_scan + scan_bytes + 256));
     char *tmp = b_tmp.as<char>();
     // (the slot sort ends in the pair (skeys, svals): the keys are written into whichever pair that takes)
-    uint32_t *k_a = !own_sort || !plan.ends_in_first ? keys : skeys, *v_a = !own_sort || !plan.ends_in_first ? vals : svals;
+    uint32_t *k_a = !plan.ends_in_first ? keys : skeys, *v_a = !plan.ends_in_first ? vals : svals;
     uint32_t *k_b = k_a == keys ? skeys : keys, *v_b = v_a == vals ? svals : vals;
-    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, k_a, v_a, stats, own_sort ? b_tmp.as<uint32_t>() : nullptr,
-                                       own_sort ? (uint32_t)((off_sort2 + sort2_bytes) / 4) : 0u);
+    k_vox_keys<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, k_a, v_a, stats, b_tmp.as<uint32_t>(), (uint32_t)((off_sort2 + sort2_bytes) / 4));
     RSREG_HIP(ctx, hipGetLastError());
-    if (own_sort) {
+    {
         bool in_first = false;
-        RSREG_HIP(ctx, radix32_sort_pairs(plan, b_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 10, st, &in_first));
-        if ((in_first ? k_a : k_b) != skeys) return fail(ctx, RSREG_ERR_STATE, "radix32: the sorted pairs are not where they belong");
-    } else {
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp, sort_bytes, keys, skeys, vals, svals, n, 0, 10, st));   // stable
+        RSREG_HIP(ctx, radix32_sort_pairs<uint32_t>(plan, b_tmp.as<uint32_t>(), k_a, k_b, v_a, v_b, n, 0, 10, st, &in_first));
+        if ((in_first ? k_a : k_b) != skeys) return fail(ctx, RSREG_ERR_STATE, "osort: the sorted pairs are not where they belong");
     }
     k_vox_flags<<<nb, kVBlock, 0, st>>>(d_in, stride, N, ivx, ivy, ivz, skeys, svals, flag);
     RSREG_HIP(ctx, hipGetLastError());
-    RSREG_HIP(ctx, rocprim::exclusive_scan(tmp + off_scan, scan_bytes, flag, rid, 0u, n, rocprim::plus<uint32_t>(), st));
+    RSREG_HIP(ctx, (oscan<uint32_t>(flag, rid, n, 0u, tmp + off_scan, st)));
     k_vox_starts<<<nb, kVBlock, 0, st>>>(skeys, flag, rid, N, start, stats);
     RSREG_HIP(ctx, hipGetLastError());
     uint32_t *h = b_host.as<uint32_t>();
@@ -377,13 +363,11 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
                                                                            long_runs);
     RSREG_HIP(ctx, hipGetLastError());
     const uint32_t *emit_order = order;
-    if (own_sort) {
+    {
         const Radix32Plan plan2 = radix32_plan(nr, 0, ebits);   // (nr <= n: its state fits the block cleared for n runs)
         bool in_first = false;
-        RSREG_HIP(ctx, radix32_sort_pairs(plan2, reinterpret_cast<uint32_t *>(tmp + off_sort2), ekey, ekey2, erun, order, nr, 0, ebits, st, &in_first));
+        RSREG_HIP(ctx, radix32_sort_pairs<uint32_t>(plan2, reinterpret_cast<uint32_t *>(tmp + off_sort2), ekey, ekey2, erun, order, nr, 0, ebits, st, &in_first));
         emit_order = in_first ? erun : order;
-    } else {
-        RSREG_HIP(ctx, rocprim::radix_sort_pairs(tmp + off_sort2, sort2_bytes, ekey, ekey2, erun, order, nr, 0, 32, st));
     }
     k_vox_emit<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(cent, emit_order, stats, stride, d_out);
     RSREG_HIP(ctx, hipGetLastError());

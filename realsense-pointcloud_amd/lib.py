@@ -101,7 +101,7 @@ def hipcc_command(out=SO_PATH):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     extra = (["-DRSREG_DIAG"] if DIAG else []) + os.environ.get("RSREG_CXXFLAGS", "").split()   # (dev: -D switches of experiment builds)
     return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-            "-Wno-unused-result", *extra, *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"]
+            "-Wno-unused-result", *extra, *srcs, "-o", out, "-ldl"]
 
 
 def needs_build():
@@ -155,7 +155,7 @@ def build(force=False, verbose=False, out=SO_PATH, obj_dir=None):
         if verbose and log:
             print(log)
     open(stamp, "w").write(" ".join(flags))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _, _ in results], "-o", out, "-L/opt/rocm/lib", "-lrccl"],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _, _ in results], "-o", out, "-ldl"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout[-4000:])

@@ -26,7 +26,24 @@ int main(int argc, char **argv)
         return 2;
     }
     const std::string mode = argv[1], prefix = argv[2];
+    const auto t_main = std::chrono::steady_clock::now();
+    auto since_main = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_main).count(); };
     try {
+        // RSREG_SCHEME_COLD=1: what the first registration() of a process is made of (main.cpp:85 calls it once per process).  The
+        // steps a cold registration() goes through by itself are taken one by one first, each timed: the HIP runtime's start
+        // (the first HIP call of the process), the context (streams, events, worker threads, first allocations); run 0 below
+        // then shows what is left: code objects loaded at the first launch of every translation unit's kernels, buffers grown.
+        const bool cold = std::getenv("RSREG_SCHEME_COLD") && std::getenv("RSREG_SCHEME_COLD")[0] == '1';
+        if (cold) {
+            const double a = since_main();
+            int ndev = 0;
+            (void)rsreg_device_count(&ndev);
+            const double b = since_main();
+            (void)Context::Default();
+            const double c = since_main();
+            std::fprintf(stderr, "%s cold: main() reached the runner + %.2f ms | first HIP call (runtime start, %d device%s) %.2f ms | context created %.2f ms\n",
+                         mode.c_str(), a, ndev, ndev == 1 ? "" : "s", b - a, c - b);
+        }
         std::vector<rgb_point_cloud_pointer> clouds;
         for (int i = 3; i < argc; ++i) {
             auto c = std::make_shared<rgb_point_cloud>();
@@ -53,6 +70,7 @@ int main(int argc, char **argv)
             c.params.max_correspondence_distance = 0.05;
         };
         std::unique_ptr<ChainRegistrar> chain;
+        if (cold) std::fprintf(stderr, "%s cold: frames read from disk, main() + %.2f ms\n", mode.c_str(), since_main());
         for (int rep = 0; rep < timed_reps; ++rep) {
             std::vector<rgb_point_cloud_pointer> fresh;
             for (auto &c : clouds) fresh.push_back(std::make_shared<rgb_point_cloud>(*c));

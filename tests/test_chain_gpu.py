@@ -69,9 +69,8 @@ def test_pairs_in_flight_are_bit_identical_to_pairs_alone(env, frames, rs, mode)
             for k in range(1, N_FRAMES):
                 np.testing.assert_array_equal(got[k], alone[k][0], err_msg="pair %d, %d in flight" % (k, in_flight))
                 assert seen[k] == alone[k][1:], (k, in_flight)
+        # (which context got which pair is a matter of timing -- a late thread may find the queue empty -- and is not asserted)
         assert set(reg.pair_context.values()) <= set(range(in_flight))
-        if in_flight > 1:
-            assert len(set(reg.pair_context.values())) > 1      # the pairs really were dealt to several contexts
 
 
 def test_pairs_in_flight_match_the_oracle(env, frames, orc):
@@ -143,7 +142,7 @@ def test_cpp_chain_registrar(env, frames, runner, tmp_path, rs, iters):
     np.testing.assert_array_equal(p1, p3)
     np.testing.assert_array_equal(poses1, poses3)
     assert [h[:2] for h in h1] == [h[:2] for h in h3]
-    assert {h[2] for h in h1} == {0} and len({h[2] for h in h3}) > 1
+    assert {h[2] for h in h1} == {0} and {h[2] for h in h3} <= {0, 1, 2}
     if iters == "0":
         params = api.icp_params(reference=True)
     else:

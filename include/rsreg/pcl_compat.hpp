@@ -380,9 +380,17 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
             target_dirty_ = false;
             ctx_->icp_target_owner = this;
         }
+        // `output = input` (PCL copies the input cloud first, then rewrites xyz) is made inside the call, by the host threads that
+        // write the aligned positions anyway (rsreg_icp_align_records): the records are never constructed or copied here
         PointCloud<PointSource> tmp;
-        detail::copy_aligned(*source_, tmp);
-        check(rsreg_icp_align(c, guess.data(), &prm_, &res_, tmp.points.data(), sizeof(PointSource)), c);
+        tmp.points = uninitialized_points<PointSource>(source_->size());
+        tmp.width = source_->width;
+        tmp.height = source_->height;
+        tmp.is_dense = source_->is_dense;
+        if (source_->size())
+            check(rsreg_icp_align_records(c, guess.data(), &prm_, &res_, source_->points.data(), tmp.points.data(), sizeof(PointSource)), c);
+        else
+            check(rsreg_icp_align(c, guess.data(), &prm_, &res_, nullptr, 0), c);
         std::memcpy(final_.m, res_.transform, sizeof(final_.m));
         output = std::move(tmp);
     }

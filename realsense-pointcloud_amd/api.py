@@ -352,9 +352,16 @@ class IterativeClosestPoint:
                                                     C.byref(res), out.h), self.ctx.h)
             self.result = res
             return out
-        out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(self._n_src, POINT_DTYPE)
-        _l.check(_l.lib().rsreg_icp_align(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
-                                          C.byref(res), out.ctypes.data, out.dtype.itemsize), self.ctx.h)
+        if isinstance(self._src, PointCloud) and len(self._src.points):
+            # `output = input` is made inside the call (rsreg_icp_align_records), by the host threads that write the aligned positions
+            recs = np.ascontiguousarray(self._src.points)
+            out = np.empty(len(recs), recs.dtype)
+            _l.check(_l.lib().rsreg_icp_align_records(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
+                                                      C.byref(res), recs.ctypes.data, out.ctypes.data, out.dtype.itemsize), self.ctx.h)
+        else:
+            out = self._src.points.copy() if isinstance(self._src, PointCloud) else np.zeros(self._n_src, POINT_DTYPE)
+            _l.check(_l.lib().rsreg_icp_align(self.ctx.h, g.ctypes.data if g is not None else None, C.byref(self.params),
+                                              C.byref(res), out.ctypes.data, out.dtype.itemsize), self.ctx.h)
         self.result = res
         src = self._src if isinstance(self._src, PointCloud) else None
         return PointCloud(out, width=src.width if src else len(out), height=src.height if src else 1,

@@ -1998,7 +1998,20 @@ int rsreg_icp_update(rsreg_ctx *ctx, const double sums[RSREG_NUM_SUMS], float *t
     return RSREG_OK;
 }
 
+namespace {
+int icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t out_stride, const void *source_records);
+}
+
 int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t out_stride)
+{
+    return icp_end(ctx, result, aligned_out, out_stride, nullptr);
+}
+
+namespace {
+// source_records (nullable): the caller's source records, out_stride bytes each -- every record of aligned_out is then the
+// WHOLE source record with xyz rewritten (what PCL's align(output) leaves: output = input, then xyz <- final * xyz), copied by
+// the host threads that write the aligned positions anyway
+int icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t out_stride, const void *source_records)
 {
     if (!ctx) return RSREG_ERR_INVALID_ARG;
     IcpState &s = ctx->icp;
@@ -2027,6 +2040,13 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
         }
         const float *src = ctx->h_stage.as<float>();
         char *dst = static_cast<char *>(aligned_out);
+        const char *rec = static_cast<const char *>(source_records);
+        // (the caller's records first, all of them, while the positions are still on the link: the positions then land in lines
+        // the cores already own)
+        // (icp_align has started that copy on a thread of its own, beside the iterations: it ends here)
+        if (ctx->records_copy.joinable()) ctx->records_copy.join();
+        else if (rec && rec != dst)
+            host_parallel_for(n, [=](size_t a, size_t b) { std::memcpy(dst + a * out_stride, rec + a * out_stride, (b - a) * out_stride); });
         for (size_t k = 0; k < pieces; ++k) {
             const size_t lo = k * piece, hi = std::min(n, lo + piece);
             RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_home[k]));
@@ -2112,6 +2132,7 @@ int rsreg_icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, s
     s.active = 0;
     return RSREG_OK;
 }
+}  // namespace
 
 int rsreg_ctx_host_timing(rsreg_ctx *ctx, rsreg_host_timing *out)
 {
@@ -2120,8 +2141,27 @@ int rsreg_ctx_host_timing(rsreg_ctx *ctx, rsreg_host_timing *out)
     return RSREG_OK;
 }
 
+namespace {
+int icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result, void *aligned_out, size_t out_stride,
+              const void *source_records);
+}
+
 int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result,
                     void *aligned_out, size_t out_stride)
+{
+    return icp_align(ctx, guess, params, result, aligned_out, out_stride, nullptr);
+}
+
+int rsreg_icp_align_records(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result,
+                            const void *source_records, void *aligned_out, size_t stride)
+{
+    if (!source_records || !aligned_out) return RSREG_ERR_INVALID_ARG;
+    return icp_align(ctx, guess, params, result, aligned_out, stride, source_records);
+}
+
+namespace {
+int icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *params, rsreg_icp_result *result, void *aligned_out, size_t out_stride,
+              const void *source_records)
 {
     const auto t_align0 = std::chrono::steady_clock::now();
     struct AlignClock {   // (whatever way the call ends: begin .. the last iteration + the aligned cloud's way home)
@@ -2130,6 +2170,20 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
         ~AlignClock() { if (c) c->host_timing.align = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - c->host_timing.aligned_copy; }
     } align_clock{ctx, t_align0};
     if (ctx) ctx->host_timing.aligned_copy = 0;
+    // `output = input`: the caller's records go into the output on a thread of their own (the pool's threads under it) while this
+    // thread queues and waits for the iterations; icp_end joins it before the aligned positions are written over the records
+    struct CopyGuard {   // (an error on the way: the copy still owns aligned_out)
+        rsreg_ctx *c;
+        ~CopyGuard() { if (c && c->records_copy.joinable()) c->records_copy.join(); }
+    } copy_guard{ctx};
+    if (ctx && source_records && aligned_out && source_records != aligned_out && ctx->n_source && out_stride >= 12) {
+        const size_t n_rec = ctx->n_source;
+        const char *rec = static_cast<const char *>(source_records);
+        char *dst = static_cast<char *>(aligned_out);
+        ctx->records_copy = std::thread([=] {
+            host_parallel_for(n_rec, [=](size_t a, size_t b) { std::memcpy(dst + a * out_stride, rec + a * out_stride, (b - a) * out_stride); });
+        });
+    }
     int rc = rsreg_icp_begin(ctx, guess, params);
     if (rc) return rc;
     int done = 0;
@@ -2154,8 +2208,9 @@ int rsreg_icp_align(rsreg_ctx *ctx, const float *guess, const rsreg_icp_params *
         rc = update_from_sums(ctx, sums, &done);
         if (rc) return rc;
     }
-    return rsreg_icp_end(ctx, result, aligned_out, out_stride);
+    return icp_end(ctx, result, aligned_out, out_stride, source_records);
 }
+}  // namespace
 
 int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info)
 {

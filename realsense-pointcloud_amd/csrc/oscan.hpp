@@ -4,8 +4,9 @@
 // the leaf-start flags of the NDT grid, the weights of the trimmed rejector, and -- on the fallback builds of the target
 // index only -- the flag words and the cell-count table.  10^4 .. 10^6 values as a rule, up to 2^28 table entries.
 //
-// Reduce, then scan: k_oscan_sums (a workgroup adds its 1 024 values), k_oscan_top (ONE workgroup turns the workgroups' sums into
-// what lies in front of each), k_oscan_apply (a workgroup scans its 1 024 values from there).  Three launches, the values
+// Reduce, then scan: k_oscan_sums (a workgroup adds its 1 024 values), k_oscan_apply (a workgroup adds up the sums in front of it --
+// at most 4 096 of them; beyond that k_oscan_top, ONE workgroup, turns the sums into what lies in front of each first -- and
+// scans its 1 024 values from there).  Two launches (three beyond 4 M values), the values
 // read twice, NO state that has to be zero beforehand and no workgroup that waits for another one -- which is what this
 // library had rocPRIM's scan for until round 6, at the price of its ~700 kernel instantiations per translation unit in the
 // code object (every architecture's tuning of every algorithm: 100 ms of code-object loading in the first registration() of
@@ -19,7 +20,7 @@
 
 namespace rsreg {
 
-constexpr unsigned kScBlock = 256, kScItems = 4, kScTile = kScBlock * kScItems, kScTopBlock = 1024;   // (4 consecutive values a thread: one 16-byte load of uint32s)
+constexpr unsigned kScBlock = 256, kScItems = 4, kScTile = kScBlock * kScItems, kScTopBlock = 1024, kScSelfTop = 4096;   // (4 consecutive values a thread: one 16-byte load of uint32s)
 
 inline uint32_t oscan_blocks(size_t n) { return (uint32_t)((n + kScTile - 1) / kScTile); }
 // bytes of scratch a scan of n values of type T needs (the workgroups' sums)
@@ -90,9 +91,19 @@ template <typename T> __global__ __launch_bounds__(kScTopBlock) void k_oscan_top
     if (threadIdx.x == 0) part[blocks] = carry;
 }
 
-template <typename T, bool kInclusive> __global__ __launch_bounds__(kScBlock) void k_oscan_apply(const T *in, T *out, size_t n, T init, const T *part)
+// kTopDone: part[b] already holds what lies in front of workgroup b (k_oscan_top has run); otherwise part[] are the workgroups'
+// own sums and every workgroup adds up the ones in front of it itself (at most kScSelfTop of them: one launch less)
+template <typename T, bool kInclusive, bool kTopDone> __global__ __launch_bounds__(kScBlock) void k_oscan_apply(const T *in, T *out, size_t n, T init, const T *part)
 {
     __shared__ T s_part[kScBlock / 64];
+    T front = 0;
+    if (kTopDone) {
+        front = part[blockIdx.x];
+    } else {
+        T mine = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kScBlock) mine += part[b];
+        (void)oscan_block_excl<T, kScBlock>(mine, s_part, &front);   // (front <- the sum over the workgroup's threads)
+    }
     const size_t at = (size_t)blockIdx.x * kScTile + (size_t)threadIdx.x * kScItems;
     T x[kScItems], v = 0;
     if (at + kScItems <= n) {
@@ -105,7 +116,7 @@ template <typename T, bool kInclusive> __global__ __launch_bounds__(kScBlock) vo
 #pragma unroll
     for (uint32_t j = 0; j < kScItems; ++j) v += x[j];
     T total;
-    T run = init + part[blockIdx.x] + oscan_block_excl<T, kScBlock>(v, s_part, &total);
+    T run = init + front + oscan_block_excl<T, kScBlock>(v, s_part, &total);
 #pragma unroll
     for (uint32_t j = 0; j < kScItems; ++j) {
         if (kInclusive) run += x[j];
@@ -122,8 +133,12 @@ template <typename T, bool kInclusive = false> inline hipError_t oscan(const T *
     const uint32_t blocks = oscan_blocks(n);
     T *part = static_cast<T *>(scratch);
     k_oscan_sums<T><<<blocks, kScBlock, 0, st>>>(in, n, part);
-    k_oscan_top<T><<<1, kScTopBlock, 0, st>>>(part, blocks);
-    k_oscan_apply<T, kInclusive><<<blocks, kScBlock, 0, st>>>(in, out, n, init, part);
+    if (blocks <= kScSelfTop) {   // (10^6 values: 977 sums, four loads a thread)
+        k_oscan_apply<T, kInclusive, false><<<blocks, kScBlock, 0, st>>>(in, out, n, init, part);
+    } else {
+        k_oscan_top<T><<<1, kScTopBlock, 0, st>>>(part, blocks);
+        k_oscan_apply<T, kInclusive, true><<<blocks, kScBlock, 0, st>>>(in, out, n, init, part);
+    }
     return hipGetLastError();
 }
 

@@ -282,6 +282,7 @@ struct rsreg_ctx {
     rsreg::PinnedBuf h_ndt;
 
     // ---- RCCL
+    std::thread records_copy;     // rsreg_icp_align_records: the caller's source records on their way into aligned_out (joined by icp_end)
     void *comm = nullptr;         // ncclComm_t
     int rank = 0, nranks = 1;
     rsreg::DevBuf d_comm;

@@ -27,7 +27,7 @@ EXPORTS = [
     "rsreg_ctx_create", "rsreg_ctx_destroy", "rsreg_ctx_synchronize", "rsreg_ctx_set_profiling",
     "rsreg_icp_params_default", "rsreg_icp_params_reference", "rsreg_ndt_params_default",
     "rsreg_ndt_params_reference", "rsreg_icp_set_target", "rsreg_icp_set_target_device",
-    "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_begin",
+    "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_align_records", "rsreg_icp_begin",
     "rsreg_icp_search", "rsreg_icp_sums", "rsreg_icp_update", "rsreg_icp_end",
     "rsreg_umeyama_from_sums", "rsreg_transform_cloud", "rsreg_approx_voxel_grid", "rsreg_approx_voxel_grid_gpu",
     "rsreg_ndt_set_target", "rsreg_ndt_align", "rsreg_ndt_derivatives", "rsreg_ndt_get_voxels", "rsreg_ndt_set_centroid_mode", "rsreg_ndt_get_centroids",
@@ -208,6 +208,7 @@ def lib():
     L.rsreg_icp_set_source.argtypes = [vp, vp, sz, sz, i32]
     L.rsreg_icp_set_source_device.argtypes = [vp, vp, sz, sz, i32]
     L.rsreg_icp_align.argtypes = [vp, vp, C.POINTER(IcpParams), C.POINTER(IcpResult), vp, sz]
+    L.rsreg_icp_align_records.argtypes = [vp, vp, C.POINTER(IcpParams), C.POINTER(IcpResult), vp, vp, sz]
     L.rsreg_icp_begin.argtypes = [vp, vp, C.POINTER(IcpParams)]
     L.rsreg_icp_search.argtypes = [vp, vp, vp]
     L.rsreg_icp_sums.argtypes = [vp, vp]

@@ -27,7 +27,7 @@ def test_header_and_exports_agree(L):
 
 
 def test_version_and_status_strings(L):
-    assert L.lib().rsreg_version() == 3          # 0.3: rsreg_grid_info lost n_updates (dead since round 4), rsreg_icp_result gained ms_allreduce
+    assert L.lib().rsreg_version() == 4          # 0.4: rsreg_icp_align_records (0.3: rsreg_grid_info lost n_updates, rsreg_icp_result gained ms_allreduce)
     assert L.status_string(0) == "ok"
     assert "device" in L.status_string(-6)
 

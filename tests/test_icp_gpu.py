@@ -449,3 +449,49 @@ def test_sources_of_every_size_through_one_context(rs):
     one = fresh()
     for k, src in enumerate(order):
         assert run(one, src) == run(fresh(), src), k
+
+
+@pytest.mark.parametrize("size", ["50k", "N300"])
+def test_align_records_is_align_after_a_copy_of_the_input(api, rs, size):
+    """rsreg_icp_align_records (PCL's `output = input` made on the way, incremental_icp.hpp:59) leaves byte for byte what
+    rsreg_icp_align leaves in a copy of the source records: colours and padding the source's, xyz <- final * xyz, data[3] = 1.
+    N300: more than one piece of 2^18 points comes home."""
+    import ctypes as C
+    from rsreg_amd import lib
+    tgt, src = rs.synth.render_frame(0, size, "parity"), rs.synth.render_frame(1, size, "parity")
+    recs = np.ascontiguousarray(src.points)
+    raw = recs.view(np.uint8).reshape(len(recs), -1).copy()
+    raw[:, 20:32] = np.arange(12, dtype=np.uint8) + 1          # the padding behind rgba travels too
+    recs = raw.view(recs.dtype).reshape(-1)
+
+    def clone(a):   # (numpy copies a structured array field by field: the padding would not travel)
+        return np.frombuffer(bytearray(a.tobytes()), a.dtype)
+
+    ctx = api.Context(0)
+    L, prm = lib.lib(), api.icp_params(reference=True)
+    outs = []
+    for with_records in (False, True):
+        res = lib.IcpResult()
+        lib.check(L.rsreg_icp_set_source(ctx.h, recs.ctypes.data, len(recs), recs.dtype.itemsize, 0), ctx.h)
+        lib.check(L.rsreg_icp_set_target(ctx.h, tgt.points.ctypes.data, len(tgt.points), tgt.points.dtype.itemsize, 0, prm.max_correspondence_distance), ctx.h)
+        if with_records:
+            out = np.full(len(recs), 0, recs.dtype)
+            lib.check(L.rsreg_icp_align_records(ctx.h, None, C.byref(prm), C.byref(res), recs.ctypes.data, out.ctypes.data, out.dtype.itemsize), ctx.h)
+        else:
+            out = clone(recs)
+            lib.check(L.rsreg_icp_align(ctx.h, None, C.byref(prm), C.byref(res), out.ctypes.data, out.dtype.itemsize), ctx.h)
+        outs.append((out, np.array(res.transform)))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][0].tobytes() == outs[1][0].tobytes()
+    assert not np.array_equal(outs[1][0]["x"], recs["x"])      # (something moved)
+    # in place: aligned_out == source_records
+    res = lib.IcpResult()
+    inplace = clone(recs)
+    lib.check(L.rsreg_icp_set_source(ctx.h, inplace.ctypes.data, len(recs), recs.dtype.itemsize, 0), ctx.h)
+    lib.check(L.rsreg_icp_set_target(ctx.h, tgt.points.ctypes.data, len(tgt.points), tgt.points.dtype.itemsize, 0, prm.max_correspondence_distance), ctx.h)
+    lib.check(L.rsreg_icp_align_records(ctx.h, None, C.byref(prm), C.byref(res), inplace.ctypes.data, inplace.ctypes.data, inplace.dtype.itemsize), ctx.h)
+    assert inplace.tobytes() == outs[0][0].tobytes()
+    # the Python and C++ adaptors go through it: the aligned cloud keeps the source's colours
+    icp = _ref_icp(api, rs.PointCloud(clone(recs)), tgt)
+    aligned = icp.align()
+    assert aligned.points.tobytes() == outs[0][0].tobytes()

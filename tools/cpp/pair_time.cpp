@@ -1,8 +1,8 @@
 // pair_time.cpp -- what a C++ caller of the C ABI pays for one pair with the reference's parameters (setInputSource,
 // setInputTarget, align with the aligned cloud; incremental_icp.hpp:57-63): no Python between the calls.
-// usage: pair_time <target.f32> <source.f32> <n_target> <n_source> [host]   (32-byte PointXYZRGB records, raw)
+// usage: pair_time <target.f32> <source.f32> <n_target> <n_source> [host [copy]]   (32-byte PointXYZRGB records, raw)
 // host: the literal call surface -- both clouds in HOST memory in, 4x4 and the aligned cloud in host memory out
-// (rsreg_icp_set_source / rsreg_icp_set_target / rsreg_icp_align with aligned_out; INTEGRATION.md adaptor A), with the
+// (rsreg_icp_set_source / rsreg_icp_set_target / rsreg_icp_align_records; INTEGRATION.md adaptor A), with the
 // library's own account of where the host's time went (rsreg_ctx_host_timing); prints one JSON line.
 // build: g++ -std=c++17 -O2 -I include tools/cpp/pair_time.cpp -o tools/_build/pair_time -L realsense-pointcloud_amd -lrsreg -Wl,-rpath,$PWD/realsense-pointcloud_amd
 #include <algorithm>
@@ -38,6 +38,7 @@ int main(int argc, char **argv)
         rsreg_icp_params_reference(&prm);
         rsreg_icp_result res;
         std::vector<char> aligned(ns * 32);
+        const bool copy_outside = argc > 6 && argv[6][0] == 'c';
         const int reps = 30, skip = 5;
         std::vector<double> total, t_src, t_tgt, t_copy, t_align;
         std::vector<std::vector<double>> parts(7);
@@ -48,9 +49,12 @@ int main(int argc, char **argv)
             const double t1 = now_ms();
             CK(rsreg_icp_set_target(ctx, t.data(), nt, 32, 0, prm.max_correspondence_distance));
             const double t2 = now_ms();
-            std::memcpy(aligned.data(), s.data(), ns * 32);   // PCL's align(output) starts from output = *input: colours and padding
+            // PCL's align(output) starts from output = *input (colours and padding): rounds 1-5, the caller's own memcpy in front of
+            // rsreg_icp_align (`copy` mode, one thread: 0.9 ms at 10^6 points); round 6, inside rsreg_icp_align_records
+            if (copy_outside) std::memcpy(aligned.data(), s.data(), ns * 32);
             const double t3 = now_ms();
-            CK(rsreg_icp_align(ctx, nullptr, &prm, &res, aligned.data(), 32));
+            if (copy_outside) CK(rsreg_icp_align(ctx, nullptr, &prm, &res, aligned.data(), 32));
+            else CK(rsreg_icp_align_records(ctx, nullptr, &prm, &res, s.data(), aligned.data(), 32));
             const double t4 = now_ms();
             if (k < skip) continue;
             total.push_back(t4 - t0); t_src.push_back(t1 - t0); t_tgt.push_back(t2 - t1); t_copy.push_back(t3 - t2); t_align.push_back(t4 - t3);
@@ -60,11 +64,11 @@ int main(int argc, char **argv)
             for (int j = 0; j < 7; ++j) parts[j].push_back(v[j]);
         }
         auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-        std::printf("{\"n_source\": %zu, \"n_target\": %zu, \"ms_per_pair\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"set_source\": %.4f, \"set_target\": %.4f, "
+        std::printf("{\"n_source\": %zu, \"n_target\": %zu, \"input_records_copied\": \"%s\", \"ms_per_pair\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"set_source\": %.4f, \"set_target\": %.4f, "
                     "\"copy_input_records\": %.4f, \"align\": %.4f, \"inside\": {\"source_stage_wait\": %.4f, \"source_pack\": %.4f, \"target_stage_wait\": %.4f, "
                     "\"target_pack\": %.4f, \"target_build\": %.4f, \"align_iterations\": %.4f, \"aligned_cloud_home\": %.4f}, \"iterations\": %d, "
                     "\"n_correspondences\": %llu, \"pairs_timed\": %zu}\n",
-                    ns, nt, med(total), [&] { auto v = total; std::sort(v.begin(), v.end()); return v[v.size() / 10]; }(),
+                    ns, nt, copy_outside ? "by the caller, in front of rsreg_icp_align" : "inside rsreg_icp_align_records", med(total), [&] { auto v = total; std::sort(v.begin(), v.end()); return v[v.size() / 10]; }(),
                     [&] { auto v = total; std::sort(v.begin(), v.end()); return v[v.size() * 9 / 10]; }(), med(t_src), med(t_tgt), med(t_copy), med(t_align),
                     med(parts[0]), med(parts[1]), med(parts[2]), med(parts[3]), med(parts[4]), med(parts[5]), med(parts[6]), res.iterations,
                     (unsigned long long)res.n_correspondences, total.size());

@@ -17,7 +17,7 @@ out = os.path.join(ROOT, "tests", "cpp", "_build")
 os.makedirs(out, exist_ok=True)
 exe = os.path.join(out, "scheme_runner")
 pkg = os.path.join(ROOT, "realsense-pointcloud_amd")
-subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "scheme_runner.cpp"),
+subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-DRSREG_PCL_COMPAT_FAST_UNINIT", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "scheme_runner.cpp"),
                 "-o", exe, "-L", pkg, "-lrsreg", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
 with tempfile.TemporaryDirectory() as d:
     paths = []

@@ -325,7 +325,12 @@ class IterativeClosestPoint:
             self._n_src = n
             self._src_dirty = False
             self.ctx.icp_source_owner = self
+        # the index's cell size derives from the gate: a gate that has changed since the build -- through the setter or by assigning
+        # `params` -- means a new index (PCL lets the caller change it between two aligns of the same target)
+        if getattr(self, "_tgt_gate", None) != self.params.max_correspondence_distance:
+            self._tgt_dirty = True
         if self._tgt_dirty or self.ctx.icp_target_owner is not self:
+            self._tgt_gate = self.params.max_correspondence_distance
             if isinstance(self._tgt, DeviceCloud):
                 # (reuse_target_index: another ICP object of this context has just built the index of this very cloud)
                 if not (self.reuse_target_index and L.rsreg_icp_target_is_cloud(h, self._tgt.h, self.params.max_correspondence_distance)):

@@ -638,8 +638,13 @@ int rsreg_cloud_transform(rsreg_ctx *ctx, const rsreg_cloud *in, const float tra
     if (in->n) {
         RSREG_HIP(ctx, launch_records_transform(ctx->stream, in->buf.as<char>(), out->buf.as<char>(), (uint32_t)in->n, in->stride, to_mat34(T), 0));
     }
+    const rsreg::CloudBox moved_box = (in->box.valid && in->box_version == in->version) ? rsreg::transformed_box(in->box, transform) : rsreg::CloudBox{};
     out->version++;
     out->n = in->n; out->stride = in->stride; out->width = in->width; out->height = in->height; out->is_dense = in->is_dense;
+    if (moved_box.valid && rsreg::tunables().box_cache) {   // (a box around the moved points, not measured on them: CloudBox::exact)
+        out->box = moved_box;
+        out->box_version = out->version;
+    }
     return RSREG_OK;
 }
 
@@ -727,6 +732,14 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     RSREG_HIP(ctx, settle(out));
     const size_t stride = a->n ? a->stride : b->stride, na = a->n, nb = b->n, total = na + nb;
     const int dense = a->is_dense && b->is_dense;
+    // the box of the parts' union, when both parts have one (`target = aligned + target`, icp_edge_based_registration.hpp:119-120:
+    // the grown target's index then starts without a measuring launch and its round trip); taken before `out` changes
+    auto box_of = [](const rsreg_cloud *c) {
+        rsreg::CloudBox b = (c->box.valid && c->box_version == c->version) ? c->box : rsreg::CloudBox{};
+        if (c->n == 0) { b = rsreg::CloudBox{}; b.valid = true; b.nfin = 0; }
+        return b;
+    };
+    const rsreg::CloudBox merged_box = rsreg::union_box(box_of(a), box_of(b));
     if (out == a && out->buf.cap >= total * stride + 16) {
         if (nb) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.as<char>() + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
@@ -744,6 +757,10 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
     }
     out->version++;
     out->n = total; out->stride = stride; out->width = (uint32_t)total; out->height = 1; out->is_dense = dense;
+    if (merged_box.valid && total && rsreg::tunables().box_cache) {
+        out->box = merged_box;
+        out->box_version = out->version;
+    }
     return RSREG_OK;
 }
 
@@ -752,6 +769,19 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
 static void harvest_source_box(rsreg_ctx *ctx)
 {
     const rsreg_cloud *s = ctx->src_cloud;
+    // a small source was loaded by one launch that measured its box on the way (k_source_plain): the words are complete once
+    // the stamp behind them is this load's -- which it is as soon as anything queued behind the launch has been waited for
+    if (s && !ctx->src_pending && ctx->plain_box_seq && ctx->h_smisc.ptr) {
+        const uint32_t *hb = ctx->h_smisc.as<uint32_t>() + 48;
+        if (__atomic_load_n(&hb[7], __ATOMIC_ACQUIRE) == ctx->plain_box_seq) {
+            rsreg::CloudBox b;
+            for (int k = 0; k < 3; ++k) { b.mn[k] = rsreg::ordered_float(hb[k]); b.mx[k] = rsreg::ordered_float(hb[3 + k]); }
+            b.nfin = hb[6];
+            b.valid = true;
+            ctx->last_src_box = b;
+            ctx->plain_box_seq = 0;
+        }
+    }
     if (!s || ctx->src_pending || !ctx->last_src_box.valid) return;
     if (s->id == ctx->src_cloud_id && s->version == ctx->src_cloud_version) {
         s->box = ctx->last_src_box;
@@ -804,7 +834,7 @@ int rsreg_icp_set_source_cloud(rsreg_ctx *ctx, const rsreg_cloud *c)
     RSREG_HIP(ctx, settle(c));
     harvest_source_box(ctx);   // (of the load before this one, if an alignment has joined it)
     ctx->next_src_box.valid = false;
-    if (c->box.valid && c->box_version == c->version) ctx->next_src_box = c->box;
+    if (c->box.valid && c->box.exact && c->box_version == c->version) ctx->next_src_box = c->box;   // (a source's order is quantised from its box: a measured one only)
     int rc = rsreg_icp_set_source_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense);
     if (rc) {
         ctx->next_src_box.valid = false;
@@ -827,6 +857,7 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
         return fail(ctx, RSREG_ERR_STATE, "the source cloud was rewritten after rsreg_icp_set_source_cloud");
     RSREG_HIP(ctx, settle(aligned_out));
     int rc = rsreg_icp_align(ctx, guess, params, result, nullptr, 0);
+    if (!rc) harvest_source_box(ctx);   // (the alignment has been waited for: a small source's box is there; the aligned cloud below starts from it)
     if (rc || !aligned_out) return rc;
     const rsreg_cloud *src = ctx->src_cloud;
     if (aligned_out != src) RSREG_HIP(ctx, cloud_reserve(ctx, aligned_out->buf, src->n * src->stride + 16));
@@ -835,9 +866,14 @@ int rsreg_icp_align_cloud(rsreg_ctx *ctx, const float *guess, const rsreg_icp_pa
     if (src->n) {
         RSREG_HIP(ctx, launch_records_transform(ctx->stream, src->buf.as<char>(), aligned_out->buf.as<char>(), (uint32_t)src->n, src->stride, to_mat34(T), 1));
     }
+    const rsreg::CloudBox moved_box = (src->box.valid && src->box_version == src->version) ? rsreg::transformed_box(src->box, result->transform) : rsreg::CloudBox{};
     aligned_out->version++;
     aligned_out->n = src->n; aligned_out->stride = src->stride; aligned_out->width = src->width; aligned_out->height = src->height;
     aligned_out->is_dense = src->is_dense;
+    if (moved_box.valid && rsreg::tunables().box_cache) {
+        aligned_out->box = moved_box;
+        aligned_out->box_version = aligned_out->version;
+    }
     return RSREG_OK;
 }
 

@@ -455,6 +455,7 @@ int build_grid(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doubl
     for (int k = 0; k < 3; ++k) { ctx->last_tgt_box.mn[k] = mn[k]; ctx->last_tgt_box.mx[k] = mx[k]; }
     ctx->last_tgt_box.nfin = nfin;
     ctx->last_tgt_box.valid = n > 0;
+    ctx->last_tgt_box.exact = !(known.valid && !no_box_cache && n > 0) || known.exact;   // (measured just now, or what the handle knew)
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_sums.as<uint32_t>();
     const size_t misc_bytes = 16 * sizeof(uint32_t);
@@ -654,6 +655,12 @@ int join_source(rsreg_ctx *ctx)
         ctx->have_source = false;
         return rcw;
     }
+    if (ctx->src_plain) {
+        // one launch on the main stream, the caller's order, no merging: the number of queries IS the number of records, and
+        // whatever reads the working copy is queued behind the launch on the same stream -- no wait on the caller's thread
+        ctx->n_work = (uint32_t)ctx->n_source;
+        return RSREG_OK;
+    }
     RSREG_HIP(ctx, hipEventSynchronize(ctx->ev_src_done));
     ctx->n_work = ctx->h_smisc.as<uint32_t>()[32];
     return RSREG_OK;
@@ -680,9 +687,19 @@ int load_source_queue(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride
             // one launch, the caller's order -- on the MAIN stream: the streams of a process share a few hardware queues,
             // and a kernel on the source stream can find itself behind a 0.4 ms voxel filter of a side stream
             hipStream_t st = ctx->stream;
+            // (its box and finite count land in pinned words 48 .. 55 behind the stamp `seq`; the ticket word lives in a buffer of its
+            // own that is zero between launches)
+            const bool box_too = tunables().box_cache;
+            if (box_too && !ctx->d_plain_ticket.ptr) {
+                RSREG_HIP(ctx, ctx->d_plain_ticket.reserve(64));
+                RSREG_HIP(ctx, hipMemsetAsync(ctx->d_plain_ticket.ptr, 0, 64, st));
+            }
+            ctx->plain_box_seq = box_too ? ++ctx->plain_box_counter : 0u;
             k_source_plain<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_raw, stride, (uint32_t)n, ctx->d_src_all.as<float4>(), ctx->d_src.as<float4>(),
                                                                            ctx->d_perm.as<uint32_t>(), ctx->d_uniq_of.as<uint32_t>(),
-                                                                           ctx->d_first.as<uint32_t>(), d_misc + 12, h_misc + 32);
+                                                                           ctx->d_first.as<uint32_t>(), d_misc + 12, h_misc + 32,
+                                                                           box_too ? d_misc + 64 : nullptr, ctx->d_plain_ticket.as<uint32_t>(), h_misc + 48,
+                                                                           ctx->plain_box_seq);
             RSREG_HIP(ctx, hipGetLastError());
             RSREG_HIP(ctx, hipEventRecord(ctx->ev_src_done, st));
             return RSREG_OK;
@@ -830,6 +847,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     int rcj = join_source(ctx);   // (a load still in flight owns the buffers this one is about to fill)
     if (rcj) return rcj;
     ctx->last_src_box.valid = false;   // (of the load before this one: cloud.hip has taken it over by now)
+    ctx->plain_box_seq = 0;
     // the box of the cloud this source comes from, if its handle knows it: taken over -- or dropped -- here, on the caller's
     // thread, after the load before this one has been joined; the worker's job gets a copy
     const rsreg::CloudBox known = ctx->next_src_box;
@@ -878,6 +896,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
         RSREG_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         const bool no_worker = !tunables().worker;
         ctx->src_on_worker = false;
+        ctx->src_plain = source_is_small(n);
         if (no_worker || source_is_small(n)) {   // (a small source is one launch: not worth a hand-over)
             int rc = load_source_queue(ctx, d_raw, n, stride, known);
             if (rc) return rc;
@@ -1060,6 +1079,7 @@ int apply_filters(rsreg_ctx *ctx)
 
 int launch_search(rsreg_ctx *ctx)
 {
+    ctx->icp.idle_after_sums = false;   // (something is queued on the main stream from here on)
     IcpState &s = ctx->icp;
     {
         int rcr = ensure_restarted(ctx);
@@ -1117,6 +1137,7 @@ int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
     double *h = ctx->h_sums.as<double>();
     if (ctx->comm) RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_sums.ptr, RSREG_NUM_SUMS * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->icp.idle_after_sums = true;
     (void)target_counts(ctx, false);
     std::memcpy(sums, h, RSREG_NUM_SUMS * 8);
     return RSREG_OK;
@@ -1124,6 +1145,7 @@ int fetch_sums(rsreg_ctx *ctx, double *sums, bool global)
 
 int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
 {
+    ctx->icp.idle_after_sums = false;   // (something is queued on the main stream from here on)
     {
         int rcr = ensure_restarted(ctx);
         if (rcr) return rcr;
@@ -1384,6 +1406,7 @@ int build_schedule(rsreg_ctx *ctx, uint32_t n_tiles, bool first = false)
 // fused pass: applies the pending increment (if any), searches, gates and reduces
 int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop = false)
 {
+    ctx->icp.idle_after_sums = false;   // (something is queued on the main stream from here on)
     IcpState &s = ctx->icp;
     const uint32_t n = (uint32_t)ctx->n_work;
     const IcpDevState *dev = device_loop ? ctx->d_icp_state.as<IcpDevState>() : nullptr;
@@ -1539,6 +1562,7 @@ int run_device_loop(rsreg_ctx *ctx)
     }
     RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_icp_state.ptr, sizeof(IcpDevState), hipMemcpyDeviceToHost, ctx->stream));
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s.idle_after_sums = true;
     (void)target_counts(ctx, false);
     std::memcpy(s.sums_last, h->sums_last, sizeof(s.sums_last));
     s.ncorr = h->ncorr;
@@ -1559,6 +1583,7 @@ int run_device_loop(rsreg_ctx *ctx)
 
 int apply_pending_transform(rsreg_ctx *ctx)
 {
+    ctx->icp.idle_after_sums = false;   // (something is queued on the main stream from here on)
     IcpState &s = ctx->icp;
     {
         int rcr = ensure_restarted(ctx);
@@ -1737,7 +1762,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         ctx->recip = nullptr;
     }
     DevBuf *bufs[] = {&ctx->d_tgt_raw, &ctx->d_tgt_sorted, &ctx->d_table, &ctx->d_keys, &ctx->d_keys_alt, &ctx->d_vals,
-                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp,
+                      &ctx->d_vals_alt, &ctx->d_flags, &ctx->d_scan, &ctx->d_cellpos, &ctx->d_dense, &ctx->d_pos_of, &ctx->d_sched, &ctx->d_brick, &ctx->d_perm, &ctx->d_tmp, &ctx->d_plain_ticket,
                       &ctx->d_misc, &ctx->d_src_raw, &ctx->d_src_all, &ctx->d_uniq_of, &ctx->d_first, &ctx->d_src, &ctx->d_cur, &ctx->d_corr_pos, &ctx->d_corr_d2, &ctx->d_seed,
                       &ctx->d_partials, &ctx->d_sums, &ctx->d_icp_state, &ctx->d_corr_w, &ctx->d_recip_pts, &ctx->d_vox_in, &ctx->d_vox_out, &ctx->d_vox_cent, &ctx->d_ndt_vox, &ctx->d_ndt_src, &ctx->d_ndt_trans,
                       &ctx->d_ndt_partials, &ctx->d_ndt_out, &ctx->d_ndt_ctl, &ctx->d_ndt_seg, &ctx->d_comm, &ctx->d_skeys, &ctx->d_skeys_alt, &ctx->d_svals,
@@ -2060,7 +2085,8 @@ int icp_end(rsreg_ctx *ctx, rsreg_icp_result *result, void *aligned_out, size_t 
         }
         ctx->host_timing.aligned_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (the usual end of an alignment: the last thing this thread did was wait for the sums, and nothing has been queued since)
+    if (!(s.idle_after_sums && !(aligned_out && n))) RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)target_counts(ctx, false);
 #ifdef RSREG_DIAG
     if (const char *sd_path = tunables().dump_seed) {   // dev: the position every query matched last, and the queries

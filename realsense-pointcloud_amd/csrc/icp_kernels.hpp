@@ -120,13 +120,7 @@ __device__ __forceinline__ uint32_t float_ordered(float f)
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-inline float ordered_float(uint32_t u)
-{
-    uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float f;
-    memcpy(&f, &v, 4);
-    return f;
-}
+using rsreg::ordered_float;   // (the host's way back: rsreg_ctx.hpp)
 
 // ------------------------------------------------------------------------------ grid build
 // per block: partial[0..2] = min (ordered uint), [3..5] = max, [6] = number of finite points
@@ -462,23 +456,101 @@ __global__ __launch_bounds__(kBlock) void k_source_unique(const float4 *src_all,
 // neither buys the search anything -- 50 k raw frame, 36 k edge cloud: the same 30.1 us and 13 us per launch either way,
 // profiles/r03_small_sources.txt -- and together they are 17 launches and a round trip to the host):
 // src_all[j] = src[j] = {xyz, 1 or 0 (non-finite)}, perm / uniq_of / first = identity, count = n.
+// On its way the launch measures the cloud's bounding box and finite count (what the sorted load gets from k_bbox and a round
+// trip): a partial per workgroup, the workgroup that finishes last (ticket: zero before the launch, zero again after it) folds
+// them and leaves mn[3] | mx[3] (ordered uints) | count | `seq` in pinned host words -- nobody waits for them; the cloud handle
+// picks them up once the alignment that followed has been waited for (cloud.hip: harvest_source_box), so that what is made of
+// this cloud -- the aligned cloud, the target it is appended to -- starts with a box (rsreg_ctx.hpp: CloudBox).
 __global__ __launch_bounds__(kBlock) void k_source_plain(const char *raw, size_t stride, uint32_t n, float4 *src_all, float4 *src,
-                                                         uint32_t *perm, uint32_t *uniq_of, uint32_t *first, uint32_t *count, uint32_t *host_count)
+                                                         uint32_t *perm, uint32_t *uniq_of, uint32_t *first, uint32_t *count, uint32_t *host_count,
+                                                         uint32_t *box_partial, uint32_t *box_ticket, uint32_t *host_box, uint32_t seq)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const float *p = rec_xyz(raw, stride, j);
-    const float x = p[0], y = p[1], z = p[2];
-    const float4 s = make_float4(x, y, z, finite3(x, y, z) ? 1.0f : 0.0f);
-    src_all[j] = s;
-    src[j] = s;
-    perm[j] = j;
-    uniq_of[j] = j;
-    first[j] = j;
-    if (j == n - 1) {
-        first[n] = n;
-        count[0] = n;
-        host_count[0] = n;   // (pinned host memory: read at the join)
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    uint32_t cnt = 0;
+    if (j < n) {
+        const float *p = rec_xyz(raw, stride, j);
+        const float x = p[0], y = p[1], z = p[2];
+        const bool fin = finite3(x, y, z);
+        const float4 s = make_float4(x, y, z, fin ? 1.0f : 0.0f);
+        src_all[j] = s;
+        src[j] = s;
+        perm[j] = j;
+        uniq_of[j] = j;
+        first[j] = j;
+        if (j == n - 1) {
+            first[n] = n;
+            count[0] = n;
+            host_count[0] = n;   // (pinned host memory: read at the join)
+        }
+        if (fin) { mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z; cnt = 1; }
+    }
+    if (!box_partial) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
+        }
+        cnt += __shfl_down(cnt, off);
+    }
+    __shared__ float smn[kBlock / 64][3], smx[kBlock / 64][3];
+    __shared__ uint32_t scnt[kBlock / 64];
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k) { smn[wave][k] = mn[k]; smx[wave][k] = mx[k]; }
+        scnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], smn[w][k]); mx[k] = fmaxf(mx[k], smx[w][k]); }
+            cnt += scnt[w];
+        }
+        uint32_t *out = box_partial + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 3; ++k) {
+            __hip_atomic_store(&out[k], float_ordered(mn[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&out[3 + k], float_ordered(mx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&out[6], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (written through and acknowledged, then counted: icp_dense.hpp's hand-over)
+        s_last = __hip_atomic_fetch_add(box_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup: one partial per thread (at most 256 workgroups of 256 records: kPlainSourceMax), folded as above
+    uint32_t omn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, omx[3] = {0, 0, 0}, ocnt = 0;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+        const uint32_t *q = box_partial + (size_t)b * 8;
+        const uint32_t c = __hip_atomic_load(&q[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c) {
+            for (int k = 0; k < 3; ++k) {
+                omn[k] = min(omn[k], __hip_atomic_load(&q[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                omx[k] = max(omx[k], __hip_atomic_load(&q[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            ocnt += c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; ++k) { omn[k] = min(omn[k], __shfl_down(omn[k], off)); omx[k] = max(omx[k], __shfl_down(omx[k], off)); }
+        ocnt += __shfl_down(ocnt, off);
+    }
+    __shared__ uint32_t sm[kBlock / 64][8];
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k) { sm[wave][k] = omn[k]; sm[wave][3 + k] = omx[k]; }
+        sm[wave][6] = ocnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            for (int k = 0; k < 3; ++k) { omn[k] = min(omn[k], sm[w][k]); omx[k] = max(omx[k], sm[w][3 + k]); }
+            ocnt += sm[w][6];
+        }
+        *box_ticket = 0u;
+        for (int k = 0; k < 3; ++k) { host_box[k] = omn[k]; host_box[3 + k] = omx[k]; }
+        host_box[6] = ocnt;
+        __threadfence_system();
+        __hip_atomic_store(&host_box[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the stamp last: the words in front of it are complete)
     }
 }
 

@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -84,11 +85,67 @@ struct PinnedBuf {
 // Bounding box and number of the finite points of a cloud: what an index build or a source load starts from (one kernel
 // pair and a round trip to the host).  A cloud handle keeps the box of its records as they are (cloud.hip: version), so a
 // frame that was the source of one pair and is the target of the next is not measured twice.
+// the way back from the order-preserving uint the kernels keep float minima / maxima in (icp_kernels.hpp: float_ordered)
+inline float ordered_float(uint32_t u)
+{
+    const uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+
 struct CloudBox {
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     uint32_t nfin = 0;
     bool valid = false;
+    // false: a box that CONTAINS the finite points without being measured on them (the transformed corners of a measured box,
+    // a union with such a box).  Good enough for a target's index (the grid's origin and extent; the search is exact whatever
+    // they are), not for a source's spatial order (its keys are quantised from the box: another box, another order of the sums)
+    bool exact = true;
 };
+
+// a box around what `T` makes of everything inside `b` (eight corners, in double, widened by a margin far above the float
+// rounding of the per-point transform): cloud.hip hands it to the output of a transform / an alignment
+inline CloudBox transformed_box(const CloudBox &b, const float *T /* 4x4 column-major */)
+{
+    CloudBox o = b;
+    if (!b.valid || b.nfin == 0) return o;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, big = 0;
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {(c & 1) ? b.mx[0] : b.mn[0], (c & 2) ? b.mx[1] : b.mn[1], (c & 4) ? b.mx[2] : b.mn[2]};
+        for (int r = 0; r < 3; ++r) {
+            const double v = (double)T[r] * p[0] + (double)T[4 + r] * p[1] + (double)T[8 + r] * p[2] + (double)T[12 + r];
+            lo[r] = v < lo[r] ? v : lo[r];
+            hi[r] = v > hi[r] ? v : hi[r];
+            big = std::fabs(v) > big ? std::fabs(v) : big;
+        }
+    }
+    const double margin = 1e-5 * big + 1e-6;   // (float rounding of R x + t is ~1e-7 of the coordinates' size)
+    for (int r = 0; r < 3; ++r) {
+        o.mn[r] = (float)(lo[r] - margin);
+        o.mx[r] = (float)(hi[r] + margin);
+        if (!(o.mn[r] == o.mn[r]) || !(o.mx[r] == o.mx[r]) || std::fabs(o.mn[r]) > 1e30f || std::fabs(o.mx[r]) > 1e30f) o.valid = false;   // (a transform that is not finite)
+    }
+    o.exact = false;
+    return o;
+}
+
+inline CloudBox union_box(const CloudBox &a, const CloudBox &b)
+{
+    if (!a.valid || !b.valid) return CloudBox{};
+    if (a.nfin == 0) return b;
+    if (b.nfin == 0) return a;
+    CloudBox o;
+    for (int r = 0; r < 3; ++r) {
+        o.mn[r] = a.mn[r] < b.mn[r] ? a.mn[r] : b.mn[r];
+        o.mx[r] = a.mx[r] > b.mx[r] ? a.mx[r] : b.mx[r];
+    }
+    const unsigned long long nf = (unsigned long long)a.nfin + b.nfin;
+    o.nfin = (uint32_t)nf;
+    o.valid = nf < 0xfffffff0ull;
+    o.exact = a.exact && b.exact;
+    return o;
+}
 
 // Uniform-grid index over the target cloud, all device-resident (layout: DESIGN.md §3).
 struct GridParams {
@@ -131,6 +188,7 @@ struct IcpState {
     bool sched_ready = false;      // d_sched holds a tile schedule for this alignment
     uint32_t sched_items = 0;      // workgroups of a scheduled launch
     bool sched_carried = false;    // ... whose schedule an earlier alignment of the context built
+    bool idle_after_sums = false;  // the caller's thread has waited for the main stream (the sums) and queued nothing since: rsreg_icp_end need not wait again
 };
 
 }  // namespace rsreg
@@ -189,6 +247,9 @@ struct rsreg_ctx {
     hipStream_t stream_src = nullptr;
     hipEvent_t ev_src_done = nullptr, ev_main = nullptr;
     bool src_pending = false;
+    rsreg::DevBuf d_plain_ticket; // k_source_plain's ticket word (zero between launches)
+    uint32_t plain_box_seq = 0, plain_box_counter = 0;   // the stamp the pending plain load leaves behind its box in h_smisc[48 .. 55] (0: none)
+    bool src_plain = false;       // the pending load is k_source_plain on the MAIN stream (every record a query of its own): nothing to wait for at the join
     bool src_on_worker = false;   // ... and its launches are being queued by the context's worker thread right now
     rsreg::SourceWorker *src_worker = nullptr;   // (created with the first source load; RSREG_NO_WORKER=1: never, the load runs on the caller's thread)
     // everything of a pending source load has been queued on stream_src (so that ev_src_done is the event of THIS load)

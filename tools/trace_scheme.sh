@@ -62,4 +62,37 @@ with open(O + "/sequence.txt", "w") as f:
             k = kname[r['Correlation_Id']]
             extra = ' %-50s gpu %8.1f..%8.1f (%.1f us)' % (short(k[0]), (k[1] - t0) / 1e3, (k[2] - t0) / 1e3, (k[2] - k[1]) / 1e3)
         f.write("%9.1f us tid %s %-22s %7.1f us%s\n" % ((s - t0) / 1e3, r['Thread_Id'][-3:], fn, (e - s) / 1e3, extra))
+# gaps.txt: the same window by thread and API call, the GPU's busy share, the caller's thread outside HIP
+w0, w1 = int(api[start]['Start_Timestamp']), int(api[end - 1]['End_Timestamp'])
+ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in ker if int(r['End_Timestamp']) > w0 and int(r['Start_Timestamp']) < w1)
+busy, cur_s, cur_e = 0, None, None
+for a, b in ks:
+    a, b = max(a, w0), min(b, w1)
+    if cur_e is None or a > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = a, b
+    else:
+        cur_e = max(cur_e, b)
+if cur_e is not None: busy += cur_e - cur_s
+with open(O + "/gaps.txt", "w") as f:
+    f.write("window: %.0f us (about three frames of the last run); kernel launches %d; GPU busy (union of the kernels' intervals) %.0f us = %.0f %% of the window\n" %
+            ((w1 - w0) / 1e3, len(ks), busy / 1e3, 100.0 * busy / (w1 - w0)))
+    by = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in api[start:end]:
+        if r['Function'] in quiet: continue
+        c = by[r['Thread_Id']][r['Function']]
+        c[0] += 1
+        c[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    for tid, d in sorted(by.items(), key=lambda kv: -sum(c[0] for c in kv[1].values())):
+        f.write("thread ..%s%s: %d API calls\n" % (tid[-3:], " (the caller's thread)" if tid == main else " (a worker of the context)", sum(c[0] for c in d.values())))
+        for fn, c in sorted(d.items(), key=lambda kv: -kv[1][1])[:6]:
+            f.write("    %-26s %3d calls %8.1f us\n" % (fn, c[0], c[1]))
+    out, prev_end = 0.0, None
+    for r in api[start:end]:
+        if r['Thread_Id'] != main: continue
+        s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if prev_end is not None and s_ - prev_end > 30000: out += (s_ - prev_end) / 1e3
+        prev_end = e_
+    f.write("caller's thread outside HIP for > 30 us at a time: %.0f us\n" % out)
 PY
+cat $O/gaps.txt

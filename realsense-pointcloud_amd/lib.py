@@ -11,9 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 # RSREG_DIAG=1 (dev tools: per-launch times, wave stamps, dumps): the diagnostic build of the library, librsreg_diag.so, compiled
 # with -DRSREG_DIAG -- the shipped librsreg.so has no switch that writes a file or changes a result (csrc/tunables.hpp).
-# RSREG_SO (dev): an experiment build of the library.
+# RSREG_SO (dev, honoured only together with RSREG_DIAG=1): an experiment build of the library.  Without RSREG_DIAG the Python layer
+# loads the in-tree librsreg.so and nothing else -- an environment variable alone cannot point the product at another library.
 DIAG = os.environ.get("RSREG_DIAG", "") == "1"
-SO_PATH = os.environ.get("RSREG_SO") or os.path.join(_HERE, "librsreg_diag.so" if DIAG else "librsreg.so")
+SO_PATH = (os.environ.get("RSREG_SO") if DIAG else None) or os.path.join(_HERE, "librsreg_diag.so" if DIAG else "librsreg.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["icp.hip", "ndt.hip", "voxel.hip", "comm.cpp", "voxel_host.cpp", "pcd_host.cpp", "cloud.hip", "edges.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) if os.path.isdir(CSRC) else []
@@ -127,7 +128,7 @@ def build(force=False, verbose=False, out=SO_PATH, obj_dir=None):
     of its wall time, and an edit of one file recompiles that file only."""
     if not force and out == SO_PATH and not needs_build():
         return SO_PATH
-    if out == SO_PATH and os.environ.get("RSREG_SO"):
+    if out == SO_PATH and DIAG and os.environ.get("RSREG_SO"):
         raise RuntimeError("RSREG_SO names a library that is missing or older than the sources: build it where it came from")
     from concurrent.futures import ThreadPoolExecutor
 

@@ -167,6 +167,16 @@ int rsreg_device_count(int *count);
 int rsreg_ctx_create(int device_id, void *stream, rsreg_ctx **out);
 int rsreg_ctx_destroy(rsreg_ctx *ctx);
 int rsreg_ctx_synchronize(rsreg_ctx *ctx);
+/* What a frame loop is about to need, requested ahead of the need (engine extra; the schemes call it when registration() starts:
+ * types.hpp:19, main.cpp:85 -- the first registration() of a process otherwise creates these one by one on its critical
+ * path): the context's upload / source / download streams and, with RSREG_PREPARE_SIDE_STREAMS, the three side streams
+ * (hardware queues: ~12 ms each for a process's first four), the pinned staging buffers of the upload and download workers
+ * for frames of `frame_bytes` (0: none), and one device buffer of `model_bytes` for a cloud that will grow to that size
+ * (0: none; the merged model of IncrementalICP then grows without re-allocation).  Returns at once: a thread of the context
+ * makes them while the caller goes on; every entry point that needs one of them waits for that thread first.  Optional:
+ * without it everything is created at first use, as before. */
+#define RSREG_PREPARE_SIDE_STREAMS 1u
+int rsreg_ctx_prepare(rsreg_ctx *ctx, size_t frame_bytes, size_t model_bytes, unsigned flags);
 int rsreg_ctx_set_profiling(rsreg_ctx *ctx, int enabled);
 
 void rsreg_icp_params_default(rsreg_icp_params *p);

@@ -224,6 +224,8 @@ class Context {
     Context &operator=(const Context &) = delete;
     rsreg_ctx *get() const { return ctx_; }
     void wait_downloads() { check(rsreg_ctx_wait_downloads(ctx_), ctx_); }   // every DeviceCloud::download_async of this context has landed
+    // what a frame loop is about to need, made on a thread of the context while the caller goes on (rsreg_ctx_prepare)
+    void prepare(size_t frame_bytes, size_t model_bytes, bool side_streams) { check(rsreg_ctx_prepare(ctx_, frame_bytes, model_bytes, side_streams ? RSREG_PREPARE_SIDE_STREAMS : 0u), ctx_); }
     // A context holds ONE ICP target index, ONE ICP source and ONE NDT voxel grid.  The object that
     // uploaded each of them last is remembered here, so that a second registration object sharing
     // the context (e.g. the default one) re-uploads its own clouds instead of silently using another's.

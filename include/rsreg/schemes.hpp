@@ -199,6 +199,11 @@ class IncrementalICP : public RegistrationScheme {
     rgb_point_cloud_pointer registration_device(std::vector<rgb_point_cloud_pointer> &clouds)
     {
         clock_start();
+        {   // the streams, the pinned staging and the model's device buffer are made while this thread sets the loop up
+            size_t largest = 0, total = 0;
+            for (auto &c : clouds) { largest = std::max(largest, c->size()); total += c->size(); }
+            Context::Default()->prepare(largest * sizeof(rgb_point), total * sizeof(rgb_point), true);
+        }
         ApproximateVoxelGrid<rgb_point> voxel;   // leaf never set: PCL's 1 m default applies
         IterativeClosestPoint<rgb_point, rgb_point> icp;
         detail::reference_icp_parameters(icp);
@@ -519,6 +524,11 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     {
         const size_t n_frames = pairs ? pairs->size() : frames->size();
         clock_start();
+        {   // the streams and the pinned staging are made while this thread sets the loop up (the merged cloud is streamed home: no model buffer)
+            size_t largest = 0;
+            for (size_t k = 0; k < n_frames; ++k) largest = std::max(largest, pairs ? (*pairs)[k].second->size() : (*frames)[k]->size());
+            Context::Default()->prepare(largest * sizeof(rgb_point), 0, true);
+        }
         say_header();
         if (use_imu) assert(n_frames == thetas.size());
         IterativeClosestPoint<rgb_point, rgb_point> icp;

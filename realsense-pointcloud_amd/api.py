@@ -65,6 +65,11 @@ class Context:
     def synchronize(self):
         _l.check(_l.lib().rsreg_ctx_synchronize(self.h), self.h)
 
+    def prepare(self, frame_bytes=0, model_bytes=0, side_streams=False):
+        """What a frame loop is about to need -- streams, pinned staging for frames of `frame_bytes`, a device buffer a model
+        can grow to `model_bytes` in -- made on a thread of the context while the caller goes on (rsreg_ctx_prepare)."""
+        _l.check(_l.lib().rsreg_ctx_prepare(self.h, int(frame_bytes), int(model_bytes), 1 if side_streams else 0), self.h)
+
     def wait_downloads(self):
         """Every DeviceCloud.download_async of this context has landed in its host array when this returns."""
         _l.check(_l.lib().rsreg_ctx_wait_downloads(self.h), self.h)

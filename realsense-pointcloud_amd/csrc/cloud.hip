@@ -173,16 +173,21 @@ void cloud_drop(rsreg_ctx *ctx, DevBuf &b)
 
 // like DevBuf::reserve (the contents are not kept), through the pool: the smallest kept buffer that is large enough
 // and not more than twice too large
-hipError_t cloud_reserve(rsreg_ctx *ctx, DevBuf &b, size_t bytes)
+// `growing`: the buffer of a cloud that keeps growing (`model += moved`): the LARGEST kept buffer that fits, however large --
+// rsreg_ctx_prepare may have left one there for the whole model
+hipError_t cloud_reserve(rsreg_ctx *ctx, DevBuf &b, size_t bytes, bool growing = false)
 {
     if (bytes <= b.cap) return hipSuccess;
+    ctx->prep_join();   // (rsreg_ctx_prepare may be holding a buffer for the pool)
     cloud_drop(ctx, b);
     CloudPool &pool = ctx->cloud_pool;
     size_t best = pool.slots.size();
-    for (size_t i = 0; i < pool.slots.size(); ++i)
-        if (pool.slots[i].cap >= bytes && pool.slots[i].cap <= 2 * bytes + (1u << 20) &&
-            (best == pool.slots.size() || pool.slots[i].cap < pool.slots[best].cap))
+    for (size_t i = 0; i < pool.slots.size(); ++i) {
+        if (pool.slots[i].cap < bytes) continue;
+        if (growing ? (best == pool.slots.size() || pool.slots[i].cap > pool.slots[best].cap)
+                    : (pool.slots[i].cap <= 2 * bytes + (1u << 20) && (best == pool.slots.size() || pool.slots[i].cap < pool.slots[best].cap)))
             best = i;
+    }
     if (best != pool.slots.size()) {
         b.ptr = pool.slots[best].ptr;
         b.cap = pool.slots[best].cap;
@@ -240,7 +245,61 @@ void cloud_pool_clear(rsreg_ctx *ctx)
 }
 }  // namespace rsreg
 
+void rsreg_ctx::prep_join()
+{
+    if (!prep_thread.joinable()) return;
+    prep_thread.join();
+    if (prep_model.ptr) {   // (the pool is the caller's thread's: the buffer joins it here)
+        cloud_pool.slots.push_back({prep_model.ptr, prep_model.cap});
+        cloud_pool.held += prep_model.cap;
+        prep_model.ptr = nullptr;
+        prep_model.cap = 0;
+    }
+}
+
 extern "C" {
+
+// What the frame loops of the schemes need besides the main stream, requested AHEAD of the need (incremental_icp.hpp:51-66,
+// icp_edge_based_registration.hpp:71-123: the first registration() of a process -- main.cpp:85 -- otherwise creates them one by
+// one on its critical path): the upload / download / source / side streams (the process's hardware queues: 12 ms each for
+// the first four, profiles/r06_cold_run.txt), the pinned staging buffers of the upload and download workers for frames of
+// `frame_bytes`, and ONE device buffer of `model_bytes` for a cloud that grows to that size (the merged model: no
+// re-allocation while it grows).  Returns at once; a thread of the context makes them while the caller goes on (reading its
+// frames, allocating its result), and every entry point that would create one of them waits for that thread first.
+int rsreg_ctx_prepare(rsreg_ctx *ctx, size_t frame_bytes, size_t model_bytes, unsigned flags)
+{
+    if (!ctx) return RSREG_ERR_INVALID_ARG;
+    ctx->prep_join();
+    ctx->prep_rc = 0;
+    const bool want_side = (flags & 1u) != 0;
+    ctx->prep_thread = std::thread([ctx, frame_bytes, model_bytes, want_side] {
+        auto ok = [&](hipError_t e) { if (e != hipSuccess && !ctx->prep_rc) ctx->prep_rc = (int)e; return e == hipSuccess; };
+        if (!ok(hipSetDevice(ctx->device))) return;
+        // in the order a frame loop needs them: the upload's stream and staging, the source's stream, the download's, the side sets'
+        if (!ctx->stream_copy) {
+            if (!ok(hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking))) return;
+            ok(hipEventCreateWithFlags(&ctx->ev_copy_gate, hipEventDisableTiming));
+            for (hipEvent_t &e : ctx->ev_up) ok(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (frame_bytes) { ok(ctx->h_up[0].reserve(frame_bytes)); ok(ctx->h_up[1].reserve(frame_bytes)); }
+        if (!ctx->stream_src) {
+            if (!ok(hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking))) return;
+            ok(hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
+            ok(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+        }
+        if (!ctx->stream_down) {
+            if (!ok(hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking))) return;
+            ok(hipEventCreateWithFlags(&ctx->ev_down_gate, hipEventDisableTiming));
+            for (hipEvent_t &e : ctx->ev_down) ok(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (frame_bytes) for (auto &h : ctx->h_down) ok(h.reserve(frame_bytes));
+        if (want_side)
+            for (auto &ss : ctx->side_sets)
+                if (!ss.stream) ok(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+        if (model_bytes) ok(ctx->prep_model.reserve(model_bytes + 16));
+    });
+    return RSREG_OK;
+}
 
 int rsreg_cloud_create(rsreg_ctx *ctx, rsreg_cloud **out)
 {
@@ -310,6 +369,7 @@ int upload_on_worker(rsreg_cloud *c, const void *points, size_t n, size_t stride
     RSREG_HIP(ctx, settle(c));
     RSREG_HIP(ctx, cloud_reserve(ctx, c->buf, n * stride + 16));
     if (n) {
+        ctx->prep_join();
         if (!ctx->stream_copy) {
             RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
             RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy_gate, hipEventDisableTiming));
@@ -493,6 +553,7 @@ int side_begin(rsreg_ctx *ctx, int *set_out)
     const int set = ctx->side_next;
     ctx->side_next = (ctx->side_next + 1) % rsreg_ctx::kSideSets;
     rsreg_ctx::SideSet &ss = ctx->side_sets[set];
+    ctx->prep_join();
     if (!ss.stream) RSREG_HIP(ctx, hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
     if (!ctx->ev_side_gate) RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
     if (!ctx->side_worker) ctx->side_worker = new rsreg::TicketWorker();
@@ -666,10 +727,13 @@ int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, settle(c));
     if (!c->n) return RSREG_OK;
+    ctx->prep_join();
     if (!ctx->stream_down) {
         RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking));
         RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_down_gate, hipEventDisableTiming));
         for (hipEvent_t &e : ctx->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!ctx->down_worker) {
         ctx->down_worker = new rsreg::DownloadWorker();
         ctx->down_worker->wait_ready = [](const rsreg::DownloadWorker::Job &j) -> int {
             hipError_t e = hipSetDevice(j.device);
@@ -744,7 +808,7 @@ int rsreg_cloud_concat(rsreg_ctx *ctx, const rsreg_cloud *a, const rsreg_cloud *
         if (nb) RSREG_HIP(ctx, hipMemcpyAsync(out->buf.as<char>() + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         DevBuf fresh;
-        RSREG_HIP(ctx, cloud_reserve(ctx, fresh, total * stride + (out == a ? total * stride / 2 : 0) + 16));   // a growing model: room for the next frames
+        RSREG_HIP(ctx, cloud_reserve(ctx, fresh, total * stride + (out == a ? total * stride / 2 : 0) + 16, out == a));   // a growing model: room for the next frames
         hipError_t e = hipSuccess;
         if (na) e = hipMemcpyAsync(fresh.ptr, a->buf.ptr, na * stride, hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess && nb) e = hipMemcpyAsync(static_cast<char *>(fresh.ptr) + na * stride, b->buf.ptr, nb * stride, hipMemcpyDeviceToDevice, ctx->stream);

@@ -852,6 +852,7 @@ int load_source(rsreg_ctx *ctx, const char *d_raw, size_t n, size_t stride)
     // thread, after the load before this one has been joined; the worker's job gets a copy
     const rsreg::CloudBox known = ctx->next_src_box;
     ctx->next_src_box.valid = false;
+    ctx->prep_join();
     if (!ctx->stream_src) {
         RSREG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_src, hipStreamNonBlocking));
         RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_src_done, hipEventDisableTiming));
@@ -1739,6 +1740,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
 {
     if (!ctx) return RSREG_OK;
     (void)hipSetDevice(ctx->device);
+    ctx->prep_join();   // (rsreg_ctx_prepare's thread: what it made is released with everything else below)
     // The helper threads go first, in the order of who waits for whom -- a queued side job waits for the upload worker
     // (side_wait_input), an upload or a download for nothing of the others -- and every stream they fed is drained before
     // a buffer, an event or a stream is released.

@@ -343,6 +343,12 @@ struct rsreg_ctx {
     rsreg::PinnedBuf h_ndt;
 
     // ---- RCCL
+    // rsreg_ctx_prepare: what a frame loop is about to need, made on a thread of its own while the caller goes on; whoever is
+    // about to create one of these lazily joins that thread first (prep_join) and finds them there
+    std::thread prep_thread;
+    rsreg::DevBuf prep_model;     // a device buffer for the merged model, handed to the cloud pool at the join
+    int prep_rc = 0;
+    void prep_join();
     std::thread records_copy;     // rsreg_icp_align_records: the caller's source records on their way into aligned_out (joined by icp_end)
     void *comm = nullptr;         // ncclComm_t
     int rank = 0, nranks = 1;

@@ -25,7 +25,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/rsreg.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "rsreg_version", "rsreg_status_string", "rsreg_last_error", "rsreg_device_count",
-    "rsreg_ctx_create", "rsreg_ctx_destroy", "rsreg_ctx_synchronize", "rsreg_ctx_set_profiling",
+    "rsreg_ctx_create", "rsreg_ctx_destroy", "rsreg_ctx_synchronize", "rsreg_ctx_prepare", "rsreg_ctx_set_profiling",
     "rsreg_icp_params_default", "rsreg_icp_params_reference", "rsreg_ndt_params_default",
     "rsreg_ndt_params_reference", "rsreg_icp_set_target", "rsreg_icp_set_target_device",
     "rsreg_icp_set_source", "rsreg_icp_set_source_device", "rsreg_icp_align", "rsreg_icp_align_records", "rsreg_icp_begin",
@@ -197,6 +197,7 @@ def lib():
     L.rsreg_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.rsreg_ctx_destroy.argtypes = [vp]
     L.rsreg_ctx_synchronize.argtypes = [vp]
+    L.rsreg_ctx_prepare.argtypes = [vp, sz, sz, C.c_uint]
     L.rsreg_ctx_set_profiling.argtypes = [vp, i32]
     for f in ("rsreg_icp_params_default", "rsreg_icp_params_reference"):
         getattr(L, f).argtypes = [C.POINTER(IcpParams)]

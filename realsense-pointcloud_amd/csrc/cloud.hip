@@ -272,6 +272,9 @@ int rsreg_ctx_prepare(rsreg_ctx *ctx, size_t frame_bytes, size_t model_bytes, un
     ctx->prep_join();
     ctx->prep_rc = 0;
     const bool want_side = (flags & 1u) != 0;
+    // (a second registration() of the process: the model's buffer of the first is in the pool already)
+    for (const CloudPool::Slot &sl : ctx->cloud_pool.slots)
+        if (sl.cap >= model_bytes + 16) model_bytes = 0;
     ctx->prep_thread = std::thread([ctx, frame_bytes, model_bytes, want_side] {
         auto ok = [&](hipError_t e) { if (e != hipSuccess && !ctx->prep_rc) ctx->prep_rc = (int)e; return e == hipSuccess; };
         if (!ok(hipSetDevice(ctx->device))) return;

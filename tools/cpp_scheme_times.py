@@ -25,7 +25,7 @@ with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "f%02d.pcd" % k)
         cloud_io.save_pcd(p, synth.render_frame(k, size, "bench"), binary=True)
         paths.append(p)
-    for mode in ("incremental", "icp_edge", "ndt_edge"):
+    for mode in os.environ.get("RSREG_SCHEME_MODES", "incremental icp_edge ndt_edge").split():
         for host_loop in ("0", "1"):
             env = dict(os.environ, RSREG_SCHEME_TIME=os.environ.get("RSREG_SCHEME_REPS", "3") if host_loop == "0" else "2", RSREG_SCHEME_HOST_LOOP=host_loop)
             r = subprocess.run([exe, mode, os.path.join(d, "out_" + mode)] + paths, env=env, stderr=subprocess.PIPE, text=True, check=True)

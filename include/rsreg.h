@@ -173,8 +173,9 @@ int rsreg_ctx_synchronize(rsreg_ctx *ctx);
  * (hardware queues: ~12 ms each for a process's first four), the pinned staging buffers of the upload and download workers
  * for frames of `frame_bytes` (0: none), and one device buffer of `model_bytes` for a cloud that will grow to that size
  * (0: none; the merged model of IncrementalICP then grows without re-allocation).  Returns at once: a thread of the context
- * makes them while the caller goes on; every entry point that needs one of them waits for that thread first.  Optional:
- * without it everything is created at first use, as before. */
+ * makes them while the caller goes on; every entry point that needs one of them waits for that thread first.  Call it while no
+ * upload or download of the context is in flight (between registrations).  Optional: without it everything is created at first
+ * use, as before. */
 #define RSREG_PREPARE_SIDE_STREAMS 1u
 int rsreg_ctx_prepare(rsreg_ctx *ctx, size_t frame_bytes, size_t model_bytes, unsigned flags);
 int rsreg_ctx_set_profiling(rsreg_ctx *ctx, int enabled);

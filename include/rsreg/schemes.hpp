@@ -388,8 +388,10 @@ class ChainRegistrar {
                 cv.notify_all();
             }
         };
+        // every context gets a thread of its own; the caller's thread brings the frames in (they arrive in order: a worker starts on
+        // pair k as soon as frames k - 1 and k are there, while the later frames are still on the link)
         std::vector<std::thread> th;
-        for (size_t w = 1; w < in_flight_; ++w) th.emplace_back(work, w);
+        for (size_t w = 0; w < in_flight_; ++w) th.emplace_back(work, w);
         std::string home_error;
         try {
             for (size_t k = 0; k < n; ++k) {
@@ -404,7 +406,6 @@ class ChainRegistrar {
             failed = true;
             cv.notify_all();
         }
-        work(0);   // the caller's thread drives a context too
         for (auto &t : th) t.join();
         if (!home_error.empty()) throw Error(RSREG_ERR_HIP, home_error);
         for (const std::string &e : errors)

@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("env", [{"RSREG_FORCE_HASH": "1"},
-                                 {"RSREG_DENSE_MAX_CELLS": "2000000"}],
-                         ids=["brick-hash", "dense-only-when-small"])
+                                 {"RSREG_DENSE_MAX_CELLS": "2000000"},
+                                 # round 6: the sort-based builds run on the library's own 64-bit radix sort and prefix sums
+                                 # (csrc/osort.hpp, csrc/oscan.hpp; rocPRIM's until then)
+                                 {"RSREG_COUNT_SORT": "0", "RSREG_KEYS64": "1"},
+                                 {"RSREG_COUNT_SORT": "0", "RSREG_SCAN_APART": "1", "RSREG_FULL_TABLE": "1"}],
+                         ids=["brick-hash", "dense-only-when-small", "sorted-build-64-bit-keys", "sorted-build-scans-apart-full-table"])
 def test_parity_suite_on_alternative_index_paths(env):
     e = dict(os.environ)
     e.update(env)

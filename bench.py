@@ -122,10 +122,14 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
         def collect_pair(k, r, c):
             g = lib.GridInfo()
             L.rsreg_icp_grid_info(c.h, C.byref(g))
+            ht = lib.HostTiming()
+            L.rsreg_ctx_host_timing(c.h, C.byref(ht))
             with stats_lock:
                 stats["ms_nn"] += r.ms_nn
                 stats["launch"] += r.n_nn_launches
                 stats["ms_build"] += g.ms_build
+                stats["ms_enqueue"] = stats.get("ms_enqueue", 0.0) + ht.loop_enqueue
+                stats["pairs"] = stats.get("pairs", 0) + 1
 
     def step(collect=False):
         if registrar is not None:
@@ -228,6 +232,8 @@ def run_chain(a, rank, world, local_rank, dist, coll_dev="cuda"):
         "roofline_note": ("launch durations measured with %d alignments in flight: they overlap, their sum exceeds the wall time" % a.in_flight)
                          if a.in_flight > 1 else None,
         "in_flight_vs_sequential_max_abs_diff": seq_diff,
+        # what queueing one alignment's device loop (2 launches per iteration) took its host thread, mean over the instrumented steps
+        "host_ms_to_queue_one_alignments_loop": (stats["ms_enqueue"] / stats["pairs"]) if stats.get("pairs") else None,
     }
     if not a.no_cpu_baseline:
         import oracle  # cpu_baseline leg: the oracle as the timed CPU port, never the product

@@ -434,7 +434,7 @@ int rsreg_icp_grid_info(rsreg_ctx *ctx, rsreg_grid_info *info);
  * align: rsreg_icp_begin .. the last iteration; aligned_copy: the aligned cloud's way home, device -> pinned -> caller. */
 typedef struct rsreg_host_timing {
     double source_stage_wait, source_pack, target_stage_wait, target_pack, target_build, align, aligned_copy;
-    double reserved;
+    double loop_enqueue;   /* device-resident loop: what queueing all its launches took the calling thread (0.4: was `reserved`) */
 } rsreg_host_timing;
 int rsreg_ctx_host_timing(rsreg_ctx *ctx, rsreg_host_timing *out);
 

@@ -1554,6 +1554,7 @@ int run_device_loop(rsreg_ctx *ctx)
     h->t_inc = to_mat34(Mat4f::identity());
     h->final_t = s.final_t;
     for (int k = 0; k < 9; ++k) h->svd_v[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    const auto t_q0 = std::chrono::steady_clock::now();
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_icp_state.ptr, h, sizeof(IcpDevState) + 16, hipMemcpyHostToDevice, ctx->stream));
     const int iters = std::max(1, s.prm.max_iterations);
     int it = 0;
@@ -1562,6 +1563,8 @@ int run_device_loop(rsreg_ctx *ctx)
         if (rc) return rc;
     }
     RSREG_HIP(ctx, hipMemcpyAsync(h, ctx->d_icp_state.ptr, sizeof(IcpDevState), hipMemcpyDeviceToHost, ctx->stream));
+    // (what queueing the whole loop took this thread: with several alignments in flight the threads share the runtime's launch path)
+    ctx->host_timing.loop_enqueue = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q0).count();
     RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s.idle_after_sums = true;
     (void)target_counts(ctx, false);

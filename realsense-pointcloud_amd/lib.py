@@ -94,7 +94,7 @@ class GridInfo(C.Structure):
 
 class HostTiming(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("source_stage_wait", "source_pack", "target_stage_wait", "target_pack", "target_build", "align",
-                                           "aligned_copy", "reserved")]
+                                           "aligned_copy", "loop_enqueue")]
 
 
 def hipcc_command(out=SO_PATH):

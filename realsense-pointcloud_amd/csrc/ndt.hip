@@ -169,16 +169,27 @@ int derivative_pass_pp(NdtRun &r, NdtPassParams &pp, bool store_trans)
     volatile uint64_t *flag = reinterpret_cast<volatile uint64_t *>(h + kNdtFlagSlot);
     const uint64_t seq = ++ctx->ndt_seq;
     *flag = 0;
-    k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
-                                                           store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
-                                                           ctx->d_ndt_partials.as<double>());
-    RSREG_HIP(ctx, hipGetLastError());
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc);
     // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue behind the kernel)
-    k_ndt_final_reduce<<<kNdtAcc, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks,
-                                                         ctx->comm ? ctx->d_ndt_out.as<double>() : h,
-                                                         reinterpret_cast<uint32_t *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc),
-                                                         watch ? const_cast<uint64_t *>(flag) : nullptr, seq);
-    RSREG_HIP(ctx, hipGetLastError());
+    double *sums_out = ctx->comm ? ctx->d_ndt_out.as<double>() : h;
+    static_assert(kPassBlocks == 2 * kNdtBlock, "k_ndt_pass_reduce adds slab t and slab t + 256");
+    if (tunables().ndt_one_launch) {
+        // the pass and its final reduce in one launch: the workgroup that finishes last adds the slabs (same tree, same bits; measured
+        // 8 us per pass slower than the launch pair below -- round 6, as round 2's form was: opt-in)
+        k_ndt_pass_reduce<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
+                                                                      store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
+                                                                      ctx->d_ndt_partials.as<double>(), sums_out, ticket,
+                                                                      watch ? const_cast<uint64_t *>(flag) : nullptr, seq);
+        RSREG_HIP(ctx, hipGetLastError());
+    } else {
+        k_ndt_pass<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,
+                                                               store_trans ? ctx->d_ndt_trans.as<float>() : nullptr,
+                                                               ctx->d_ndt_partials.as<double>());
+        RSREG_HIP(ctx, hipGetLastError());
+        k_ndt_final_reduce<<<kNdtAcc, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_partials.as<double>(), kPassBlocks, sums_out, ticket,
+                                                                   watch ? const_cast<uint64_t *>(flag) : nullptr, seq);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
     if (ctx->profiling) (void)hipEventRecord(e1, ctx->stream);
     if (ctx->comm) {   // also on a one-rank communicator: same calls, same stream order
         int rc = rsreg_comm_allreduce_device_(ctx, ctx->d_ndt_out.as<double>(), kNdtAcc);

@@ -354,6 +354,75 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_pass(const float4 *src, uint3
     ndt_pass_body<false>(src, n, vox, pp, trans_out, partials);
 }
 
+// The pass and its final reduce in ONE launch (round 6; RSREG_NDT_ONE_LAUNCH=1 -- measured SLOWER, 0.72-0.74 against 0.57-0.61 ms per
+// alignment of 17 passes, so the launch pair stays the default): the workgroup that finishes last adds the slabs up.  Every workgroup
+// writes its 28 sums through (agent-scope stores), waits for their acknowledgement and takes a ticket; the last one -- 256
+// threads -- loads slab t and slab t + 256 of all 28 sums (56 loads in flight per thread), adds them in k_ndt_final_reduce's
+// order ((0 + x[t]) + x[t + 256] per thread, the shuffle tree over a wave, the waves in order) and writes the sums and the pass
+// number where the host watches for it.  The 28 shuffle trees of 256 threads are ONE recursive-halving exchange
+// (records.hpp: halve_sums pairs lane l with l + 32, then l with l + 16, ... exactly as `v += __shfl_down(v, off)` does, and
+// an addition does not care which of the two lanes performs it): the same tree, hence the same bits as the two-launch form
+// (k_ndt_pass + k_ndt_final_reduce, the default) -- with 28 x 6 shuffles replaced by 29 moved doubles.
+// (Round 2 measured a last-workgroup reduce slower with release fences and sum-by-sum adds; this form -- no fence, one exchange --
+// is slower too: every workgroup's written-through sums with their acknowledgement, 512 tickets on one word, and a tail in which ONE
+// workgroup fetches 114 KB past the L2s cost more than a second launch of 28 workgroups behind a kernel boundary.)  Requires gridDim.x == 2 * kNdtBlock (the fixed 512 workgroups of a pass).
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_pass_reduce(const float4 *src, uint32_t n, const NdtVoxel *vox, NdtPassParams pp, float *trans_out,
+                                                               double *partials, double *out, uint32_t *ticket, uint64_t *flag, uint64_t seq)
+{
+    ndt_pass_body<true>(src, n, vox, pp, trans_out, partials);
+    __shared__ uint32_t s_last;
+    __shared__ double sh2[kNdtBlock / 64][kNdtAcc];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's partial sums have arrived device-wide)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[kNdtAcc];
+    {
+        const unsigned long long *p0 = reinterpret_cast<const unsigned long long *>(partials) + (size_t)threadIdx.x * kNdtAcc;
+        const unsigned long long *p1 = p0 + (size_t)kNdtBlock * kNdtAcc;
+        unsigned long long x0[kNdtAcc], x1[kNdtAcc];
+#pragma unroll
+        for (int k = 0; k < kNdtAcc; ++k) x0[k] = __hip_atomic_load(const_cast<unsigned long long *>(p0 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kNdtAcc; ++k) x1[k] = __hip_atomic_load(const_cast<unsigned long long *>(p1 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kNdtAcc; ++k) {
+            double v = 0.0;
+            v += __longlong_as_double((long long)x0[k]);
+            v += __longlong_as_double((long long)x1[k]);
+            acc[k] = v;
+        }
+    }
+    {
+        int base = 0, cnt = kNdtAcc;
+        double v14[14], v7[7], v4[4], v2[2], v1[1], v0[1];
+        rsreg::halve_sums<kNdtAcc>(acc, v14, lane, 32, base, cnt);
+        rsreg::halve_sums<14>(v14, v7, lane, 16, base, cnt);
+        rsreg::halve_sums<7>(v7, v4, lane, 8, base, cnt);
+        rsreg::halve_sums<4>(v4, v2, lane, 4, base, cnt);
+        rsreg::halve_sums<2>(v2, v1, lane, 2, base, cnt);
+        rsreg::halve_sums<1>(v1, v0, lane, 1, base, cnt);
+        if (cnt >= 1) sh2[wave][base] = v0[0];
+    }
+    __syncthreads();
+    if (threadIdx.x < kNdtAcc) {
+        double t = sh2[0][threadIdx.x];
+        for (int w = 1; w < kNdtBlock / 64; ++w) t += sh2[w][threadIdx.x];
+        out[threadIdx.x] = t;
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *ticket = 0;
+        if (flag) {
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // One workgroup per sum: fixed order (each thread its share of the partials in ascending order, shuffle tree, waves in
 // order).  With a flag (one GPU, sums written straight to pinned host memory) the workgroup that finishes last stamps the
 // pass number behind the sums, and the host watches for it instead of going through a stream synchronisation.

@@ -48,6 +48,7 @@ struct Tunables {
     long long cloud_pool_mb = 4096;        // RSREG_CLOUD_POOL_MB
     bool upload_wait_staged = false;       // RSREG_UPLOAD_WAIT_STAGED=1
     bool ndt_watch = true;                 // RSREG_NDT_NO_WATCH: hipStreamSynchronize instead of watching the stamped pass number
+    bool ndt_one_launch = false;           // RSREG_NDT_ONE_LAUNCH=1: a derivative pass as ONE launch whose last workgroup adds the slabs (k_ndt_pass_reduce; same bits, 8 us per pass SLOWER: DESIGN.md §5f) instead of k_ndt_pass + k_ndt_final_reduce
     bool ndt_resident_ls = false;          // RSREG_NDT_RESIDENT_LS=1: all the passes of a line search in one launch (k_ndt_line_search; same bits, not faster: DESIGN.md §5e)
 #ifdef RSREG_DIAG
     const char *dump_seed = nullptr, *wave_times = nullptr, *edge_dump = nullptr;   // RSREG_DUMP_SEED, RSREG_WAVE_TIMES, RSREG_EDGE_DUMP: files
@@ -93,6 +94,7 @@ inline Tunables tunables_from_environment()
     if (const char *e = std::getenv("RSREG_CLOUD_POOL_MB")) v.cloud_pool_mb = std::max(0ll, std::atoll(e));
     v.upload_wait_staged = on("RSREG_UPLOAD_WAIT_STAGED");
     v.ndt_watch = !set("RSREG_NDT_NO_WATCH");
+    v.ndt_one_launch = on("RSREG_NDT_ONE_LAUNCH");
     v.ndt_resident_ls = on("RSREG_NDT_RESIDENT_LS");
 #ifdef RSREG_DIAG
     v.dump_seed = std::getenv("RSREG_DUMP_SEED");
@@ -116,7 +118,7 @@ inline std::string tunables_signature()
         "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_SORT_SMALL",
         "RSREG_PLAIN_SOURCE_MAX", "RSREG_MORTON_BITS", "RSREG_NO_WORKER", "RSREG_NO_SEED", "RSREG_RESTART_APART", "RSREG_NO_SCAN", "RSREG_SCHED",
         "RSREG_SCHED_F4", "RSREG_SCHED_F2", "RSREG_SCHED_MIN_TILES", "RSREG_SCHED_AT", "RSREG_SCHED_XCD", "RSREG_SCHED_XCD_DEAL", "RSREG_SCHED_KEEP",
-        "RSREG_CLOUD_POOL_MB", "RSREG_UPLOAD_WAIT_STAGED", "RSREG_NDT_NO_WATCH", "RSREG_NDT_RESIDENT_LS", "RSREG_NDT_TWO_LAUNCHES",
+        "RSREG_CLOUD_POOL_MB", "RSREG_UPLOAD_WAIT_STAGED", "RSREG_NDT_NO_WATCH", "RSREG_NDT_RESIDENT_LS", "RSREG_NDT_ONE_LAUNCH",
 #ifdef RSREG_DIAG
         "RSREG_DUMP_SEED", "RSREG_WAVE_TIMES", "RSREG_EDGE_DUMP", "RSREG_WAVE_TIMES_LIGHT", "RSREG_DUMP_NN_MS", "RSREG_SCHED_VERBOSE", "RSREG_GRID_STATS",
         "RSREG_DEBUG_SKIP",

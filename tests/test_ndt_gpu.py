@@ -221,3 +221,30 @@ def test_line_search_in_one_launch_gives_the_same_bits(api, rs, monkeypatch):
         assert run() == base
     monkeypatch.delenv("RSREG_NDT_RESIDENT_LS")
     assert base[3] > 3   # several passes: a line search did run
+
+
+def test_pass_with_its_reduce_in_one_launch_gives_the_same_bits(api, rs, monkeypatch):
+    """Round 6, RSREG_NDT_ONE_LAUNCH=1: a derivative pass as ONE launch whose last workgroup adds the 512 slabs (k_ndt_pass_reduce;
+    opt-in: measured slower) -- against the default launch pair (k_ndt_pass + k_ndt_final_reduce): the same summation tree, so the same
+    28 sums of every pass and the same transform, score and pass count, bit for bit; the derivatives entry point returns the same doubles."""
+    tgt, src = rs.synth.render_frame(0, "50k", "parity"), rs.synth.render_frame(1, "50k", "parity")
+    guess = rs.synth.small_transform(0.4, (0.01, -0.005, 0.008)).astype(np.float32)
+
+    def run():
+        n = api.NormalDistributionsTransform(api.Context(0))   # (a context looks at the environment when it is created)
+        n.params = api.ndt_params(reference=True)
+        n.setInputSource(src)
+        n.setInputTarget(tgt)
+        out = n.align(guess)
+        r = n.result
+        score, grad, hess = n.derivatives(np.array([0.01, -0.005, 0.008, 0.002, -0.004, 0.007]))
+        return (bytes(r.transform), r.score, r.iterations, r.n_derivative_passes, r.converged, np.stack([out.points[k] for k in "xyz"]).tobytes(),
+                float(score), np.asarray(grad).tobytes(), np.asarray(hess).tobytes())
+
+    monkeypatch.delenv("RSREG_NDT_ONE_LAUNCH", raising=False)
+    two = run()
+    monkeypatch.setenv("RSREG_NDT_ONE_LAUNCH", "1")
+    for _ in range(3):
+        assert run() == two
+    monkeypatch.delenv("RSREG_NDT_ONE_LAUNCH")
+    assert two[3] > 3

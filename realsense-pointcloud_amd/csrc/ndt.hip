@@ -22,7 +22,10 @@ extern "C" int rsreg_comm_allreduce_device_(rsreg_ctx *ctx, double *d_buf, int c
 
 namespace {
 
-constexpr int kPassBlocks = 512;   // fixed: the summation order does not depend on the GPU (2 workgroups per CU of an MI355X;
+#ifndef RSREG_NDT_PASS_BLOCKS
+#define RSREG_NDT_PASS_BLOCKS 512   // (dev: experiment builds with another count, RSREG_CXXFLAGS=-DRSREG_NDT_PASS_BLOCKS=...)
+#endif
+constexpr int kPassBlocks = RSREG_NDT_PASS_BLOCKS;   // fixed: the summation order does not depend on the GPU (2 workgroups per CU of an MI355X;
                                    // 36 k points against 23 voxels: 0.61-0.62 ms per alignment, 1024: 0.65-0.68, 256: 0.62-0.63)
 constexpr int kMinPointsPerVoxel = 6;
 constexpr double kMinCovarEigMult = 0.01;
@@ -172,8 +175,7 @@ int derivative_pass_pp(NdtRun &r, NdtPassParams &pp, bool store_trans)
     uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_ndt_partials.as<double>() + (size_t)kPassBlocks * kNdtAcc);
     // one GPU: the 28 sums go straight into the pinned host buffer (no copy to queue behind the kernel)
     double *sums_out = ctx->comm ? ctx->d_ndt_out.as<double>() : h;
-    static_assert(kPassBlocks == 2 * kNdtBlock, "k_ndt_pass_reduce adds slab t and slab t + 256");
-    if (tunables().ndt_one_launch) {
+    if (tunables().ndt_one_launch && kPassBlocks == 2 * kNdtBlock) {   // (k_ndt_pass_reduce adds slab t and slab t + 256)
         // the pass and its final reduce in one launch: the workgroup that finishes last adds the slabs (same tree, same bits; measured
         // 8 us per pass slower than the launch pair below -- round 6, as round 2's form was: opt-in)
         k_ndt_pass_reduce<<<kPassBlocks, kNdtBlock, 0, ctx->stream>>>(ctx->d_ndt_src.as<float4>(), r.n, ctx->d_ndt_vox.as<NdtVoxel>(), pp,

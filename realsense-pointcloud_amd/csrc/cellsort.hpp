@@ -273,10 +273,10 @@ __global__ __launch_bounds__(kCcScanBlock) void k_cc_scan(uint32_t *gcnt, uint32
 }
 
 // record -> first record of its cell + its rank in arrival order
-__global__ __launch_bounds__(kBlock) void k_cc_scatter(const char *pts, size_t stride, uint32_t n, DenseDev g, const uint32_t *rank, const uint32_t *table,
-                                                       float4 *arrived)
+__device__ __forceinline__ void cc_scatter_body(uint32_t bid, const char *pts, size_t stride, uint32_t n, const DenseDev &g, const uint32_t *rank,
+                                                const uint32_t *table, float4 *arrived)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = rank[i];
     if (r == kCcDropped) return;
@@ -285,13 +285,29 @@ __global__ __launch_bounds__(kBlock) void k_cc_scatter(const char *pts, size_t s
     arrived[table[cc_slot(g, x, y, z)] + r] = tgt_rec(x, y, z, i);
 }
 
+__global__ __launch_bounds__(kBlock) void k_cc_scatter(const char *pts, size_t stride, uint32_t n, DenseDev g, const uint32_t *rank, const uint32_t *table,
+                                                       float4 *arrived)
+{
+    cc_scatter_body(blockIdx.x, pts, stride, n, g, rank, table, arrived);
+}
+
+// k_cc_scatter and k_dense_nbr need k_cc_scan's results and nothing of each other: ONE launch, the occupancy words'
+// workgroups (the longer job: scattered atomics) in front.  Round 6: the build is count, scan, this, k_cc_small_big -- four
+// dependent launches where it had six (RSREG_CC_APART=1: the six).
+__global__ __launch_bounds__(kBlock) void k_cc_scatter_nbr(const char *pts, size_t stride, uint32_t n, DenseDev g, const uint32_t *rank, const uint32_t *table,
+                                                           float4 *arrived, uint32_t nbr_blocks, const uint32_t *cellslot, const uint32_t *stats, uint32_t *occ)
+{
+    if (blockIdx.x < nbr_blocks) dense_nbr_body(blockIdx.x, cellslot, stats, g.sx, g.sxy, occ);
+    else cc_scatter_body(blockIdx.x - nbr_blocks, pts, stride, n, g, rank, table, arrived);
+}
+
 // One lane per record of the arrival-order array, for the cells of at most kCcSmall records: the record belongs behind the
 // cell's records with a smaller (x position to 16 bits, original index).  Records of crowded cells are k_cc_big's.
 // pos_of: original index -> position.
-__global__ __launch_bounds__(kBlock) void k_cc_small(const float4 *arrived, DenseDev g, const uint32_t *table, float4 *sorted, uint32_t *pos_of,
-                                                     const uint32_t *stats)
+__device__ __forceinline__ void cc_small_body(uint32_t bid, const float4 *arrived, const DenseDev &g, const uint32_t *table, float4 *sorted, uint32_t *pos_of,
+                                              const uint32_t *stats)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, nrec = stats[1];
+    const uint32_t p = bid * blockDim.x + threadIdx.x, nrec = stats[1];
     if (p == 0) {
         // far-away points behind the last sorted point: a 4-wide candidate read may run past it
         for (uint32_t k = 0; k < 4; ++k) sorted[nrec + k] = tgt_rec(1e30f, 1e30f, 1e30f, 0xffffffffu);
@@ -314,17 +330,23 @@ __global__ __launch_bounds__(kBlock) void k_cc_small(const float4 *arrived, Dens
     pos_of[idx] = s + before;
 }
 
+__global__ __launch_bounds__(kBlock) void k_cc_small(const float4 *arrived, DenseDev g, const uint32_t *table, float4 *sorted, uint32_t *pos_of,
+                                                     const uint32_t *stats)
+{
+    cc_small_body(blockIdx.x, arrived, g, table, sorted, pos_of, stats);
+}
+
 // The crowded cells (more than kCcSmall records: `big`, k_cc_scan's list), one wave per cell: count the cell's records per
 // x bucket (kCcXBits bits) in LDS, scan the 256 counts, place every record behind the buckets before its own, in arrival
 // order inside a bucket.
-__global__ __launch_bounds__(kBlock) void k_cc_big(const float4 *arrived, DenseDev g, const uint32_t *table, const uint32_t *big, float4 *sorted,
-                                                   uint32_t *pos_of, const uint32_t *stats)
+__device__ __forceinline__ void cc_big_body(uint32_t bid, uint32_t nblocks, const float4 *arrived, const DenseDev &g, const uint32_t *table, const uint32_t *big,
+                                            float4 *sorted, uint32_t *pos_of, const uint32_t *stats)
 {
     constexpr uint32_t kBins = 1u << kCcXBits;
     __shared__ uint32_t s_bin[kBlock / 64][kBins];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nbig = stats[2];
     uint32_t *bin = s_bin[wave];
-    for (uint32_t c = blockIdx.x * (kBlock / 64) + wave; c < nbig; c += gridDim.x * (kBlock / 64)) {
+    for (uint32_t c = bid * (kBlock / 64) + wave; c < nbig; c += nblocks * (kBlock / 64)) {
         const uint32_t slot = big[c];
         const uint32_t s = table[slot], e = table[slot + 1u];
         // (the slot's x coordinate: the padded table's index is ((z + 1) * (ny + 2) + (y + 1)) * (nx + 2) + (x + 1))
@@ -359,6 +381,21 @@ __global__ __launch_bounds__(kBlock) void k_cc_big(const float4 *arrived, DenseD
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cc_big(const float4 *arrived, DenseDev g, const uint32_t *table, const uint32_t *big, float4 *sorted,
+                                                   uint32_t *pos_of, const uint32_t *stats)
+{
+    cc_big_body(blockIdx.x, gridDim.x, arrived, g, table, big, sorted, pos_of, stats);
+}
+
+// The in-cell order of the small cells and of the crowded ones touch different records: ONE launch, the crowded cells'
+// workgroups (a wave per cell, the long jobs) in front.
+__global__ __launch_bounds__(kBlock) void k_cc_small_big(const float4 *arrived, DenseDev g, const uint32_t *table, const uint32_t *big, float4 *sorted,
+                                                         uint32_t *pos_of, const uint32_t *stats, uint32_t big_blocks)
+{
+    if (blockIdx.x < big_blocks) cc_big_body(blockIdx.x, big_blocks, arrived, g, table, big, sorted, pos_of, stats);
+    else cc_small_body(blockIdx.x - big_blocks, arrived, g, table, sorted, pos_of, stats);
 }
 
 }  // namespace rsreg

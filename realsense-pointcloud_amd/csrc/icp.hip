@@ -308,14 +308,24 @@ int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stri
     RSREG_HIP(ctx, hipGetLastError());
     k_cc_scan<<<spans, kCcScanBlock, 0, st>>>(cnt, (uint32_t)total, chunks, coarse, table, cellslot, cellpos, big, stats, h_counts);
     RSREG_HIP(ctx, hipGetLastError());
-    k_cc_scatter<<<div_up((uint32_t)n, kBlock), kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>());
+    const uint32_t nbf = div_up(nfin, kBlock), scatter_blocks = div_up((uint32_t)n, kBlock);
+    // (one wave per crowded cell, the waves of the grid in turn; the grid covers every cell a cloud of nfin points can crowd)
+    const uint32_t big_blocks = std::max(1u, std::min(div_up(nfin / (kCcSmall + 1u) + 1u, kBlock / 64), 2048u));
+    if (!tunables().cc_apart) {
+        // four dependent launches: scatter + occupancy words side by side (both need the scan only), then the in-cell order of the
+        // small and of the crowded cells side by side
+        k_cc_scatter_nbr<<<nbf + scatter_blocks, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>(), nbf, cellslot, stats, occ);
+        RSREG_HIP(ctx, hipGetLastError());
+        k_cc_small_big<<<big_blocks + nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, big, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats,
+                                                            big_blocks);
+        RSREG_HIP(ctx, hipGetLastError());
+        return RSREG_OK;
+    }
+    k_cc_scatter<<<scatter_blocks, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>());
     RSREG_HIP(ctx, hipGetLastError());
-    const uint32_t nbf = div_up(nfin, kBlock);
     k_cc_small<<<nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
     RSREG_HIP(ctx, hipGetLastError());
-    // (one wave per crowded cell, the waves of the grid in turn; the grid covers every cell a cloud of nfin points can crowd)
-    k_cc_big<<<std::max(1u, std::min(div_up(nfin / (kCcSmall + 1u) + 1u, kBlock / 64), 2048u)), kBlock, 0, st>>>(
-        ctx->d_arrived.as<float4>(), g, table, big, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
+    k_cc_big<<<big_blocks, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, big, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats);
     RSREG_HIP(ctx, hipGetLastError());
     // occupancy word of every cell's 27-cell neighbourhood: a query never opens an empty cell
     k_dense_nbr<<<nbf, kBlock, 0, st>>>(cellslot, stats, g.sx, g.sxy, occ);

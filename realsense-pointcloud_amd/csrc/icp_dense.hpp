@@ -260,9 +260,9 @@ __global__ __launch_bounds__(kBlock) void k_dense_max_count(const uint32_t *cell
 // the thread of that cell if it is occupied, else by the thread of the occupied cell to its left, else by the one to
 // its right -- 9 atomics per occupied cell inside a run of occupied cells, 27 for a lone one (it was 27 for all:
 // 3.9 M atomic ORs, 27 us, for the 10^6-point target of the bench).
-__global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, const uint32_t *stats, int sx, int sxy, uint32_t *nbr)
+__device__ __forceinline__ void dense_nbr_body(uint32_t bid, const uint32_t *cellslot, const uint32_t *stats, int sx, int sxy, uint32_t *nbr)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nc = stats[0];
+    const uint32_t c = bid * blockDim.x + threadIdx.x, nc = stats[0];
     if (c >= nc) return;
     const int slot = (int)cellslot[c];
     const int sl1 = c >= 1 ? (int)cellslot[c - 1] : -9, sl2 = c >= 2 ? (int)cellslot[c - 2] : -9;
@@ -291,6 +291,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, 
             if (w_left) atomicOr(&nbr[row - 1], w_left);
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_dense_nbr(const uint32_t *cellslot, const uint32_t *stats, int sx, int sxy, uint32_t *nbr)
+{
+    dense_nbr_body(blockIdx.x, cellslot, stats, sx, sxy, nbr);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

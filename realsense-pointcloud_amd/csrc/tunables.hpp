@@ -27,6 +27,7 @@ struct Tunables {
     bool adaptive_cell = true;             // RSREG_NO_ADAPTIVE_CELL=1: the brick-hash build never refines its cell size
     bool box_cache = true;                 // RSREG_NO_BOX_CACHE=1: a cloud handle's bounding box is measured by every build / load
     bool count_sort = true;                // RSREG_COUNT_SORT=0: the index by sorting (k_dense_keys, radix sort, k_dense_compact) instead of counting (cellsort.hpp)
+    bool cc_apart = false;                 // RSREG_CC_APART=1: the counting build's scatter / occupancy words / small cells / crowded cells as four launches (rounds 5; default: two)
     bool scan_apart = false;               // RSREG_SCAN_APART=1: sort-based build: flag, scan, scatter as three launches
     // ---- source
     bool sort_small = false;               // RSREG_SORT_SMALL=1: sources of <= 65 536 points are put into spatial order too
@@ -73,6 +74,7 @@ inline Tunables tunables_from_environment()
     v.adaptive_cell = !on("RSREG_NO_ADAPTIVE_CELL");
     v.box_cache = !on("RSREG_NO_BOX_CACHE");
     v.count_sort = !off("RSREG_COUNT_SORT");
+    v.cc_apart = on("RSREG_CC_APART");
     v.scan_apart = on("RSREG_SCAN_APART");
     v.sort_small = on("RSREG_SORT_SMALL");
     if (const char *e = std::getenv("RSREG_PLAIN_SOURCE_MAX")) v.plain_source_max = (size_t)std::atoll(e);
@@ -115,7 +117,7 @@ inline std::string tunables_signature()
 {
     static const char *const names[] = {
         "RSREG_CELL_CAP", "RSREG_DENSE_MAX_CELLS", "RSREG_FORCE_HASH", "RSREG_KEYS64", "RSREG_FULL_TABLE", "RSREG_FAR_ROWS", "RSREG_NO_WIDE_CELLS",
-        "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_SORT_SMALL",
+        "RSREG_NO_ADAPTIVE_CELL", "RSREG_NO_BOX_CACHE", "RSREG_COUNT_SORT", "RSREG_SCAN_APART", "RSREG_CC_APART", "RSREG_SORT_SMALL",
         "RSREG_PLAIN_SOURCE_MAX", "RSREG_MORTON_BITS", "RSREG_NO_WORKER", "RSREG_NO_SEED", "RSREG_RESTART_APART", "RSREG_NO_SCAN", "RSREG_SCHED",
         "RSREG_SCHED_F4", "RSREG_SCHED_F2", "RSREG_SCHED_MIN_TILES", "RSREG_SCHED_AT", "RSREG_SCHED_XCD", "RSREG_SCHED_XCD_DEAL", "RSREG_SCHED_KEEP",
         "RSREG_CLOUD_POOL_MB", "RSREG_UPLOAD_WAIT_STAGED", "RSREG_NDT_NO_WATCH", "RSREG_NDT_RESIDENT_LS", "RSREG_NDT_ONE_LAUNCH",

@@ -539,17 +539,18 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         voxel.setLeafSize(0.01f, 0.01f, 0.01f);
         configure_coarse();
         const rgb_point_cloud &frame0 = pairs ? *(*pairs)[0].second : *(*frames)[0];
-        rgb_device_cloud target, merged, fulls[3], features_of[2], reduced_of[2], coarse_out, refined, moved;   // (inputs of queued jobs outlive their outputs)
-        // frames only: frame k + 2 is on the PCIe link and the features of frame k + 1 are extracted and voxel-filtered
-        // (a thread, a stream and scratch of the context's own) while frame k goes through its two alignments here: the
+        // frames only: the features of the next kAhead frames are extracted and voxel-filtered (a thread, streams and scratch of the
+        // context's own) while frame k goes through its two alignments here, and frame k + kAhead + 1 is on the PCIe link: the
         // reference extracts all features before it registers anything (types.hpp:30-43), none depends on a registration
+        constexpr size_t kAhead = 2, kFulls = kAhead + 2, kFeat = kAhead + 1;
+        rgb_device_cloud target, merged, fulls[kFulls], features_of[kFeat], reduced_of[kFeat], coarse_out, refined, moved;   // (inputs of queued jobs outlive their outputs)
         auto prepare = [&](size_t k) {
-            extract_edge_features_async(fulls[k % 3], features_of[k & 1]);
-            voxel.filter_async(features_of[k & 1], reduced_of[k & 1]);
+            extract_edge_features_async(fulls[k % kFulls], features_of[k % kFeat]);
+            voxel.filter_async(features_of[k % kFeat], reduced_of[k % kFeat]);
         };
         if (!pairs)
-            for (size_t k = 1; k < std::min<size_t>(3, n_frames); ++k) fulls[k % 3].upload_deferred(*(*frames)[k]);   // (the worker starts on these ...)
-        merged.upload(frame0);                                                                                      // (... while frame 0 goes up from here)
+            for (size_t k = 1; k < std::min<size_t>(kAhead + 2, n_frames); ++k) fulls[k % kFulls].upload_deferred(*(*frames)[k]);   // (the worker starts on these ...)
+        merged.upload(frame0);                                                                                                  // (... while frame 0 goes up from here)
         // (`merged` on the GPU: frame 0 for its features, and the whole merged cloud only when it is downloaded at the end)
         std::unique_ptr<detail::StreamedResult> result;
         if (stream_result) {
@@ -557,7 +558,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             for (size_t k = 0; k < n_frames; ++k) capacity += pairs ? (*pairs)[k].second->size() : (*frames)[k]->size();
             result.reset(new detail::StreamedResult(merged.context(), frame0, capacity));
         }
-        if (!pairs && n_frames > 1) prepare(1);
+        if (!pairs)
+            for (size_t k = 1; k < std::min<size_t>(kAhead + 1, n_frames); ++k) prepare(k);
         if (pairs) target.upload(*(*pairs)[0].first);
         else extract_edge_features(merged, target);
         voxel.filter(target, target);   // frame-0 features: filtered in place, then grown
@@ -566,13 +568,14 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         frame_transforms.clear();
         clock_mark();
         for (size_t k = 1; k < n_frames; ++k, clock_mark()) {
-            rgb_device_cloud &full = fulls[k % 3], &features = features_of[k & 1], &reduced = reduced_of[k & 1];
+            rgb_device_cloud &full = fulls[k % kFulls], &features = features_of[k % kFeat], &reduced = reduced_of[k % kFeat];
             if (pairs) {
                 features.upload(*(*pairs)[k].first);
                 voxel.filter(features, reduced);
             } else {
-                if (k + 2 < n_frames) fulls[(k + 2) % 3].upload_deferred(*(*frames)[k + 2]);
-                if (k + 1 < n_frames) prepare(k + 1);
+                // (frame k + kAhead + 1 takes the buffer of frame k - 1, the features of frame k + kAhead those of frame k - 1)
+                if (k + kAhead + 1 < n_frames) fulls[(k + kAhead + 1) % kFulls].upload_deferred(*(*frames)[k + kAhead + 1]);
+                if (k + kAhead < n_frames) prepare(k + kAhead);
             }
             if (byproducts_on()) save_edge(k, features);
             const Matrix4f guess = next_guess(k, acc_rads);

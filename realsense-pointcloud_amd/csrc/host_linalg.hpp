@@ -148,6 +148,48 @@ template <int N> RSREG_HD inline void jacobi_svd(const double *A, SvdResult<N> &
 // reciprocal of its norm (one division per column instead of three).
 RSREG_HD inline double pick3(double a0, double a1, double a2, int i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
 
+// the columns of U (row-major 3 x 3) from `rank` on: unit vectors orthogonalised against the columns found so far (a
+// cross-covariance of rank < 3: coplanar or collinear matches).  Shared by jacobi_svd3 and its lane-parallel twin on the
+// device (icp_kernels.hpp: umeyama_wave).
+RSREG_HD inline void complete_u3(double *U, int rank)
+{
+#pragma clang fp contract(off)
+    constexpr int N = 3;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k < rank) continue;
+        double best[3] = {0, 0, 0}, bestn = -1;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            double v[3];
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = i == e ? 1.0 : 0.0;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+                    if (m >= k) continue;
+                    double d = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) d += v[i] * U[i * N + m];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) v[i] -= d * U[i * N + m];
+                }
+            double nn = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) nn += v[i] * v[i];
+            if (nn > bestn) {
+                bestn = nn;
+#pragma unroll
+                for (int i = 0; i < N; ++i) best[i] = v[i];
+            }
+        }
+        const double inv = 1.0 / sqrt(bestn);
+#pragma unroll
+        for (int i = 0; i < N; ++i) U[i * N + k] = best[i] * inv;
+    }
+}
+
 // `v0` (optional): an orthogonal matrix to start from, e.g. the V of a nearby matrix (the
 // cross-covariances of consecutive ICP iterations differ little: two or three sweeps then do
 // what takes six from the identity).  Starting from the identity, W = A exactly as before.
@@ -231,40 +273,7 @@ RSREG_HD inline void jacobi_svd3(const double *A, SvdResult<3> &out, const doubl
             for (int i = 0; i < N; ++i) out.U[i * N + k] = 0.0;
         }
     }
-    // complete U with unit vectors orthogonalised against the columns found so far
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        if (k < rank) continue;
-        double best[3] = {0, 0, 0}, bestn = -1;
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-            double v[3];
-#pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = i == e ? 1.0 : 0.0;
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-                for (int m = 0; m < N; ++m) {
-                    if (m >= k) continue;
-                    double d = 0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) d += v[i] * out.U[i * N + m];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) v[i] -= d * out.U[i * N + m];
-                }
-            double nn = 0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) nn += v[i] * v[i];
-            if (nn > bestn) {
-                bestn = nn;
-#pragma unroll
-                for (int i = 0; i < N; ++i) best[i] = v[i];
-            }
-        }
-        const double inv = 1.0 / sqrt(bestn);
-#pragma unroll
-        for (int i = 0; i < N; ++i) out.U[i * N + k] = best[i] * inv;
-    }
+    complete_u3(out.U, rank);
 }
 
 RSREG_HD inline double det3(const double *M)

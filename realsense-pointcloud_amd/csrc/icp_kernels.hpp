@@ -1037,6 +1037,163 @@ struct IcpSolvePrefetch {
     double svd_v[9];
 };
 
+// ---- umeyama_from_sums across the lanes of a wave (round 6).  Same operations on the same operands in the same order as
+// host_linalg.hpp's umeyama_from_sums / jacobi_svd3 (host and the one-lane device form): lane r (r = 0, 1, 2) owns ROW r of W = A V
+// and of V.  A rotation (p, q) of the one-sided Jacobi iteration touches columns p and q of every row -- each lane updates its
+// own row (4 products-and-sums instead of 12 on one lane) -- and needs the three column dot products, whose terms the lanes
+// compute one row each and hand round by v_readlane, added in the scalar code's order ((0 + k0) + k1) + k2.  The chain from
+// the dot products to (c, s) -- three divisions and two square roots, each a dozen dependent instructions -- is what no lane
+// count shortens; every lane runs it on the same numbers.  All 64 lanes of the wave must be active (lanes >= 3 mirror lane r % 3).
+__device__ __forceinline__ double lane_bcast(double x, int k)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sel3d(int r, double a0, double a1, double a2) { return r == 0 ? a0 : (r == 1 ? a1 : a2); }
+
+__device__ __forceinline__ bool umeyama_wave(const double *sums, Mat4f &T, double *v_warm /* 9, in/out, uniform */)
+{
+#pragma clang fp contract(off)
+    const int r = (int)(threadIdx.x & 63u) % 3;
+    const double n = sums[0];
+    if (!(n >= 1.0)) return false;
+    double mu_p[3], mu_q[3], sigma[9];
+    const double inv_n = 1.0 / n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { mu_p[i] = sums[1 + i] * inv_n; mu_q[i] = sums[4 + i] * inv_n; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = sums[7 + i * 3 + j] * inv_n - mu_q[i] * mu_p[j];
+    // W = A V0, V = V0: this lane's rows
+    const double a0 = sel3d(r, sigma[0], sigma[3], sigma[6]), a1 = sel3d(r, sigma[1], sigma[4], sigma[7]), a2 = sel3d(r, sigma[2], sigma[5], sigma[8]);
+    double W[3], V[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        W[j] = (a0 * v_warm[j] + a1 * v_warm[3 + j]) + a2 * v_warm[6 + j];
+        V[j] = sel3d(r, v_warm[j], v_warm[3 + j], v_warm[6 + j]);
+    }
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p + 1 < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double kpp = W[p] * W[p], kqq = W[q] * W[q], kpq = W[p] * W[q];
+                double app = 0, aqq = 0, apq = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    app += lane_bcast(kpp, k);
+                    aqq += lane_bcast(kqq, k);
+                    apq += lane_bcast(kpq, k);
+                }
+                if (apq == 0.0 || apq * apq <= 1e-32 * app * aqq) continue;
+                rotated = true;
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                const double wp = W[p], wq = W[q];
+                W[p] = c * wp - sn * wq;
+                W[q] = sn * wp + c * wq;
+                const double vp = V[p], vq = V[q];
+                V[p] = c * vp - sn * vq;
+                V[q] = sn * vp + c * vq;
+            }
+        if (!rotated) break;
+    }
+    double norm[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double sq = W[j] * W[j];
+        double nn = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) nn += lane_bcast(sq, k);
+        norm[j] = sqrt(nn);
+    }
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (pick3(norm[0], norm[1], norm[2], o1) > pick3(norm[0], norm[1], norm[2], o0)) { const int x = o0; o0 = o1; o1 = x; }
+    if (pick3(norm[0], norm[1], norm[2], o2) > pick3(norm[0], norm[1], norm[2], o0)) { const int x = o0; o0 = o2; o2 = x; }
+    if (pick3(norm[0], norm[1], norm[2], o2) > pick3(norm[0], norm[1], norm[2], o1)) { const int x = o1; o1 = o2; o2 = x; }
+    const double smax = pick3(norm[0], norm[1], norm[2], o0);
+    int rank = 0;
+    double Ur[3], Vr[3];   // this lane's rows of the ordered U and V
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        const double nj = pick3(norm[0], norm[1], norm[2], j);
+        Vr[k] = pick3(V[0], V[1], V[2], j);
+        if (nj > 0 && nj > 1e-13 * smax) {
+            const double inv = 1.0 / nj;
+            Ur[k] = pick3(W[0], W[1], W[2], j) * inv;
+            rank = k + 1;
+        } else {
+            Ur[k] = 0.0;
+        }
+    }
+    // everybody gets everything: the ordered U and V, row-major
+    double U[9], Vf[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { U[i * 3 + k] = lane_bcast(Ur[k], i); Vf[i * 3 + k] = lane_bcast(Vr[k], i); }
+    if (rank < 3) complete_u3(U, rank);   // (coplanar / collinear matches: the scalar code, on every lane)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v_warm[i] = Vf[i];
+    double S[3] = {1, 1, 1};
+    if (det3(U) * det3(Vf) < 0) S[2] = -1;
+    // R = U S V^T and t = mu_q - R mu_p: row r on lane r, then handed round
+    double Rr[3];
+    const double u0 = sel3d(r, U[0], U[3], U[6]), u1 = sel3d(r, U[1], U[4], U[7]), u2 = sel3d(r, U[2], U[5], U[8]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double v = 0;
+        v += u0 * S[0] * Vf[j * 3 + 0];
+        v += u1 * S[1] * Vf[j * 3 + 1];
+        v += u2 * S[2] * Vf[j * 3 + 2];
+        Rr[j] = v;
+    }
+    const double tr = sel3d(r, mu_q[0], mu_q[1], mu_q[2]) - (Rr[0] * mu_p[0] + Rr[1] * mu_p[1] + Rr[2] * mu_p[2]);
+    T = Mat4f::identity();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T(i, j) = float(lane_bcast(Rr[j], i));
+        T(i, 3) = float(lane_bcast(tr, i));
+    }
+    return true;
+}
+
+// the solve of the device-resident loop on a whole wave (all 64 lanes active; lane 0 stores)
+__device__ __forceinline__ void icp_solve_step_wave(const double *sums, IcpDevState *st, IcpSolvePrefetch &pf)
+{
+    if (pf.stopped) return;
+    const bool writer = (threadIdx.x & 63u) == 0;
+    double s[RSREG_NUM_SUMS];
+#pragma unroll
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) s[k] = sums[k];
+    if (writer) {
+#pragma unroll
+        for (int k = 0; k < RSREG_NUM_SUMS; ++k) st->sums_last[k] = s[k];
+        st->ncorr = (unsigned long long)(s[0] + 0.5);
+    }
+    if ((unsigned long long)(s[0] + 0.5) < 3) {
+        if (writer) { st->stopped = 1; st->apply = 0; }
+        return;
+    }
+    Mat4f t;
+    umeyama_wave(s, t, pf.svd_v);
+    const Mat4f f = mul(t, pf.final_t);
+    if (writer) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) st->svd_v[i] = pf.svd_v[i];
+        st->t_inc = to_mat34(t);
+        st->apply = 1;
+        st->final_t = f;
+        st->iterations = pf.iterations + 1;
+        st->cur_mse = s[16] / s[0];
+    }
+}
+
 __device__ __forceinline__ void icp_solve_step_prefetched(const double *sums, IcpDevState *st, IcpSolvePrefetch &pf)
 {
     if (pf.stopped) return;
@@ -1065,8 +1222,9 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
 {
     __shared__ double shf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_last;
     IcpSolvePrefetch pf;
-    if (threadIdx.x == 0) {
+    if (wave == 0) {   // (every lane of the wave that may run the solve: the same words, one request)
         pf.stopped = st->stopped;
         pf.iterations = st->iterations;
         pf.final_t = st->final_t;
@@ -1085,13 +1243,16 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
         // invalidate this XCD's L2
         __hip_atomic_store(&sums[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            double all[RSREG_NUM_SUMS];
-            for (int k = 0; k < RSREG_NUM_SUMS; ++k) all[k] = __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *ticket = 0;
-            icp_solve_step_prefetched(all, st, pf);
-        }
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    // the workgroup that finished last: its first wave runs the solve, the 3 x 3 Jacobi iteration a row per lane (umeyama_wave)
+    double all[RSREG_NUM_SUMS];
+#pragma unroll
+    for (int k = 0; k < RSREG_NUM_SUMS; ++k) all[k] = __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) *ticket = 0;
+    icp_solve_step_wave(all, st, pf);
 }
 
 // ------------------------------------------------------------------------ no index: a handful of queries

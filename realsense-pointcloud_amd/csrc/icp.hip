@@ -1173,7 +1173,7 @@ int launch_sums(rsreg_ctx *ctx, double *sums, bool global)
                                                                     ctx->d_corr_d2.as<float>(), ctx->d_tgt_sorted.as<float4>(), n,
                                                                     ctx->d_partials.as<double>());
         RSREG_HIP(ctx, hipGetLastError());
-        k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), host_sums_target(ctx));
+        k_final_reduce<<<RSREG_NUM_SUMS, kReduceBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), host_sums_target(ctx));
         RSREG_HIP(ctx, hipGetLastError());
     }
     return fetch_sums(ctx, sums, global);
@@ -1531,12 +1531,12 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
     s.have_search = want_corr;
     if (device_loop && !ctx->comm) {   // final reduce + solve in one launch
         auto *st = ctx->d_icp_state.as<IcpDevState>();
-        k_final_reduce_solve<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>(),
+        k_final_reduce_solve<<<RSREG_NUM_SUMS, kReduceBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n), ctx->d_sums.as<double>(),
                                                                           st, reinterpret_cast<unsigned int *>(st + 1));
         RSREG_HIP(ctx, hipGetLastError());
         return RSREG_OK;
     }
-    k_final_reduce<<<RSREG_NUM_SUMS, kBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n),
+    k_final_reduce<<<RSREG_NUM_SUMS, kReduceBlock, 0, ctx->stream>>>(ctx->d_partials.as<double>(), reduce_blocks(n),
                                                                device_loop ? ctx->d_sums.as<double>() : host_sums_target(ctx));
     RSREG_HIP(ctx, hipGetLastError());
     if (device_loop) {   // the sums stay on the device: (all-reduce,) solve, next pass

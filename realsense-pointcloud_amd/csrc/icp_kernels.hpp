@@ -924,25 +924,29 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const i
 // A thread's share of `count` partials (every kBlock-th, ascending), added in that order.  The loads go out sixteen at a
 // time before the first is used: one after the other, each waiting for the last (what the plain loop compiles to),
 // thirty trips to memory in a row were 10 of the 14 us between two search kernels.
+// (kReduceBlock threads: round 6 -- 1 024 instead of 256: the 7 813 slabs of a 10^6-point launch are eight loads a thread, all in
+// flight at once, where they were 31 in two rounds.  The order of the additions is part of every pipeline's result: staged,
+// fused and device-loop launches all go through this function.)
+constexpr int kReduceBlock = 1024;
 __device__ __forceinline__ double strided_sum(const double *src, uint32_t count)
 {
     constexpr int kInFlight = 16;
     double v = 0.0;
-    for (uint32_t b = threadIdx.x; b < count; b += kBlock * kInFlight) {
+    for (uint32_t b = threadIdx.x; b < count; b += kReduceBlock * kInFlight) {
         double x[kInFlight];
 #pragma unroll
-        for (int j = 0; j < kInFlight; ++j) x[j] = b + j * kBlock < count ? src[b + j * kBlock] : 0.0;
+        for (int j = 0; j < kInFlight; ++j) x[j] = b + j * kReduceBlock < count ? src[b + j * kReduceBlock] : 0.0;
 #pragma unroll
         for (int j = 0; j < kInFlight; ++j)
-            if (b + j * kBlock < count) v += x[j];
+            if (b + j * kReduceBlock < count) v += x[j];
     }
     return v;
 }
 
-// 17 blocks of 256 threads: block k adds sum k over all slabs, fixed order
-__global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials, uint32_t nblocks, double *sums)
+// 17 blocks of kReduceBlock threads: block k adds sum k over all slabs, fixed order
+__global__ __launch_bounds__(kReduceBlock) void k_final_reduce(const double *partials, uint32_t nblocks, double *sums)
 {
-    __shared__ double shf[kBlock / 64];
+    __shared__ double shf[kReduceBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *src = partials + (size_t)blockIdx.x * nblocks;
     double v = strided_sum(src, nblocks);
@@ -951,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce(const double *partials,
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = shf[0];
-        for (int w = 1; w < kBlock / 64; ++w) t += shf[w];
+        for (int w = 1; w < kReduceBlock / 64; ++w) t += shf[w];
         sums[blockIdx.x] = t;
     }
 }
@@ -1217,10 +1221,10 @@ __device__ __forceinline__ void icp_solve_step_prefetched(const double *sums, Ic
     st->cur_mse = s[16] / s[0];
 }
 
-__global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *partials, uint32_t nblocks, double *sums,
-                                                               IcpDevState *st, unsigned int *ticket)
+__global__ __launch_bounds__(kReduceBlock) void k_final_reduce_solve(const double *partials, uint32_t nblocks, double *sums,
+                                                                     IcpDevState *st, unsigned int *ticket)
 {
-    __shared__ double shf[kBlock / 64];
+    __shared__ double shf[kReduceBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ uint32_t s_last;
     IcpSolvePrefetch pf;
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(kBlock) void k_final_reduce_solve(const double *par
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = shf[0];
-        for (int w = 1; w < kBlock / 64; ++w) t += shf[w];
+        for (int w = 1; w < kReduceBlock / 64; ++w) t += shf[w];
         // written through (agent-scope store), acknowledged, then counted: no fence, which would write back and
         // invalidate this XCD's L2
         __hip_atomic_store(&sums[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

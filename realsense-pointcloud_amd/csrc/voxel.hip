@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kVBlock) void k_vox_starts(const uint32_t *skeys, c
 }
 
 constexpr uint32_t kLongRun = 48;   // runs from this length on are summed by a whole wave (k_vox_long_runs)
+constexpr uint32_t kHugeRun = 4096; // and from this length on by a block that scans instead of adding (k_vox_huge_runs)
 
 __device__ __forceinline__ void vox_store_run(const float acc[7], uint32_t a, uint32_t b, uint32_t n, uint32_t nfin, uint32_t r,
                                               const uint32_t *skeys, const uint32_t *svals, float *cent, uint32_t *ekey, uint32_t *erun)
@@ -128,12 +129,16 @@ __device__ __forceinline__ void vox_terms(const char *rec, float t[7])
 __global__ __launch_bounds__(kVBlock) void k_vox_runs(const char *recs, size_t stride, uint32_t n, const uint32_t *skeys,
                                                       const uint32_t *svals, const uint32_t *start, uint32_t *stats,
                                                       float *cent /* 8 floats per run */, uint32_t *ekey, uint32_t *erun,
-                                                      uint32_t *long_runs)
+                                                      uint32_t *long_runs, uint32_t *huge_runs)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nr = stats[0], nfin = stats[1];
     if (r >= nr) return;
     const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
+    if (b - a >= kHugeRun) {
+        huge_runs[atomicAdd(&stats[3], 1u)] = r;
+        return;
+    }
     if (b - a >= kLongRun) {
         long_runs[atomicAdd(&stats[2], 1u)] = r;
         return;
@@ -258,6 +263,270 @@ __global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, siz
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Huge runs (PCL's default 1 m leaf puts 10^4..10^5 points of a frame into ONE run): a float sum in input order, bit for bit,
+// WITHOUT adding the floats one after the other.
+//
+// While a running sum s stays inside one binade [2^E, 2^(E+1)), s = m u with u = 2^(E-23) and an integer m, and s (+) t =
+// round-to-nearest-even(m + t/u) u: the step moves m by rndne(t/u) whatever m is -- except when t/u lies exactly half way
+// between two integers, where the result is the even neighbour, i.e. depends on the PARITY of m only.  So every step, and every
+// sequence of steps, is a function m -> m + (m odd ? A1 : A0); two such functions compose into another (f then g: h_p = f_p +
+// g_[(p + f_p) & 1]), the composition is associative, and a block can scan it: thread t composes its own kHL points, the block
+// scans the 512 functions, and every thread learns the sum it would START from.
+//
+// The binade is only an assumption (the sum doubles ~17 times on its way to 10^5 points, a coordinate may cancel, a colour sum
+// may pass 2^24).  It is not argued away, it is CHECKED: every thread adds its own points to its predicted start with real float
+// additions (16 of them, all threads at once) and compares the bits with its predicted end.  Thread 0 starts from the true sum;
+// if thread i started from the true sum and its real additions end where the prediction said, thread i + 1 started from the
+// true sum too.  So everything before the first thread that disagrees is exact whatever the prediction was made of, that
+// thread's REAL end is the true sum there, and the block goes round again from the next thread with the binade of that sum.
+// A round costs what 16 additions cost; a run of 130 000 points takes ~30 of them instead of 130 000 dependent additions.
+// (Six sums: x y z r g b.  PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back:
+// the centroid's fourth component is not part of the output record, and this kernel leaves it out.)
+constexpr int kHB = 512;                 // threads of a block = functions of a scan
+constexpr int kHL = 16;                  // points a thread composes in a full window
+constexpr int kHWaves = kHB / 64;
+constexpr uint32_t kHPrefix = 1024;      // the first points of a run are added one after the other (the sum changes binade every few points there)
+static_assert(kHugeRun >= kHPrefix, "a huge run is longer than its prefix");
+constexpr uint32_t kHNone = 0xffffffffu;
+
+struct HFn {   // m -> m + (m odd ? a1 : a0), modulo 2^32
+    uint32_t a0, a1;
+};
+__device__ __forceinline__ HFn h_then(const HFn f, const HFn g)
+{
+    HFn h;
+    h.a0 = f.a0 + ((f.a0 & 1u) ? g.a1 : g.a0);
+    h.a1 = f.a1 + ((f.a1 & 1u) ? g.a0 : g.a1);
+    return h;
+}
+struct HBase {   // a sum as (sign, exponent field >= 1, integer mantissa): value = (-1)^neg m 2^(e - 150)
+    uint32_t e, m, neg;
+};
+__device__ __forceinline__ HBase h_base(uint32_t bits)
+{
+    HBase b;
+    const uint32_t ef = (bits >> 23) & 0xffu;
+    b.e = ef ? ef : 1u;
+    b.m = (bits & 0x7fffffu) | (ef ? 0x800000u : 0u);
+    b.neg = bits >> 31;
+    return b;
+}
+__device__ __forceinline__ uint32_t h_bits(const HBase &b, uint32_t m) { return ((((b.e - 1u) << 23) + m) & 0x7fffffffu) | (b.neg << 31); }
+
+struct HWin {   // a thread's points of one window (positions past the end of the run: +0.0f, which leaves a sum as it is)
+    float x[kHL], y[kHL], z[kHL];
+    uint32_t rgb[kHL];
+};
+__device__ __forceinline__ float h_term(const HWin &w, int i, int c)
+{
+    switch (c) {
+    case 0: return w.x[i];
+    case 1: return w.y[i];
+    case 2: return w.z[i];
+    case 3: return (float)((w.rgb[i] >> 16) & 0xffu);
+    case 4: return (float)((w.rgb[i] >> 8) & 0xffu);
+    default: return (float)(w.rgb[i] & 0xffu);
+    }
+}
+
+__global__ __launch_bounds__(kHB) void k_vox_huge_runs(const char *recs, size_t stride, uint32_t n, const uint32_t *skeys,
+                                                       const uint32_t *svals, const uint32_t *start, const uint32_t *stats,
+                                                       float *cent, uint32_t *ekey, uint32_t *erun, const uint32_t *huge_runs)
+{
+    __shared__ __attribute__((aligned(16))) float sh_pre[6][kHPrefix];
+    __shared__ HFn sh_tot[6][kHWaves];
+    __shared__ uint32_t sh_mis[6][kHWaves], sh_acc[6][kHWaves], sh_end[6], sh_s[6];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nr = stats[0], nfin = stats[1], n_huge = stats[3];
+    const bool vec = (stride % 16 == 0) && ((reinterpret_cast<size_t>(recs) & 15) == 0);
+    for (uint32_t k = blockIdx.x; k < n_huge; k += gridDim.x) {
+        const uint32_t r = huge_runs[k];
+        const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
+        // window w: lw(w) points a thread, kHB lw(w) points in all; the windows double with the sum until they are full
+        auto lw_of = [](uint32_t w) -> uint32_t { return w < 3u ? (2u << w) : (uint32_t)kHL; };
+        auto fetch_idx = [&](uint32_t base, uint32_t lw, uint32_t idx[kHL]) {
+#pragma unroll
+            for (int i = 0; i < kHL; ++i) {
+                const uint32_t p = base + tid * lw + (uint32_t)i;
+                idx[i] = ((uint32_t)i < lw && p < b) ? svals[p] : kHNone;
+            }
+        };
+        auto fetch_recs = [&](const uint32_t idx[kHL], HWin &w) {
+#pragma unroll
+            for (int i = 0; i < kHL; ++i) {
+                VoxRaw v{0.0f, 0.0f, 0.0f, 0u};
+                if (idx[i] != kHNone) v = vox_load(recs + (size_t)idx[i] * stride, vec);
+                w.x[i] = v.x; w.y[i] = v.y; w.z[i] = v.z; w.rgb[i] = v.rgb;
+            }
+        };
+        // what is in flight: the records of window 0, the indices of window 1
+        uint32_t idx[kHL];
+        HWin cur;
+        uint32_t base = a + kHPrefix, w_no = 0;
+        fetch_idx(base, lw_of(0), idx);
+        // the first kHPrefix points: through LDS, six lanes of wave 0 add them in input order
+        __syncthreads();   // (the block's previous run has been read out of the LDS)
+        for (uint32_t e = tid; e < kHPrefix; e += kHB) {
+            const VoxRaw v = vox_load(recs + (size_t)svals[a + e] * stride, vec);
+            sh_pre[0][e] = v.x; sh_pre[1][e] = v.y; sh_pre[2][e] = v.z;
+            sh_pre[3][e] = (float)((v.rgb >> 16) & 0xffu);
+            sh_pre[4][e] = (float)((v.rgb >> 8) & 0xffu);
+            sh_pre[5][e] = (float)(v.rgb & 0xffu);
+        }
+        fetch_recs(idx, cur);
+        fetch_idx(base + kHB * lw_of(0), lw_of(1), idx);
+        __syncthreads();
+        if (tid < 6) {
+            float acc = 0.0f;
+            const float4 *v = reinterpret_cast<const float4 *>(&sh_pre[tid][0]);
+            for (uint32_t i = 0; i < kHPrefix / 4; ++i) {
+                const float4 q = v[i];
+                acc = __fadd_rn(acc, q.x);
+                acc = __fadd_rn(acc, q.y);
+                acc = __fadd_rn(acc, q.z);
+                acc = __fadd_rn(acc, q.w);
+            }
+            sh_s[tid] = __float_as_uint(acc);
+        }
+        __syncthreads();
+        uint32_t s[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[c] = sh_s[c];
+        while (base < b) {
+            const uint32_t lw = lw_of(w_no);
+            const uint32_t next_base = base + kHB * lw;
+            HWin nxt;
+            if (next_base < b) {   // (uniform) the next window's records and the indices of the one after go out now
+                fetch_recs(idx, nxt);
+                fetch_idx(next_base + kHB * lw_of(w_no + 1), lw_of(w_no + 2), idx);
+            }
+            uint32_t lo[6] = {0, 0, 0, 0, 0, 0};   // component c is exact up to thread lo[c] (exclusive); s[c] is the true sum there
+            bool open = true;
+            while (open) {
+                HFn own[6], before[6];   // a thread's own points; (after the scan) its wave's lanes before it / up to and including it
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    own[c] = before[c] = HFn{0u, 0u};
+                    if (lo[c] >= (uint32_t)kHB) continue;   // (uniform)
+                    const HBase bs = h_base(s[c]);
+                    const int sh = 150 - (int)bs.e;
+                    if (c >= 3 && sh >= 0 && sh < 24) {
+                        // a colour sum below 2^24: bytes on a grid of 2^-sh, nothing to round (if the sum leaves that range inside
+                        // the window the check below notices, like everything else)
+                        if (tid >= lo[c]) {
+                            uint32_t sum = 0;
+#pragma unroll
+                            for (int i = 0; i < kHL; ++i)
+                                if ((uint32_t)i < lw) sum += (cur.rgb[i] >> (8 * (5 - c))) & 0xffu;
+                            sum <<= sh;
+                            if (bs.neg) sum = 0u - sum;
+                            own[c].a0 = own[c].a1 = sum;
+                        }
+                    } else if (tid >= lo[c]) {
+#pragma unroll
+                        for (int i = 0; i < kHL; ++i) {
+                            if ((uint32_t)i >= lw) continue;   // (uniform)
+                            float q = ldexpf(h_term(cur, i, c), sh);
+                            if (bs.neg) q = -q;
+                            const float rn = rintf(q);
+                            const bool tie = fabsf(q - rn) == 0.5f;
+                            if (__builtin_amdgcn_ballot_w64(tie)) {   // (uniform) somebody's step depends on the parity
+                                const uint32_t st = (uint32_t)(int)(tie ? floorf(q) : rn);
+                                const uint32_t x0 = own[c].a0 + st, x1 = own[c].a1 + st;
+                                own[c].a0 = x0 + (tie ? (x0 & 1u) : 0u);
+                                own[c].a1 = x1 + (tie ? (~x1 & 1u) : 0u);
+                            } else {
+                                const uint32_t st = (uint32_t)(int)rn;
+                                own[c].a0 += st;
+                                own[c].a1 += st;
+                            }
+                        }
+                    }
+                    // inclusive scan over the wave; the wave's total goes to the LDS
+                    HFn inc = own[c];
+                    if (__builtin_amdgcn_ballot_w64(inc.a0 != inc.a1)) {   // (uniform) a step of this wave depends on the parity
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            HFn f;
+                            f.a0 = __shfl_up(inc.a0, d);
+                            f.a1 = __shfl_up(inc.a1, d);
+                            if (lane >= (uint32_t)d) inc = h_then(f, inc);
+                        }
+                    } else {   // plain steps compose by adding
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t f = __shfl_up(inc.a0, d);
+                            if (lane >= (uint32_t)d) inc.a0 += f;
+                        }
+                        inc.a1 = inc.a0;
+                    }
+                    if (lane == 63u) sh_tot[c][wave] = inc;
+                    before[c].a0 = __shfl_up(inc.a0, 1);
+                    before[c].a1 = __shfl_up(inc.a1, 1);
+                    if (lane == 0u) before[c] = HFn{0u, 0u};
+                    own[c] = inc;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (lo[c] >= (uint32_t)kHB) continue;
+                    HFn pre{0u, 0u};   // the waves before this one
+                    for (uint32_t w = 0; w < wave; ++w) pre = h_then(pre, sh_tot[c][w]);
+                    const HFn bef = h_then(pre, before[c]);
+                    const HFn upto = h_then(pre, own[c]);
+                    const HBase bs = h_base(s[c]);
+                    const uint32_t p0 = bs.m & 1u;
+                    float v = __uint_as_float(h_bits(bs, bs.m + (p0 ? bef.a1 : bef.a0)));
+#pragma unroll
+                    for (int i = 0; i < kHL; ++i) {
+                        if ((uint32_t)i < lw) v = __fadd_rn(v, h_term(cur, i, c));
+                    }
+                    const uint32_t want = h_bits(bs, bs.m + (p0 ? upto.a1 : upto.a0));
+                    const bool wrong = tid >= lo[c] && __float_as_uint(v) != want;
+                    const unsigned long long bad = __builtin_amdgcn_ballot_w64(wrong);
+                    const uint32_t first = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                    const uint32_t v_first = __shfl(__float_as_uint(v), (int)(first & 63u));
+                    if (lane == 0u) {
+                        sh_mis[c][wave] = bad ? wave * 64u + first : kHNone;
+                        sh_acc[c][wave] = v_first;
+                    }
+                    if (tid == (uint32_t)kHB - 1u) sh_end[c] = want;
+                }
+                __syncthreads();
+                open = false;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (lo[c] >= (uint32_t)kHB) continue;
+                    uint32_t t_bad = kHNone;
+                    for (int w = kHWaves - 1; w >= 0; --w)
+                        if (sh_mis[c][w] != kHNone) t_bad = sh_mis[c][w];
+                    if (t_bad == kHNone) {
+                        s[c] = sh_end[c];
+                        lo[c] = (uint32_t)kHB;
+                    } else {
+                        s[c] = sh_acc[c][t_bad >> 6];
+                        lo[c] = t_bad + 1u;
+                        if (lo[c] < (uint32_t)kHB) open = true;
+                    }
+                }
+                // (the next round writes sh_tot only after every wave has passed the barrier above, and sh_mis / sh_acc /
+                //  sh_end only after the barrier behind its scan)
+            }
+            if (next_base < b) cur = nxt;
+            base = next_base;
+            ++w_no;
+        }
+        if (tid == 0) {
+            float all[7];
+            all[0] = __uint_as_float(s[0]); all[1] = __uint_as_float(s[1]); all[2] = __uint_as_float(s[2]);
+            all[3] = 0.0f;   // (the sum PCL never reads)
+            all[4] = __uint_as_float(s[3]); all[5] = __uint_as_float(s[4]); all[6] = __uint_as_float(s[5]);
+            vox_store_run(all, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);
+        }
+    }
+}
+
 // output record j = centroid of run order[j]: a default PointXYZRGB with xyz and packed rgb set
 __global__ __launch_bounds__(kVBlock) void k_vox_emit(const float *cent, const uint32_t *order, const uint32_t *stats, size_t stride,
                                                       char *out)
@@ -324,6 +593,7 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     uint32_t *ekey = vals, *erun = flag;    // vals dead once sorted, flag dead after the starts
     uint32_t *ekey2 = keys + N, *order = vals + N;
     uint32_t *long_runs = rid;              // the run ids are dead once the starts are written
+    uint32_t *huge_runs = rid + N;          // (at most N / kLongRun long runs; the buffer holds 2 N words)
     float *cent = b_cent.as<float>();
     uint32_t *stats = b_misc.as<uint32_t>() + 32;
     const uint32_t nb = div_up_u(N, kVBlock);
@@ -357,11 +627,15 @@ int voxel_filter_device(rsreg_ctx *ctx, const char *d_in, uint32_t N, size_t str
     RSREG_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t nr = h[0];
     if (nr == 0) return RSREG_OK;
-    k_vox_runs<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun, long_runs);
+    k_vox_runs<<<div_up_u(nr, kVBlock), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun, long_runs, huge_runs);
     RSREG_HIP(ctx, hipGetLastError());
     k_vox_long_runs<<<std::min(div_up_u(nr, 4u), 2048u), kVBlock, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun,
                                                                            long_runs);
     RSREG_HIP(ctx, hipGetLastError());
+    if (const uint32_t huge_at_most = (N - std::min(N, nr)) / (kHugeRun - 1u)) {   // (nr runs hold at least one point each)
+        k_vox_huge_runs<<<std::min(huge_at_most, 512u), kHB, 0, st>>>(d_in, stride, N, skeys, svals, start, stats, cent, ekey, erun, huge_runs);
+        RSREG_HIP(ctx, hipGetLastError());
+    }
     const uint32_t *emit_order = order;
     {
         const Radix32Plan plan2 = radix32_plan(nr, 0, ebits);   // (nr <= n: its state fits the block cleared for n runs)

@@ -271,24 +271,32 @@ __global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, siz
 // round-to-nearest-even(m + t/u) u: the step moves m by rndne(t/u) whatever m is -- except when t/u lies exactly half way
 // between two integers, where the result is the even neighbour, i.e. depends on the PARITY of m only.  So every step, and every
 // sequence of steps, is a function m -> m + (m odd ? A1 : A0); two such functions compose into another (f then g: h_p = f_p +
-// g_[(p + f_p) & 1]), the composition is associative, and a block can scan it: thread t composes its own kHL points, the block
-// scans the 512 functions, and every thread learns the sum it would START from.
+// g_[(p + f_p) & 1]), the composition is associative, and a wave can scan it: lane l composes its own kHL points, the wave
+// scans the 64 functions (plain integer additions unless somebody met a half-way case), and every lane learns the sum it would
+// START from.
 //
 // The binade is only an assumption (the sum doubles ~17 times on its way to 10^5 points, a coordinate may cancel, a colour sum
-// may pass 2^24).  It is not argued away, it is CHECKED: every thread adds its own points to its predicted start with real float
-// additions (16 of them, all threads at once) and compares the bits with its predicted end.  Thread 0 starts from the true sum;
-// if thread i started from the true sum and its real additions end where the prediction said, thread i + 1 started from the
-// true sum too.  So everything before the first thread that disagrees is exact whatever the prediction was made of, that
-// thread's REAL end is the true sum there, and the block goes round again from the next thread with the binade of that sum.
-// A round costs what 16 additions cost; a run of 130 000 points takes ~30 of them instead of 130 000 dependent additions.
-// (Six sums: x y z r g b.  PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back:
-// the centroid's fourth component is not part of the output record, and this kernel leaves it out.)
-constexpr int kHB = 512;                 // threads of a block = functions of a scan
-constexpr int kHL = 16;                  // points a thread composes in a full window
-constexpr int kHWaves = kHB / 64;
-constexpr uint32_t kHPrefix = 1024;      // the first points of a run are added one after the other (the sum changes binade every few points there)
-static_assert(kHugeRun >= kHPrefix, "a huge run is longer than its prefix");
-constexpr uint32_t kHNone = 0xffffffffu;
+// may pass 2^24).  It is not argued away, it is CHECKED: every lane adds its own points to its predicted start with real float
+// additions (16 of them, all lanes at once) and compares the bits with its predicted end.  Lane 0 starts from the true sum; if
+// lane i started from the true sum and its real additions end where the prediction said, lane i + 1 started from the true sum
+// too.  So everything before the first lane that disagrees is exact whatever the prediction was made of, that lane's REAL end is
+// the true sum there, and the wave goes round again from the next lane with the binade of that sum.  A round costs what ~40
+// additions cost and settles up to 1 024 points; a run of 37 000 points (the longest of a 307 k-point frame) takes ~50 rounds.
+//
+// One workgroup per run.  Its eight waves fetch the run's records -- 8 192 points at a time, the next 8 192 in flight in
+// registers, the indices of the 8 192 after those as well -- and lay them out in the LDS by component; then six of the waves sum
+// ONE component each (x y z r g b), window after window of 1 024 points, every wave at its own pace: no wave waits for
+// another's rounds.  (PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back: the
+// centroid's fourth component is not part of the output record, and this kernel leaves it out.)
+constexpr int kHB = 512;                          // threads of a workgroup
+constexpr int kHL = 16;                           // points of a lane in a window
+constexpr uint32_t kHWin = 64u * kHL;             // points of a window (one wave, one round at least)
+constexpr uint32_t kHWins = 8;                    // windows in the LDS at a time
+constexpr uint32_t kHSuper = kHWin * kHWins;      // = points the workgroup fetches at a time
+constexpr int kHPer = (int)(kHSuper / kHB);       // ... each thread this many
+constexpr uint32_t kHPitch = 68;                  // a window in the LDS: 16 rows (a lane's i-th point) of 64 values, 68 words apart:
+                                                  //   64 consecutive points written (16 rows x 4 columns) hit 64 different banks, a row read does too
+static_assert(kHL == 16 && kHPer == 16, "the fetch loops and the window layout below are written for 16 points a thread");
 
 struct HFn {   // m -> m + (m odd ? a1 : a0), modulo 2^32
     uint32_t a0, a1;
@@ -314,19 +322,94 @@ __device__ __forceinline__ HBase h_base(uint32_t bits)
 }
 __device__ __forceinline__ uint32_t h_bits(const HBase &b, uint32_t m) { return ((((b.e - 1u) << 23) + m) & 0x7fffffffu) | (b.neg << 31); }
 
-struct HWin {   // a thread's points of one window (positions past the end of the run: +0.0f, which leaves a sum as it is)
-    float x[kHL], y[kHL], z[kHL];
-    uint32_t rgb[kHL];
-};
-__device__ __forceinline__ float h_term(const HWin &w, int i, int c)
+// inclusive sum over the 64 lanes of a wave in six DPP steps (rows of 16 lanes, then the rows' last lanes handed on)
+__device__ __forceinline__ uint32_t h_wave_scan_add(uint32_t v)
 {
-    switch (c) {
-    case 0: return w.x[i];
-    case 1: return w.y[i];
-    case 2: return w.z[i];
-    case 3: return (float)((w.rgb[i] >> 16) & 0xffu);
-    case 4: return (float)((w.rgb[i] >> 8) & 0xffu);
-    default: return (float)(w.rgb[i] & 0xffu);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// One window of one component: t[i] = the lane's i-th term (a float; bytes already converted), s = the sum so far (bits, the
+// same in every lane).  Returns the sum after the window.  kBytes: the terms are integers 0..255 (a colour).
+template <bool kBytes>
+__device__ __forceinline__ uint32_t h_window(const float (&t)[kHL], uint32_t s, uint32_t lane)
+{
+    uint32_t lo = 0;   // lanes below lo are settled; s is the true sum in front of lane lo
+    for (;;) {
+        const HBase bs = h_base(s);
+        const int sh = 150 - (int)bs.e;
+        HFn own{0u, 0u};
+        if (lane >= lo) {
+            if (kBytes && sh >= 0 && sh < 20) {
+                // a colour sum well below 2^24: bytes on a grid of 2^-sh, nothing to round (should the sum leave that range
+                // inside the window, the check below notices, like everything else)
+                uint32_t sum = 0;
+#pragma unroll
+                for (int i = 0; i < kHL; ++i) sum += (uint32_t)t[i];
+                sum <<= sh;
+                own.a0 = own.a1 = bs.neg ? 0u - sum : sum;
+            } else {
+                // all 16 steps as plain ones first (no branch between them: they overlap in the pipeline) ...
+                bool tie_any = false;
+#pragma unroll
+                for (int i = 0; i < kHL; ++i) {
+                    float q = ldexpf(t[i], sh);
+                    if (bs.neg) q = -q;
+                    const float rn = rintf(q);
+                    tie_any |= fabsf(q - rn) == 0.5f;
+                    own.a0 += (uint32_t)(int)rn;
+                }
+                own.a1 = own.a0;
+                if (__builtin_amdgcn_ballot_w64(tie_any)) {   // (uniform, rare) ... again with the parity where a step needs it
+                    own = HFn{0u, 0u};
+#pragma unroll
+                    for (int i = 0; i < kHL; ++i) {
+                        float q = ldexpf(t[i], sh);
+                        if (bs.neg) q = -q;
+                        const float rn = rintf(q);
+                        const bool tie = fabsf(q - rn) == 0.5f;
+                        const uint32_t st = (uint32_t)(int)(tie ? floorf(q) : rn);
+                        const uint32_t x0 = own.a0 + st, x1 = own.a1 + st;
+                        own.a0 = x0 + (tie ? (x0 & 1u) : 0u);
+                        own.a1 = x1 + (tie ? (~x1 & 1u) : 0u);
+                    }
+                }
+            }
+        }
+        HFn upto, before;   // the lanes up to and including this one / before it
+        if (__builtin_amdgcn_ballot_w64(own.a0 != own.a1)) {   // (uniform, rare) a step of this window depends on the parity
+            upto = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                HFn f;
+                f.a0 = __shfl_up(upto.a0, d);
+                f.a1 = __shfl_up(upto.a1, d);
+                if (lane >= (uint32_t)d) upto = h_then(f, upto);
+            }
+            before.a0 = __shfl_up(upto.a0, 1);
+            before.a1 = __shfl_up(upto.a1, 1);
+            if (lane == 0u) before = HFn{0u, 0u};
+        } else {   // plain steps compose by adding
+            upto.a0 = upto.a1 = h_wave_scan_add(own.a0);
+            before.a0 = before.a1 = upto.a0 - own.a0;
+        }
+        const uint32_t p0 = bs.m & 1u;
+        float v = __uint_as_float(h_bits(bs, bs.m + (p0 ? before.a1 : before.a0)));
+#pragma unroll
+        for (int i = 0; i < kHL; ++i) v = __fadd_rn(v, t[i]);
+        const uint32_t want = h_bits(bs, bs.m + (p0 ? upto.a1 : upto.a0));
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(lane >= lo && __float_as_uint(v) != want);
+        if (!bad) return (uint32_t)__builtin_amdgcn_readlane((int)want, 63);
+        const uint32_t first = (uint32_t)__builtin_ctzll(bad);
+        s = (uint32_t)__shfl((int)__float_as_uint(v), (int)first);
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        if (first == 63u) return s;
+        lo = first + 1u;
     }
 }
 
@@ -334,194 +417,74 @@ __global__ __launch_bounds__(kHB) void k_vox_huge_runs(const char *recs, size_t 
                                                        const uint32_t *svals, const uint32_t *start, const uint32_t *stats,
                                                        float *cent, uint32_t *ekey, uint32_t *erun, const uint32_t *huge_runs)
 {
-    __shared__ __attribute__((aligned(16))) float sh_pre[6][kHPrefix];
-    __shared__ HFn sh_tot[6][kHWaves];
-    __shared__ uint32_t sh_mis[6][kHWaves], sh_acc[6][kHWaves], sh_end[6], sh_s[6];
+    // [component: x y z rgb][window][row][column]
+    __shared__ uint32_t sh[4][kHWins][kHL * kHPitch];
+    __shared__ uint32_t sh_s[6];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nr = stats[0], nfin = stats[1], n_huge = stats[3];
     const bool vec = (stride % 16 == 0) && ((reinterpret_cast<size_t>(recs) & 15) == 0);
     for (uint32_t k = blockIdx.x; k < n_huge; k += gridDim.x) {
         const uint32_t r = huge_runs[k];
         const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
-        // window w: lw(w) points a thread, kHB lw(w) points in all; the windows double with the sum until they are full
-        auto lw_of = [](uint32_t w) -> uint32_t { return w < 3u ? (2u << w) : (uint32_t)kHL; };
-        auto fetch_idx = [&](uint32_t base, uint32_t lw, uint32_t idx[kHL]) {
+        // thread t fetches the points base + t + kHB j (consecutive threads, consecutive indices).  Every load is unconditional
+        // -- a position past the end of the run reads SOME record of the cloud and is set to zero where it is written to the
+        // LDS -- so that nothing waits for a load before the next one is issued.
+        auto fetch_idx = [&](uint32_t base, uint32_t idx[kHPer]) {
 #pragma unroll
-            for (int i = 0; i < kHL; ++i) {
-                const uint32_t p = base + tid * lw + (uint32_t)i;
-                idx[i] = ((uint32_t)i < lw && p < b) ? svals[p] : kHNone;
-            }
+            for (int j = 0; j < kHPer; ++j) idx[j] = svals[min(base + tid + (uint32_t)kHB * (uint32_t)j, n - 1u)];
         };
-        auto fetch_recs = [&](const uint32_t idx[kHL], HWin &w) {
+        auto fetch_recs = [&](const uint32_t idx[kHPer], VoxRaw rec[kHPer]) {
 #pragma unroll
-            for (int i = 0; i < kHL; ++i) {
-                VoxRaw v{0.0f, 0.0f, 0.0f, 0u};
-                if (idx[i] != kHNone) v = vox_load(recs + (size_t)idx[i] * stride, vec);
-                w.x[i] = v.x; w.y[i] = v.y; w.z[i] = v.z; w.rgb[i] = v.rgb;
-            }
+            for (int j = 0; j < kHPer; ++j) rec[j] = vox_load(recs + (size_t)idx[j] * stride, vec);
         };
-        // what is in flight: the records of window 0, the indices of window 1
-        uint32_t idx[kHL];
-        HWin cur;
-        uint32_t base = a + kHPrefix, w_no = 0;
-        fetch_idx(base, lw_of(0), idx);
-        // the first kHPrefix points: through LDS, six lanes of wave 0 add them in input order
-        __syncthreads();   // (the block's previous run has been read out of the LDS)
-        for (uint32_t e = tid; e < kHPrefix; e += kHB) {
-            const VoxRaw v = vox_load(recs + (size_t)svals[a + e] * stride, vec);
-            sh_pre[0][e] = v.x; sh_pre[1][e] = v.y; sh_pre[2][e] = v.z;
-            sh_pre[3][e] = (float)((v.rgb >> 16) & 0xffu);
-            sh_pre[4][e] = (float)((v.rgb >> 8) & 0xffu);
-            sh_pre[5][e] = (float)(v.rgb & 0xffu);
-        }
-        fetch_recs(idx, cur);
-        fetch_idx(base + kHB * lw_of(0), lw_of(1), idx);
-        __syncthreads();
-        if (tid < 6) {
-            float acc = 0.0f;
-            const float4 *v = reinterpret_cast<const float4 *>(&sh_pre[tid][0]);
-            for (uint32_t i = 0; i < kHPrefix / 4; ++i) {
-                const float4 q = v[i];
-                acc = __fadd_rn(acc, q.x);
-                acc = __fadd_rn(acc, q.y);
-                acc = __fadd_rn(acc, q.z);
-                acc = __fadd_rn(acc, q.w);
+        uint32_t idx[kHPer];
+        VoxRaw rec[kHPer];
+        fetch_idx(a, idx);
+        fetch_recs(idx, rec);
+        fetch_idx(a + kHSuper, idx);
+        uint32_t s = 0u;   // (waves 0..5) the wave's component so far: +0.0f
+        for (uint32_t base = a; base < b; base += kHSuper) {
+            __syncthreads();   // (the LDS has been read: the previous 8 192 points, or the previous run's)
+#pragma unroll
+            for (int j = 0; j < kHPer; ++j) {
+                const uint32_t e = tid + (uint32_t)kHB * (uint32_t)j;        // point e of these 8 192
+                const uint32_t w = e / kHWin, ew = e % kHWin;                 // window, point of the window: lane ew / 16, its point ew % 16
+                const uint32_t at = (ew % (uint32_t)kHL) * kHPitch + ew / (uint32_t)kHL;
+                const bool in = base + e < b;   // (past the end of the run: +0.0f and a black byte leave every sum as it is)
+                sh[0][w][at] = in ? __float_as_uint(rec[j].x) : 0u;
+                sh[1][w][at] = in ? __float_as_uint(rec[j].y) : 0u;
+                sh[2][w][at] = in ? __float_as_uint(rec[j].z) : 0u;
+                sh[3][w][at] = in ? rec[j].rgb : 0u;
             }
-            sh_s[tid] = __float_as_uint(acc);
-        }
-        __syncthreads();
-        uint32_t s[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s[c] = sh_s[c];
-        while (base < b) {
-            const uint32_t lw = lw_of(w_no);
-            const uint32_t next_base = base + kHB * lw;
-            HWin nxt;
-            if (next_base < b) {   // (uniform) the next window's records and the indices of the one after go out now
-                fetch_recs(idx, nxt);
-                fetch_idx(next_base + kHB * lw_of(w_no + 1), lw_of(w_no + 2), idx);
+            if (base + kHSuper < b) {   // (uniform) the next 8 192 records and the indices of those after them go out now
+                fetch_recs(idx, rec);
+                fetch_idx(base + 2u * kHSuper, idx);
             }
-            uint32_t lo[6] = {0, 0, 0, 0, 0, 0};   // component c is exact up to thread lo[c] (exclusive); s[c] is the true sum there
-            bool open = true;
-            while (open) {
-                HFn own[6], before[6];   // a thread's own points; (after the scan) its wave's lanes before it / up to and including it
+            __syncthreads();
+            if (wave < 6u) {
+                const uint32_t n_win = min(kHWins, (b - base + kHWin - 1u) / kHWin);
+                for (uint32_t w = 0; w < n_win; ++w) {
+                    float t[kHL];
+                    if (wave < 3u) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    own[c] = before[c] = HFn{0u, 0u};
-                    if (lo[c] >= (uint32_t)kHB) continue;   // (uniform)
-                    const HBase bs = h_base(s[c]);
-                    const int sh = 150 - (int)bs.e;
-                    if (c >= 3 && sh >= 0 && sh < 24) {
-                        // a colour sum below 2^24: bytes on a grid of 2^-sh, nothing to round (if the sum leaves that range inside
-                        // the window the check below notices, like everything else)
-                        if (tid >= lo[c]) {
-                            uint32_t sum = 0;
-#pragma unroll
-                            for (int i = 0; i < kHL; ++i)
-                                if ((uint32_t)i < lw) sum += (cur.rgb[i] >> (8 * (5 - c))) & 0xffu;
-                            sum <<= sh;
-                            if (bs.neg) sum = 0u - sum;
-                            own[c].a0 = own[c].a1 = sum;
-                        }
-                    } else if (tid >= lo[c]) {
-#pragma unroll
-                        for (int i = 0; i < kHL; ++i) {
-                            if ((uint32_t)i >= lw) continue;   // (uniform)
-                            float q = ldexpf(h_term(cur, i, c), sh);
-                            if (bs.neg) q = -q;
-                            const float rn = rintf(q);
-                            const bool tie = fabsf(q - rn) == 0.5f;
-                            if (__builtin_amdgcn_ballot_w64(tie)) {   // (uniform) somebody's step depends on the parity
-                                const uint32_t st = (uint32_t)(int)(tie ? floorf(q) : rn);
-                                const uint32_t x0 = own[c].a0 + st, x1 = own[c].a1 + st;
-                                own[c].a0 = x0 + (tie ? (x0 & 1u) : 0u);
-                                own[c].a1 = x1 + (tie ? (~x1 & 1u) : 0u);
-                            } else {
-                                const uint32_t st = (uint32_t)(int)rn;
-                                own[c].a0 += st;
-                                own[c].a1 += st;
-                            }
-                        }
-                    }
-                    // inclusive scan over the wave; the wave's total goes to the LDS
-                    HFn inc = own[c];
-                    if (__builtin_amdgcn_ballot_w64(inc.a0 != inc.a1)) {   // (uniform) a step of this wave depends on the parity
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            HFn f;
-                            f.a0 = __shfl_up(inc.a0, d);
-                            f.a1 = __shfl_up(inc.a1, d);
-                            if (lane >= (uint32_t)d) inc = h_then(f, inc);
-                        }
-                    } else {   // plain steps compose by adding
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t f = __shfl_up(inc.a0, d);
-                            if (lane >= (uint32_t)d) inc.a0 += f;
-                        }
-                        inc.a1 = inc.a0;
-                    }
-                    if (lane == 63u) sh_tot[c][wave] = inc;
-                    before[c].a0 = __shfl_up(inc.a0, 1);
-                    before[c].a1 = __shfl_up(inc.a1, 1);
-                    if (lane == 0u) before[c] = HFn{0u, 0u};
-                    own[c] = inc;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    if (lo[c] >= (uint32_t)kHB) continue;
-                    HFn pre{0u, 0u};   // the waves before this one
-                    for (uint32_t w = 0; w < wave; ++w) pre = h_then(pre, sh_tot[c][w]);
-                    const HFn bef = h_then(pre, before[c]);
-                    const HFn upto = h_then(pre, own[c]);
-                    const HBase bs = h_base(s[c]);
-                    const uint32_t p0 = bs.m & 1u;
-                    float v = __uint_as_float(h_bits(bs, bs.m + (p0 ? bef.a1 : bef.a0)));
-#pragma unroll
-                    for (int i = 0; i < kHL; ++i) {
-                        if ((uint32_t)i < lw) v = __fadd_rn(v, h_term(cur, i, c));
-                    }
-                    const uint32_t want = h_bits(bs, bs.m + (p0 ? upto.a1 : upto.a0));
-                    const bool wrong = tid >= lo[c] && __float_as_uint(v) != want;
-                    const unsigned long long bad = __builtin_amdgcn_ballot_w64(wrong);
-                    const uint32_t first = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-                    const uint32_t v_first = __shfl(__float_as_uint(v), (int)(first & 63u));
-                    if (lane == 0u) {
-                        sh_mis[c][wave] = bad ? wave * 64u + first : kHNone;
-                        sh_acc[c][wave] = v_first;
-                    }
-                    if (tid == (uint32_t)kHB - 1u) sh_end[c] = want;
-                }
-                __syncthreads();
-                open = false;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    if (lo[c] >= (uint32_t)kHB) continue;
-                    uint32_t t_bad = kHNone;
-                    for (int w = kHWaves - 1; w >= 0; --w)
-                        if (sh_mis[c][w] != kHNone) t_bad = sh_mis[c][w];
-                    if (t_bad == kHNone) {
-                        s[c] = sh_end[c];
-                        lo[c] = (uint32_t)kHB;
+                        for (int i = 0; i < kHL; ++i) t[i] = __uint_as_float(sh[wave][w][(uint32_t)i * kHPitch + lane]);
+                        s = h_window<false>(t, s, lane);
                     } else {
-                        s[c] = sh_acc[c][t_bad >> 6];
-                        lo[c] = t_bad + 1u;
-                        if (lo[c] < (uint32_t)kHB) open = true;
+                        const uint32_t shift = 8u * (5u - wave);
+#pragma unroll
+                        for (int i = 0; i < kHL; ++i) t[i] = (float)((sh[3][w][(uint32_t)i * kHPitch + lane] >> shift) & 0xffu);
+                        s = h_window<true>(t, s, lane);
                     }
                 }
-                // (the next round writes sh_tot only after every wave has passed the barrier above, and sh_mis / sh_acc /
-                //  sh_end only after the barrier behind its scan)
             }
-            if (next_base < b) cur = nxt;
-            base = next_base;
-            ++w_no;
         }
+        if (wave < 6u && lane == 0u) sh_s[wave] = s;
+        __syncthreads();
         if (tid == 0) {
             float all[7];
-            all[0] = __uint_as_float(s[0]); all[1] = __uint_as_float(s[1]); all[2] = __uint_as_float(s[2]);
+            all[0] = __uint_as_float(sh_s[0]); all[1] = __uint_as_float(sh_s[1]); all[2] = __uint_as_float(sh_s[2]);
             all[3] = 0.0f;   // (the sum PCL never reads)
-            all[4] = __uint_as_float(s[3]); all[5] = __uint_as_float(s[4]); all[6] = __uint_as_float(s[5]);
+            all[4] = __uint_as_float(sh_s[3]); all[5] = __uint_as_float(sh_s[4]); all[6] = __uint_as_float(sh_s[5]);
             vox_store_run(all, a, b, n, nfin, r, skeys, svals, cent, ekey, erun);
         }
     }

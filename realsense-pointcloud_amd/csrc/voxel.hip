@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kVBlock) void k_vox_starts(const uint32_t *skeys, c
 }
 
 constexpr uint32_t kLongRun = 48;   // runs from this length on are summed by a whole wave (k_vox_long_runs)
-constexpr uint32_t kHugeRun = 4096; // and from this length on by a block that scans instead of adding (k_vox_huge_runs)
+constexpr uint32_t kHugeRun = 1024; // and from this length on by a workgroup that scans instead of adding (k_vox_huge_runs)
 
 __device__ __forceinline__ void vox_store_run(const float acc[7], uint32_t a, uint32_t b, uint32_t n, uint32_t nfin, uint32_t r,
                                               const uint32_t *skeys, const uint32_t *svals, float *cent, uint32_t *ekey, uint32_t *erun)

@@ -95,7 +95,7 @@ def blob(rs, rng, n, lo, hi, rgba=None):
     return rs.PointCloud.from_xyz(xyz, rgba=rgba)
 
 
-@pytest.mark.parametrize("n", [4095, 4096, 4097, 5119, 5120, 5121, 7168, 7169, 11264, 11265, 19456, 19457, 27648, 40000])
+@pytest.mark.parametrize("n", [1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 5119, 5120, 5121, 7168, 7169, 11264, 11265, 19456, 19457, 27648, 40000])
 def test_huge_run_lengths_around_the_window_edges(api, rs, n):
     """One voxel, one run: k_vox_huge_runs (runs of 4 096 points and more) scans instead of adding -- a prefix of 1 024 points, then
     windows of 1 024, 2 048, 4 096, 8 192, 8 192 ... points; the lengths sit on and beside every edge."""

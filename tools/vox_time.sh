@@ -24,7 +24,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 8e3
 print("   all kernels: %.1f us per filter" % tot)
-for r in rows[:14]:
-    print("   %-60s %3d calls %9.1f us avg" % (r["Name"].split("(")[0][-60:], int(r["Calls"]), float(r["AverageNs"]) / 1e3))
+for r in rows[:16]:
+    name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rsreg::", "")
+    print("   %-50s %3d calls %9.1f us each" % (name[:50], int(r["Calls"]), float(r["AverageNs"]) / 1e3))
 PY
 done

@@ -30,6 +30,7 @@ struct rsreg_cloud {
     // not known (resolve)
     mutable bool filter_pending = false;
     uint64_t filter_ticket = 0;
+    int filter_worker = 0;   // which side worker of the context runs (ran) that job
     int filter_rc = 0;
     // rsreg_cloud_download_async: a copy of these records to the host may still be reading them
     hipEvent_t ev_down = nullptr;
@@ -117,7 +118,7 @@ hipError_t resolve(const rsreg_cloud *c)
 {
     if (!c || !c->filter_pending) return hipSuccess;
     c->filter_pending = false;
-    (void)c->ctx->side_worker->wait(c->filter_ticket);
+    (void)c->ctx->side_workers[c->filter_worker]->wait(c->filter_ticket);
     return c->filter_rc ? hipErrorUnknown : hipSuccess;   // (the job has left its message in the context: fail())
 }
 
@@ -548,21 +549,29 @@ int rsreg_cloud_filter(rsreg_ctx *ctx, const rsreg_cloud *in, const float leaf[3
 // has been used; in != out.
 namespace {
 
-// The next scratch set of the side worker, its stream behind what the main stream holds so far (`in` may have been
-// produced there, and the buffer `out` is about to get may come from the pool with work of its previous owner queued).
-// The sets take turns: a job queues behind the one that used its set last (same stream) and runs beside the others.
-int side_begin(rsreg_ctx *ctx, int *set_out)
+// The side worker of a job and its next scratch set, the set's stream behind what the main stream holds so far (`in` may
+// have been produced there, and the buffer `out` is about to get may come from the pool with work of its previous owner
+// queued).  follow >= 0: the worker that runs the job this one's input comes from (jobs of one worker run in the order
+// they were posted); -1: the workers take turns.  A worker's two sets take turns: a job queues behind the one that used
+// its set last (same stream) and runs beside the others.
+int side_begin(rsreg_ctx *ctx, int follow, int *worker_out, int *set_out)
 {
-    const int set = ctx->side_next;
-    ctx->side_next = (ctx->side_next + 1) % rsreg_ctx::kSideSets;
+    int worker = follow;
+    if (worker < 0) {
+        worker = tunables().one_side_worker ? 0 : ctx->side_rr;
+        ctx->side_rr = (ctx->side_rr + 1) % rsreg_ctx::kSideWorkers;
+    }
+    const int set = worker + rsreg_ctx::kSideWorkers * ctx->side_turn[worker];
+    ctx->side_turn[worker] ^= 1;
     rsreg_ctx::SideSet &ss = ctx->side_sets[set];
     ctx->prep_join();
     if (!ss.stream) RSREG_HIP(ctx, hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
     if (!ctx->ev_side_gate) RSREG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_gate, hipEventDisableTiming));
-    if (!ctx->side_worker) ctx->side_worker = new rsreg::TicketWorker();
+    if (!ctx->side_workers[worker]) ctx->side_workers[worker] = new rsreg::TicketWorker();
     RSREG_HIP(ctx, hipEventRecord(ctx->ev_side_gate, ctx->stream));
     RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_side_gate, 0));
     if (ctx->src_pending) { (void)ctx->source_enqueued(); RSREG_HIP(ctx, hipStreamWaitEvent(ss.stream, ctx->ev_src_done, 0)); }
+    *worker_out = worker;
     *set_out = set;
     return RSREG_OK;
 }
@@ -603,8 +612,8 @@ int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float 
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     if (!chained) RSREG_HIP(ctx, settle(in));
     RSREG_HIP(ctx, settle(out));
-    int set = 0;
-    rc = side_begin(ctx, &set);
+    int set = 0, worker = 0;
+    rc = side_begin(ctx, chained ? in->filter_worker : -1, &worker, &set);
     if (rc) return rc;
     const size_t stride = in->stride;
     // the filter's twenty launches and its round trip for the number of output records are a third of a frame's host time
@@ -616,7 +625,8 @@ int rsreg_cloud_filter_async(rsreg_ctx *ctx, const rsreg_cloud *in, const float 
     out->version++;
     out->n = 0; out->stride = stride; out->width = 0; out->height = 1; out->is_dense = 0;
     out->filter_rc = 0;
-    out->filter_ticket = ctx->side_worker->post([ctx, in, out, chained, stride, l0, l1, l2, set]() -> int {
+    out->filter_worker = worker;
+    out->filter_ticket = ctx->side_workers[worker]->post([ctx, in, out, chained, stride, l0, l1, l2, set]() -> int {
         rsreg_ctx::SideSet &ws = ctx->side_sets[set];
         const float lf[3] = {l0, l1, l2};
         uint32_t nr = 0;
@@ -655,8 +665,8 @@ int rsreg_cloud_edge_features_async(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg
     RSREG_HIP(ctx, hipSetDevice(ctx->device));
     RSREG_HIP(ctx, settle(out));
     if (in->downloading) RSREG_HIP(ctx, settle(in));   // (rare: only its own download pending needs the caller's stream)
-    int set = 0;
-    rc = side_begin(ctx, &set);
+    int set = 0, worker = 0;
+    rc = side_begin(ctx, -1, &worker, &set);
     if (rc) return rc;
     const size_t stride = in->stride, n_in = in->n;
     const uint32_t w = in->width, h = in->height;
@@ -667,7 +677,8 @@ int rsreg_cloud_edge_features_async(rsreg_ctx *ctx, const rsreg_cloud *in, rsreg
     out->version++;
     out->n = 0; out->stride = stride; out->width = 0; out->height = 1; out->is_dense = in->is_dense;
     out->filter_rc = 0;
-    out->filter_ticket = ctx->side_worker->post([ctx, out, src, stride, w, h, inf, set]() -> int {
+    out->filter_worker = worker;
+    out->filter_ticket = ctx->side_workers[worker]->post([ctx, out, src, stride, w, h, inf, set]() -> int {
         rsreg_ctx::SideSet &ws = ctx->side_sets[set];
         uint32_t ne = 0;
         int r = hipSetDevice(ctx->device) == hipSuccess ? RSREG_OK : RSREG_ERR_HIP;

@@ -1762,7 +1762,8 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         delete ctx->src_worker;
         ctx->src_worker = nullptr;
     }
-    if (ctx->side_worker) ctx->side_worker->shutdown();
+    for (rsreg::TicketWorker *w : ctx->side_workers)
+        if (w) w->shutdown();
     if (ctx->up_worker) ctx->up_worker->shutdown();
     if (ctx->down_worker) ctx->down_worker->shutdown();
     (void)hipStreamSynchronize(ctx->stream);
@@ -1822,10 +1823,11 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
         for (hipEvent_t e : ctx->ev_down) (void)hipEventDestroy(e);
     }
     for (rsreg::PinnedBuf &b : ctx->h_down) b.release();
-    if (ctx->side_worker) {
-        ctx->side_worker->shutdown();
-        delete ctx->side_worker;
-        ctx->side_worker = nullptr;
+    for (rsreg::TicketWorker *&w : ctx->side_workers) {
+        if (!w) continue;
+        w->shutdown();
+        delete w;
+        w = nullptr;
     }
     for (rsreg_ctx::SideSet &ss : ctx->side_sets) {
         if (ss.stream) {

@@ -294,16 +294,21 @@ struct rsreg_ctx {
     // rsreg_cloud_filter_async: scratch sets and streams of their own, so that the filters of the next frames (one wave
     // per long run, latency-bound: 0.4 ms for PCL's default 1 m leaf) run under the alignment of this one AND beside each
     // other; a set is used again in turn, behind the filter that used it last (same stream).  ev_side_gate lets a filter
-    // start after what the main stream holds.
-    static constexpr int kSideSets = 3;
+    // start after what the main stream holds.  Round 6: TWO side workers (threads) -- a frame's extraction and filter are ~20
+    // launches and two waits for counts, as long as the frame's two alignments on the caller's thread, and every other
+    // frame waited for them; jobs that do not depend on each other alternate between the workers, a job whose input is the
+    // output of a job still queued follows it on the same worker.  Worker w owns the sets w and w + 2 and uses them in turn.
+    static constexpr int kSideWorkers = 2;
+    static constexpr int kSideSets = 2 * kSideWorkers;
     struct SideSet {
         hipStream_t stream = nullptr;
         rsreg::DevBuf out, keys, keys_alt, vals, vals_alt, flags, scan, cent, misc, tmp;
         rsreg::PinnedBuf host;
     } side_sets[kSideSets];
-    int side_next = 0;
+    int side_turn[kSideWorkers] = {0, 0};   // which of its two sets a worker's next job takes
+    int side_rr = 0;                          // the worker of the next job that follows no other
     hipEvent_t ev_side_gate = nullptr;
-    rsreg::TicketWorker *side_worker = nullptr;   // (queues those filters: rsreg_cloud_filter_async returns at once)
+    rsreg::TicketWorker *side_workers[kSideWorkers] = {nullptr, nullptr};   // (queue those jobs: rsreg_cloud_filter_async returns at once)
 
     // ---- NDT
     bool have_ndt_target = false;

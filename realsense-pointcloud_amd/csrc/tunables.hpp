@@ -27,6 +27,7 @@ struct Tunables {
     bool adaptive_cell = true;             // RSREG_NO_ADAPTIVE_CELL=1: the brick-hash build never refines its cell size
     bool box_cache = true;                 // RSREG_NO_BOX_CACHE=1: a cloud handle's bounding box is measured by every build / load
     bool count_sort = true;                // RSREG_COUNT_SORT=0: the index by sorting (k_dense_keys, radix sort, k_dense_compact) instead of counting (cellsort.hpp)
+    bool one_side_worker = false;          // RSREG_ONE_SIDE_WORKER=1: the side jobs of a context (filters, edge extractions of the frames ahead) on one thread as in rounds 3-5 (default: two, alternating)
     bool cc_apart = false;                 // RSREG_CC_APART=1: the counting build's scatter / occupancy words / small cells / crowded cells as four launches (rounds 5; default: two)
     bool scan_apart = false;               // RSREG_SCAN_APART=1: sort-based build: flag, scan, scatter as three launches
     // ---- source
@@ -75,6 +76,7 @@ inline Tunables tunables_from_environment()
     v.box_cache = !on("RSREG_NO_BOX_CACHE");
     v.count_sort = !off("RSREG_COUNT_SORT");
     v.cc_apart = on("RSREG_CC_APART");
+    v.one_side_worker = on("RSREG_ONE_SIDE_WORKER");
     v.scan_apart = on("RSREG_SCAN_APART");
     v.sort_small = on("RSREG_SORT_SMALL");
     if (const char *e = std::getenv("RSREG_PLAIN_SOURCE_MAX")) v.plain_source_max = (size_t)std::atoll(e);

@@ -69,12 +69,23 @@ class RegistrationScheme {
     // engine extra (stream_result): what the end of the loop waited for, in ms -- the host copy of frame 0, the downloads still
     // on their way -- and the host time of all download_async calls together
     double stream_finish_ms[3] = {0, 0, 0};
+    // engine extra (device-resident loops): where the caller's thread spent the frame loop, in ms over all frames, call by call --
+    // IncrementalICP: [0] queueing the uploads / filters of the frames ahead, [1] setInputSource, [2] setInputTarget, [3] align,
+    // [4] transformPointCloud, [5] +=, [6] handing the moved points to the result's download
+    double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   protected:
     void clock_start()
     {
-        clock0_ = std::chrono::steady_clock::now();
+        clock0_ = lap_ = std::chrono::steady_clock::now();
         frame_clock_ms.clear();
+        for (double &v : stage_ms) v = 0;
+    }
+    void clock_lap(int stage)   // the time since the last lap (or mark) goes to stage_ms[stage]
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (stage >= 0) stage_ms[stage] += std::chrono::duration<double, std::milli>(now - lap_).count();
+        lap_ = now;
     }
     template <class R> void note_finish(const R &r)
     {
@@ -85,7 +96,7 @@ class RegistrationScheme {
     void clock_mark() { frame_clock_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0_).count()); }
 
   private:
-    std::chrono::steady_clock::time_point clock0_;
+    std::chrono::steady_clock::time_point clock0_, lap_;
 };
 
 class TwoPhaseRegistrationScheme : public RegistrationScheme {
@@ -227,15 +238,23 @@ class IncrementalICP : public RegistrationScheme {
         for (size_t k = 1; k < n; ++k, clock_mark()) {
             rgb_device_cloud &frame = frames[k % kRing], &reduced = reduced_of[k % (kFilters + 1)];
             // (frame k + kUploads takes the buffer of frame k - 1, the filtered frame k + kFilters that of frame k - 1)
+            clock_lap(-1);
             if (k + kUploads < n) frames[(k + kUploads) % kRing].upload_deferred(*clouds[k + kUploads]);
             if (k + kFilters < n) voxel.filter_async(frames[(k + kFilters) % kRing], reduced_of[(k + kFilters) % (kFilters + 1)]);
+            clock_lap(0);
             icp.setInputSource(reduced);
+            clock_lap(1);
             icp.setInputTarget(model);
+            clock_lap(2);
             icp.align(aligned);
+            clock_lap(3);
             if (!icp.hasConverged()) continue;
             transformPointCloud(frame, moved, icp.getFinalTransformation());
+            clock_lap(4);
             model += moved;
+            clock_lap(5);
             if (result) result->append(moved);   // on its way to the host while the next frame is aligned
+            clock_lap(6);
             ++merged_frames;
             transforms.push_back(icp.getFinalTransformation());
         }

@@ -343,7 +343,7 @@ int rsreg_cloud_upload(rsreg_cloud *c, const void *points, size_t n, size_t stri
         RSREG_HIP(ctx, ctx->h_stage.reserve(n * stride));
         char *stage = ctx->h_stage.as<char>();
         const char *src = static_cast<const char *>(points);
-        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+        host_parallel_for(n, [=](size_t lo, size_t hi) { rsreg::stream_copy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
         RSREG_HIP(ctx, hipMemcpyAsync(c->buf.ptr, stage, n * stride, hipMemcpyHostToDevice, ctx->stream));
         RSREG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next call
     }
@@ -400,7 +400,7 @@ int upload_on_worker(rsreg_cloud *c, const void *points, size_t n, size_t stride
             }
             if ((e = ctx->h_up[slot].reserve(bytes)) != hipSuccess) return (int)e;
             char *stage = ctx->h_up[slot].as<char>();
-            host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+            host_parallel_for(n, [=](size_t lo, size_t hi) { rsreg::stream_copy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
             if ((e = hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream_copy)) != hipSuccess) return (int)e;
             if ((e = hipEventRecord(ctx->ev_up[slot], ctx->stream_copy)) != hipSuccess) return (int)e;
             ctx->up_busy[slot] = true;

@@ -441,7 +441,7 @@ int rsreg_extract_edge_features(rsreg_ctx *ctx, const void *points, uint32_t wid
     {
         char *stage = ctx->h_stage.as<char>();
         const char *src = static_cast<const char *>(points);
-        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+        host_parallel_for(n, [=](size_t lo, size_t hi) { rsreg::stream_copy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
     }
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, ctx->stream));
     uint32_t ne = 0;

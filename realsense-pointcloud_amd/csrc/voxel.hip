@@ -630,7 +630,7 @@ extern "C" int rsreg_approx_voxel_grid_gpu(rsreg_ctx *ctx, const void *in, size_
     {
         char *stage = ctx->h_stage.as<char>();
         const char *src = static_cast<const char *>(in);
-        host_parallel_for(n, [=](size_t lo, size_t hi) { std::memcpy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
+        host_parallel_for(n, [=](size_t lo, size_t hi) { rsreg::stream_copy(stage + lo * stride, src + lo * stride, (hi - lo) * stride); });
     }
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_vox_in.ptr, ctx->h_stage.ptr, n * stride, hipMemcpyHostToDevice, st));
     uint32_t nr = 0;

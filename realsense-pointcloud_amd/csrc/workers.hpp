@@ -11,6 +11,9 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#if defined(__x86_64__) || defined(_M_X64)
+#include <emmintrin.h>
+#endif
 
 namespace rsreg {
 
@@ -72,6 +75,97 @@ struct SourceWorker {
     }
 };
 
+// A copy of megabytes whose destination nobody reads soon -- a pinned staging buffer on its way to the DMA engine, a result the
+// caller looks at after the registration: the stores go past the caches (x86-64: movntdq), so a line of the destination is
+// not first READ from memory to be overwritten (a third of a plain copy's traffic) and the copy does not evict what the
+// other threads work on.  Staging a 9.8 MB frame with the pool's threads: 0.25-0.31 -> see profiles/r06_link_pipeline.txt.
+inline void stream_copy(void *dst_, const void *src_, size_t bytes)
+{
+#if defined(__x86_64__) || defined(_M_X64)
+    char *dst = static_cast<char *>(dst_);
+    const char *src = static_cast<const char *>(src_);
+    if (bytes < 4096) { std::memcpy(dst, src, bytes); return; }
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+    if (head) { std::memcpy(dst, src, head); dst += head; src += head; bytes -= head; }
+    const size_t blocks = bytes / 64;
+    for (size_t k = 0; k < blocks; ++k) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src) + 0), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src) + 1);
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src) + 2), d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src) + 3);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst) + 0, a);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst) + 1, b);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst) + 2, c);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst) + 3, d);
+        src += 64; dst += 64;
+    }
+    _mm_sfence();
+    if (bytes % 64) std::memcpy(dst, src, bytes % 64);
+#else
+    std::memcpy(dst_, src_, bytes);
+#endif
+}
+
+// Host-side record loops (32-byte records <-> packed xyz in pinned staging, staging <-> the caller's memory) are memory-bound
+// copies of tens of MB that want a handful of cores for a fraction of a millisecond: the threads are kept (starting eight
+// threads costs as much as the copy they are started for).  One loop at a time, process-wide; the caller's thread works too.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m, call_m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(size_t, size_t)> *f = nullptr;
+    size_t n = 0, parts = 0, next = 0, running = 0;
+    bool stop = false;
+
+    explicit HostPool(unsigned workers)
+    {
+        for (unsigned k = 0; k < workers; ++k) th.emplace_back([this] { loop(); });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    // (m held) runs parts until none is left; returns with m held
+    void work(std::unique_lock<std::mutex> &lk)
+    {
+        while (f && next < parts) {
+            const size_t p = next++;
+            const std::function<void(size_t, size_t)> *g = f;
+            const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
+            ++running;
+            lk.unlock();
+            if (lo < hi) (*g)(lo, hi);
+            lk.lock();
+            if (--running == 0 && next >= parts) cv_done.notify_all();
+        }
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (f && next < parts); });
+            if (stop) return;
+            work(lk);
+        }
+    }
+    // f(lo, hi) over [0, count) in `pieces` pieces (more pieces than threads: a slow thread does not hold the others up)
+    void run(size_t count, size_t pieces, const std::function<void(size_t, size_t)> &fn)
+    {
+        if (count == 0) return;
+        if (pieces <= 1 || th.empty()) { fn(0, count); return; }
+        std::lock_guard<std::mutex> one(call_m);
+        std::unique_lock<std::mutex> lk(m);
+        f = &fn; n = count; parts = pieces; next = 0;
+        cv.notify_all();
+        work(lk);
+        cv_done.wait(lk, [&] { return running == 0 && next >= parts; });
+        f = nullptr;
+    }
+};
+
 // Downloads that run beside the frame loop (rsreg_cloud_download_async): the copy lands in one of a few pinned staging
 // buffers on a stream of its own; this thread waits for it and copies it out to the caller's (pageable) memory.
 struct DownloadWorker {
@@ -90,6 +184,7 @@ struct DownloadWorker {
     bool slot_busy[3] = {false, false, false};
     int err = 0;
     std::function<int(const Job &)> wait_ready;   // blocks until the job's staging buffer is filled; 0 or an error code
+    HostPool copiers{5};   // (with this thread: six)
 
     void loop()
     {
@@ -104,13 +199,14 @@ struct DownloadWorker {
             // (wait_ready: the creator's -- hipSetDevice + hipEventSynchronize in the library, a stub in tests/cpp/workers_tsan.cpp)
             const int e = wait_ready ? wait_ready(j) : 0;
             if (e == 0) {
-                // a few threads: one core copies ~10 GB/s, a frame of 10 MB would take as long as the link needs for it
-                const size_t parts = j.bytes >= (size_t)4 << 20 ? 4 : 1, step = (j.bytes + parts - 1) / parts;
-                std::vector<std::thread> helpers;
-                for (size_t p = 1; p < parts; ++p)
-                    helpers.emplace_back([=] { const size_t lo = p * step, hi = std::min(j.bytes, lo + step); if (lo < hi) std::memcpy(j.dst + lo, j.stage + lo, hi - lo); });
-                std::memcpy(j.dst, j.stage, std::min(step, j.bytes));
-                for (auto &t : helpers) t.join();
+                // a few threads of its own (kept: starting them per job cost a quarter of the copy): one core copies ~10 GB/s
+                // into pages it touches first, and a frame of 10 MB would take three times as long as the link needs for it
+                if (j.bytes >= (size_t)4 << 20) {
+                    const std::function<void(size_t, size_t)> fn = [&j](size_t lo, size_t hi) { stream_copy(j.dst + lo * 4096, j.stage + lo * 4096, std::min(j.bytes, hi * 4096) - lo * 4096); };
+                    copiers.run((j.bytes + 4095) / 4096, 12, fn);
+                } else {
+                    stream_copy(j.dst, j.stage, j.bytes);
+                }
             }
             lk.lock();
             if (e != 0 && !err) err = e;
@@ -227,68 +323,6 @@ struct TicketWorker {
     }
 };
 
-
-// Host-side record loops (32-byte records <-> packed xyz in pinned staging, staging <-> the caller's memory) are memory-bound
-// copies of tens of MB that want a handful of cores for a fraction of a millisecond: the threads are kept (starting eight
-// threads costs as much as the copy they are started for).  One loop at a time, process-wide; the caller's thread works too.
-struct HostPool {
-    std::vector<std::thread> th;
-    std::mutex m, call_m;
-    std::condition_variable cv, cv_done;
-    const std::function<void(size_t, size_t)> *f = nullptr;
-    size_t n = 0, parts = 0, next = 0, running = 0;
-    bool stop = false;
-
-    explicit HostPool(unsigned workers)
-    {
-        for (unsigned k = 0; k < workers; ++k) th.emplace_back([this] { loop(); });
-    }
-    ~HostPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop = true;
-        }
-        cv.notify_all();
-        for (auto &t : th) t.join();
-    }
-    // (m held) runs parts until none is left; returns with m held
-    void work(std::unique_lock<std::mutex> &lk)
-    {
-        while (f && next < parts) {
-            const size_t p = next++;
-            const std::function<void(size_t, size_t)> *g = f;
-            const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
-            ++running;
-            lk.unlock();
-            if (lo < hi) (*g)(lo, hi);
-            lk.lock();
-            if (--running == 0 && next >= parts) cv_done.notify_all();
-        }
-    }
-    void loop()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return stop || (f && next < parts); });
-            if (stop) return;
-            work(lk);
-        }
-    }
-    // f(lo, hi) over [0, count) in `pieces` pieces (more pieces than threads: a slow thread does not hold the others up)
-    void run(size_t count, size_t pieces, const std::function<void(size_t, size_t)> &fn)
-    {
-        if (count == 0) return;
-        if (pieces <= 1 || th.empty()) { fn(0, count); return; }
-        std::lock_guard<std::mutex> one(call_m);
-        std::unique_lock<std::mutex> lk(m);
-        f = &fn; n = count; parts = pieces; next = 0;
-        cv.notify_all();
-        work(lk);
-        cv_done.wait(lk, [&] { return running == 0 && next >= parts; });
-        f = nullptr;
-    }
-};
 
 inline HostPool &host_pool()
 {

@@ -759,7 +759,7 @@ int rsreg_cloud_download_async(const rsreg_cloud *c, void *out, size_t capacity)
     if (!mc->ev_down) RSREG_HIP(ctx, hipEventCreateWithFlags(&mc->ev_down, hipEventDisableTiming));
     const size_t bytes = c->n * c->stride;
     const int slot = ctx->down_next;
-    ctx->down_next = (ctx->down_next + 1) % 3;
+    ctx->down_next = (ctx->down_next + 1) % rsreg::DownloadWorker::kSlots;
     ctx->down_worker->wait_slot(slot);   // (the copy-out that last used this staging buffer)
     {
         // (a failure before the job is posted must give the slot back: nobody else would, and the third download after it

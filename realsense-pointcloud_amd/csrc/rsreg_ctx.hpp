@@ -331,8 +331,8 @@ struct rsreg_ctx {
     rsreg::TicketWorker *up_worker = nullptr;
     // rsreg_cloud_download_async: a download stream, three pinned staging buffers with an event each, the copy-out thread
     hipStream_t stream_down = nullptr;
-    hipEvent_t ev_down_gate = nullptr, ev_down[3] = {nullptr, nullptr, nullptr};
-    rsreg::PinnedBuf h_down[3];
+    hipEvent_t ev_down_gate = nullptr, ev_down[rsreg::DownloadWorker::kSlots] = {};
+    rsreg::PinnedBuf h_down[rsreg::DownloadWorker::kSlots];
     int down_next = 0;
     rsreg::DownloadWorker *down_worker = nullptr;
     uint64_t ndt_seq = 0;  // derivative passes launched; the final reduce stamps it into h_ndt

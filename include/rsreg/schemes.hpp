@@ -48,7 +48,10 @@ using rgb_device_cloud = DeviceCloud<rgb_point>;
 
 class RegistrationScheme {
   public:
-    virtual ~RegistrationScheme() = default;
+    virtual ~RegistrationScheme()
+    {
+        if (release_.joinable()) release_.join();
+    }
     virtual rgb_point_cloud_pointer registration(std::vector<rgb_point_cloud_pointer> &clouds) = 0;
     // true: the reference's progress lines on stdout, text for text (types.hpp:35-41, icp_edge_based_registration.hpp:27-32,
     // 94-96,103-104,110,113,122,127, ndt_edge_based_registration.hpp:24-29,82-84,91-93,98,101,110,114); IncrementalICP
@@ -68,7 +71,7 @@ class RegistrationScheme {
     std::vector<double> frame_clock_ms;
     // engine extra (stream_result): what the end of the loop waited for, in ms -- the host copy of frame 0, the downloads still
     // on their way -- and the host time of all download_async calls together
-    double stream_finish_ms[3] = {0, 0, 0};
+    double stream_finish_ms[4] = {0, 0, 0, 0};   // ([3]: handing the records over to the caller's cloud: its old storage is let go of)
     // engine extra (device-resident loops): where the caller's thread spent the frame loop, in ms over all frames, call by call --
     // IncrementalICP: [0] queueing the uploads / filters of the frames ahead, [1] setInputSource, [2] setInputTarget, [3] align,
     // [4] transformPointCloud, [5] +=, [6] handing the moved points to the result's download
@@ -87,16 +90,22 @@ class RegistrationScheme {
         if (stage >= 0) stage_ms[stage] += std::chrono::duration<double, std::milli>(now - lap_).count();
         lap_ = now;
     }
-    template <class R> void note_finish(const R &r)
+    template <class R> void note_finish(R &r)
     {
+        // (the storage the caller's frame 0 had before it became the merged cloud is let go of by a thread: unmapping 9.8 MB
+        //  took 0.7-1.0 ms of the call; it is over when this object is destroyed or registers again)
+        if (release_.joinable()) release_.join();
+        release_ = r.take_release();
         stream_finish_ms[0] = r.join_ms;
         stream_finish_ms[1] = r.wait_ms;
         stream_finish_ms[2] = r.append_ms;
+        stream_finish_ms[3] = r.hand_over_ms;
     }
     void clock_mark() { frame_clock_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0_).count()); }
 
   private:
     std::chrono::steady_clock::time_point clock0_, lap_;
+    std::thread release_;
 };
 
 class TwoPhaseRegistrationScheme : public RegistrationScheme {
@@ -139,8 +148,10 @@ class StreamedResult {
         const size_t n = n_;
         copy0_ = std::thread([dst, src, n] { std::memcpy(static_cast<void *>(dst), src, n * sizeof(rgb_point)); });
     }
+    std::thread take_release() { return std::move(release_); }
     ~StreamedResult()
     {
+        if (release_.joinable()) release_.join();
         if (copy0_.joinable()) copy0_.join();
         if (pending_) (void)rsreg_ctx_wait_downloads(ctx_->get());   // (an exception on the way: the copies still own pts_)
     }
@@ -168,15 +179,18 @@ class StreamedResult {
         wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         append_ms = append_us_ / 1e3;
         pending_ = false;
+        const auto t2 = std::chrono::steady_clock::now();
         pts_.resize(n_);
-        out.points = std::move(pts_);
+        out.points.swap(pts_);   // (pts_: what `out` held before -- the caller's frame 0 in IncrementalICP, nothing in the edge schemes)
+        if (!pts_.empty()) release_ = std::thread([old = std::move(pts_)]() mutable { PointVector<rgb_point>().swap(old); });
         out.width = (uint32_t)n_;
         out.height = 1;
         out.is_dense = dense_;
+        hand_over_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
     }
 
     // what finish() waited for: the copy of frame 0, the downloads still on their way; and the host time of all download_async calls
-    double join_ms = 0, wait_ms = 0, append_ms = 0;
+    double join_ms = 0, wait_ms = 0, append_ms = 0, hand_over_ms = 0;
 
   private:
     std::shared_ptr<Context> ctx_;
@@ -184,7 +198,7 @@ class StreamedResult {
     size_t n_;
     bool dense_, pending_ = false;
     double append_us_ = 0;   // (host time inside download_async)
-    std::thread copy0_;
+    std::thread copy0_, release_;
 };
 
 inline void reference_icp_parameters(IterativeClosestPoint<rgb_point, rgb_point> &icp)

@@ -74,7 +74,9 @@ class RegistrationScheme {
     double stream_finish_ms[4] = {0, 0, 0, 0};   // ([3]: handing the records over to the caller's cloud: its old storage is let go of)
     // engine extra (device-resident loops): where the caller's thread spent the frame loop, in ms over all frames, call by call --
     // IncrementalICP: [0] queueing the uploads / filters of the frames ahead, [1] setInputSource, [2] setInputTarget, [3] align,
-    // [4] transformPointCloud, [5] +=, [6] handing the moved points to the result's download
+    // [4] transformPointCloud, [5] +=, [6] handing the moved points to the result's download; the edge schemes: [0] queueing the
+    // uploads / extractions / filters of the frames ahead, [1] the coarse alignment (ICP on the filtered edges, or NDT), [2] the
+    // refining ICP, [3] the two transformPointCloud and the grown target, [4] the result's download (or merged +=)
     double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   protected:
@@ -602,6 +604,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         clock_mark();
         for (size_t k = 1; k < n_frames; ++k, clock_mark()) {
             rgb_device_cloud &full = fulls[k % kFulls], &features = features_of[k % kFeat], &reduced = reduced_of[k % kFeat];
+            clock_lap(-1);
             if (pairs) {
                 features.upload(*(*pairs)[k].first);
                 voxel.filter(features, reduced);
@@ -613,12 +616,15 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             if (byproducts_on()) save_edge(k, features);
             const Matrix4f guess = next_guess(k, acc_rads);
             say_iteration(coarse_name(), k);
+            clock_lap(0);
             const Matrix4f t_coarse = coarse_align_device(reduced, target, coarse_out, guess);
+            clock_lap(1);
             say("OK");
             icp.setInputSource(coarse_out);
             icp.setInputTarget(target);
             say_iteration("ICP", k);
             icp.align(refined);
+            clock_lap(2);
             if (!icp.hasConverged()) {   // frame dropped, like the reference
                 say("");
                 continue;
@@ -628,8 +634,10 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             transformPointCloud(full, moved, t_coarse);
             transformPointCloud(moved, moved, icp.getFinalTransformation());
             rgb_device_cloud::concatenate(refined, target, target);   // new points first
+            clock_lap(3);
             if (result) result->append(moved);   // `*global = *global + *transformed`: on its way to the host already
             else merged += moved;
+            clock_lap(4);
             frame_transforms.emplace_back(t_coarse, icp.getFinalTransformation());
         }
         if (pairs) target.download(*(*pairs)[0].first);   // the caller's frame-0 feature cloud has become the grown target

@@ -924,10 +924,16 @@ __global__ __launch_bounds__(kTile) void k_cov_reduce(const float4 *cur, const i
 // A thread's share of `count` partials (every kBlock-th, ascending), added in that order.  The loads go out sixteen at a
 // time before the first is used: one after the other, each waiting for the last (what the plain loop compiles to),
 // thirty trips to memory in a row were 10 of the 14 us between two search kernels.
-// (kReduceBlock threads: round 6 -- 1 024 instead of 256: the 7 813 slabs of a 10^6-point launch are eight loads a thread, all in
-// flight at once, where they were 31 in two rounds.  The order of the additions is part of every pipeline's result: staged,
-// fused and device-loop launches all go through this function.)
-constexpr int kReduceBlock = 1024;
+// (kReduceBlock threads a sum.  Round 6 measured 1 024 -- the 7 813 slabs of a 10^6-point launch as eight loads a thread, one round
+// in flight, instead of 31 in two rounds: k_final_reduce_solve 8.24 -> 7.85 us and the single pair 3.165 -> 3.15 ms, but a
+// workgroup of sixteen waves has to find sixteen free wave slots on ONE CU behind the other pairs' search launches, and the chain with
+// three pairs in flight went from 1.05-1.21 to 1.22-1.27 ms per pair on the same box (profiles/r06_experiments/reduce_block.txt):
+// 256 stays.  The order of the additions is part of every pipeline's result: staged, fused and device-loop launches all go through
+// this function.)
+#ifndef RSREG_REDUCE_BLOCK
+#define RSREG_REDUCE_BLOCK 256   // (dev: experiment builds, RSREG_CXXFLAGS=-DRSREG_REDUCE_BLOCK=1024)
+#endif
+constexpr int kReduceBlock = RSREG_REDUCE_BLOCK;
 __device__ __forceinline__ double strided_sum(const double *src, uint32_t count)
 {
     constexpr int kInFlight = 16;

@@ -335,7 +335,7 @@ int rsreg_cloud_upload_deferred(rsreg_cloud *cloud, const void *points, size_t n
                                 uint32_t height, int is_dense);
 int rsreg_cloud_download(const rsreg_cloud *cloud, void *out, size_t capacity_records);
 /* rsreg_cloud_download that returns at once: the records as they are when the context's stream gets here go to `out`
- * (capacity in records) on a download stream and a copy-out thread of the context; the cloud may be rewritten or
+ * (capacity in records) on a download stream and the copy-out threads of the context; the cloud may be rewritten or
  * destroyed right away.  `out` must stay valid and untouched until rsreg_ctx_wait_downloads(ctx) has returned.  The frame
  * loops hand every frame's moved points to the host this way while the next frames are aligned (the merged cloud the
  * schemes return, types.hpp:19, is then complete when the loop ends: incremental_icp.hpp:63-64, icp_edge...hpp:116-120). */

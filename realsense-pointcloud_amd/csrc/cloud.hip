@@ -964,7 +964,15 @@ int rsreg_ndt_set_target_cloud(rsreg_ctx *ctx, const rsreg_cloud *c, double reso
 {
     if (!ctx || !c || c->ctx != ctx) return RSREG_ERR_INVALID_ARG;
     RSREG_HIP(ctx, settle(c));
-    return rsreg_ndt_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, resolution);
+    ctx->next_ndt_box.valid = false;
+    if (c->box.valid && c->box_version == c->version) ctx->next_ndt_box = c->box;
+    const int rc = rsreg_ndt_set_target_device(ctx, c->n ? c->buf.ptr : nullptr, c->n, c->stride, c->is_dense, resolution);
+    ctx->next_ndt_box.valid = false;
+    if (rc == RSREG_OK && ctx->last_ndt_box.valid && !(c->box.valid && c->box_version == c->version)) {
+        c->box = ctx->last_ndt_box;
+        c->box_version = c->version;
+    }
+    return rc;
 }
 
 int rsreg_ndt_align_cloud(rsreg_ctx *ctx, const rsreg_cloud *source, const float *guess, const rsreg_ndt_params *params,

@@ -1794,6 +1794,7 @@ int rsreg_ctx_destroy(rsreg_ctx *ctx)
     ctx->h_smisc.release();
     ctx->h_stage.release();
     ctx->h_ndt.release();
+    ctx->h_ndt_build.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_ndt)
         if (e) (void)hipEventDestroy(e);

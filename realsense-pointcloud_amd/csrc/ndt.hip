@@ -414,15 +414,33 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     const size_t pstride = stride;
     uint32_t *d_misc = ctx->d_misc.as<uint32_t>();
     uint32_t *h_misc = ctx->h_ndt.as<uint32_t>();
-    // minima start at all ones, maxima and the count at zero (ordered-float encoding): two memsets, no upload + sync
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0xff, 12, st));
-    RSREG_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, 52, st));
     h_misc[6] = 0;
-    if (n) {
+    // A cloud handle that knows a box around its finite points and their number (measured by an earlier build, or the union / the
+    // transformed corners of measured ones: rsreg_ctx.hpp CloudBox) saves the kernel and the round trip.  The box only has to
+    // CONTAIN the points: a leaf is floor(x / leaf) whatever the grid's origin is, and the leaves are visited in the order of
+    // (z, y, x) leaf coordinates whatever its extent is -- the same voxels in the same order as from the measured box.
+    const rsreg::CloudBox known = ctx->next_ndt_box;
+    ctx->next_ndt_box.valid = false;
+    ctx->last_ndt_box.valid = false;
+    if (n && known.valid && known.nfin <= n && tunables().box_cache) {
+        auto host_f2o = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        for (int k = 0; k < 3; ++k) { h_misc[k] = host_f2o(known.mn[k]); h_misc[3 + k] = host_f2o(known.mx[k]); }
+        h_misc[6] = known.nfin;
+        ctx->last_ndt_box = known;
+    } else if (n) {
+        // minima start at all ones, maxima and the count at zero (ordered-float encoding): two memsets, no upload + sync
+        RSREG_HIP(ctx, hipMemsetAsync(d_misc, 0xff, 12, st));
+        RSREG_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, 52, st));
         k_ndt_bbox<<<std::min<uint32_t>(div_up((uint32_t)n, 256), 256), 256, 0, st>>>(d_pts, pstride, (uint32_t)n, d_misc);
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
         RSREG_HIP(ctx, hipStreamSynchronize(st));
+        if (h_misc[6]) {   // (measured: the handle keeps it)
+            for (int k = 0; k < 3; ++k) { ctx->last_ndt_box.mn[k] = o2f(h_misc[k]); ctx->last_ndt_box.mx[k] = o2f(h_misc[3 + k]); }
+            ctx->last_ndt_box.nfin = h_misc[6];
+            ctx->last_ndt_box.valid = true;
+            ctx->last_ndt_box.exact = true;
+        }
     }
     const uint32_t nfin = h_misc[6];
     if (nfin == 0) {
@@ -512,15 +530,20 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * n_parts * 10 * 8, 64 * 8)));
     k_ndt_voxel_stats<<<nseg * n_parts, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, n_parts, ctx->d_ndt_out.as<double>());
     RSREG_HIP(ctx, hipGetLastError());
-    std::vector<double> parts((size_t)nseg * n_parts * 10);
-    RSREG_HIP(ctx, hipMemcpyAsync(parts.data(), ctx->d_ndt_out.ptr, parts.size() * 8, hipMemcpyDeviceToHost, st));
-    std::vector<float> csum;   // PCL-mode centroids (rsreg_ndt_set_centroid_mode)
+    // (through pinned memory: [partial moments | PCL-mode centroid sums | later the finished table])
+    const size_t n_parts_d = (size_t)nseg * n_parts * 10, parts_bytes = n_parts_d * 8;
+    const size_t csum_off = (parts_bytes + 255) & ~(size_t)255, csum_bytes = (size_t)nseg * 12;
+    const size_t table_off = (csum_off + csum_bytes + 255) & ~(size_t)255;
+    RSREG_HIP(ctx, ctx->h_ndt_build.reserve(table_off + (size_t)nseg * sizeof(NdtVoxel) + 256));
+    const double *parts = ctx->h_ndt_build.as<double>();
+    RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_ndt_build.ptr, ctx->d_ndt_out.ptr, parts_bytes, hipMemcpyDeviceToHost, st));
+    const float *csum = nullptr;   // PCL-mode centroids (rsreg_ndt_set_centroid_mode)
     if (ctx->ndt_centroid_mode == 1) {
-        csum.resize((size_t)nseg * 3);
         RSREG_HIP(ctx, ctx->d_scan.reserve(std::max<size_t>(n * 4, (size_t)nseg * 12)));   // (sid is no longer needed)
         k_ndt_voxel_csum<<<nseg, 64, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_scan.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
-        RSREG_HIP(ctx, hipMemcpyAsync(csum.data(), ctx->d_scan.ptr, csum.size() * 4, hipMemcpyDeviceToHost, st));
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_ndt_build.as<char>() + csum_off, ctx->d_scan.ptr, csum_bytes, hipMemcpyDeviceToHost, st));
+        csum = reinterpret_cast<const float *>(ctx->h_ndt_build.as<char>() + csum_off);
     }
     RSREG_HIP(ctx, hipStreamSynchronize(st));
 
@@ -568,7 +591,7 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
         for (int k = 0; k < 3; ++k) {
             nv.mean[k] = mean[k];
             // PCL: f32 running sum / n (mode 1); default: the f64 mean rounded
-            nv.centroid[k] = csum.empty() ? (float)mean[k] : csum[(size_t)v * 3 + k];
+            nv.centroid[k] = !csum ? (float)mean[k] : csum[(size_t)v * 3 + k];
         }
         std::memcpy(nv.icov, icov, sizeof(icov));
         table.push_back(nv);
@@ -581,8 +604,10 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     ctx->ndt_n_voxels = (int)table.size();
     RSREG_HIP(ctx, ctx->d_ndt_vox.reserve(std::max<size_t>(table.size(), 1) * sizeof(NdtVoxel)));
     if (!table.empty()) {
-        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_ndt_vox.ptr, table.data(), table.size() * sizeof(NdtVoxel), hipMemcpyHostToDevice, st));
-        RSREG_HIP(ctx, hipStreamSynchronize(st));
+        // (from pinned memory, and nobody waits for it: the first pass is queued behind it on the same stream, and the next
+        //  build's moments land in front of this region, which is rewritten only after that build's own waits)
+        std::memcpy(ctx->h_ndt_build.as<char>() + table_off, table.data(), table.size() * sizeof(NdtVoxel));
+        RSREG_HIP(ctx, hipMemcpyAsync(ctx->d_ndt_vox.ptr, ctx->h_ndt_build.as<char>() + table_off, table.size() * sizeof(NdtVoxel), hipMemcpyHostToDevice, st));
     }
     ctx->have_ndt_target = true;
     return RSREG_OK;

@@ -279,6 +279,7 @@ struct rsreg_ctx {
     // next_*: the box of the cloud about to be set, when its handle knows it (consumed by build_grid / load_source_queue);
     // last_*: what the last index build / source load started from (valid: computed or taken over)
     rsreg::CloudBox next_tgt_box, last_tgt_box, next_src_box, last_src_box;
+    rsreg::CloudBox next_ndt_box, last_ndt_box;   // the same for the NDT target's grid (rsreg_ndt_set_target_cloud)
 
     rsreg::PinnedBuf h_stage;     // pinned staging for H2D / D2H of clouds
     // host clouds of rsreg_icp_set_source / _set_target: a staging buffer each, the upload stream, the event behind each buffer's last copy
@@ -346,6 +347,7 @@ struct rsreg_ctx {
     std::vector<int> ndt_counts;
     std::vector<float> ndt_centroid;         // 3 per voxel
     rsreg::PinnedBuf h_ndt;
+    rsreg::PinnedBuf h_ndt_build;   // the target build's transfers: the voxels' partial moments home, the finished table out (pageable copies cost a frame of the NDT-edge loop 0.1 ms)
 
     // ---- RCCL
     // rsreg_ctx_prepare: what a frame loop is about to need, made on a thread of its own while the caller goes on; whoever is

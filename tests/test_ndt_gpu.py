@@ -248,3 +248,43 @@ def test_pass_with_its_reduce_in_one_launch_gives_the_same_bits(api, rs, monkeyp
         assert run() == two
     monkeypatch.delenv("RSREG_NDT_ONE_LAUNCH")
     assert two[3] > 3
+
+
+def test_target_grid_from_a_known_box_is_the_grid_from_the_measured_one(api, rs, edge_like, monkeypatch):
+    """A cloud handle that knows a box AROUND its points (the union of a measured box and the transformed corners of another:
+    what the NDT-edge loop's grown target carries) builds its voxel grid without measuring the box: the leaves are
+    floor(x / leaf) whatever the grid's origin, and they are visited in (z, y, x) order whatever its extent -- the same voxels
+    in the same order, the same alignment bit for bit, as from the box measured on the records (RSREG_NO_BOX_CACHE=1)."""
+    src, tgt = edge_like
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = (0.03, -0.02, 0.04)
+    c, s = np.cos(0.02), np.sin(0.02)
+    T[0, 0], T[0, 2], T[2, 0], T[2, 2] = c, s, -s, c
+
+    def run():
+        ctx = api.Context(0)   # (a context looks at the environment when it is created)
+        a, b = api.DeviceCloud(src, ctx=ctx), api.DeviceCloud(tgt, ctx=ctx)
+        icp = api.IterativeClosestPoint(ctx)   # (an ICP index build measures b's box and a source load a's; the transform's output carries a's, moved)
+        icp.setMaxCorrespondenceDistance(0.05)
+        icp.setMaximumIterations(1)
+        icp.setInputSource(a)
+        icp.setInputTarget(b)
+        icp.align()
+        moved = api.transformPointCloud(a, T)
+        grown = moved + b
+        ndt = api.NormalDistributionsTransform(ctx)
+        ndt.params = api.ndt_params(reference=True)
+        ndt.setInputSource(a)
+        ndt.setInputTarget(grown)
+        ndt.align()
+        m, cnt = ndt.voxels()
+        r = ndt.result
+        return m.tobytes(), cnt.tobytes(), bytes(r.transform), r.score, r.iterations, r.n_derivative_passes, len(cnt)
+
+    monkeypatch.delenv("RSREG_NO_BOX_CACHE", raising=False)
+    with_box = run()
+    monkeypatch.setenv("RSREG_NO_BOX_CACHE", "1")
+    measured = run()
+    monkeypatch.delenv("RSREG_NO_BOX_CACHE")
+    assert with_box[-1] > 3
+    assert with_box == measured

@@ -522,30 +522,37 @@ int rsreg_ndt_set_target_device(rsreg_ctx *ctx, const void *d_points, size_t n, 
     k_ndt_seg_offsets<<<div_up(nfin, kNdtBlock), kNdtBlock, 0, st>>>(start, sid, nfin, seg_begin, d_misc + 8);
     RSREG_HIP(ctx, hipGetLastError());
     RSREG_HIP(ctx, hipMemcpyAsync(h_misc, d_misc, 64, hipMemcpyDeviceToHost, st));
-    RSREG_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t nseg = h_misc[8];
+    // A grid of a few dozen leaves (the reference's 1 m resolution): the moments are launched for EVERY leaf of the box, the
+    // workgroups beyond the occupied ones leave at once, and the number of occupied leaves comes home with the moments --
+    // one round trip instead of two.
+    const bool few_leaves = n_leaves <= 256 && ctx->ndt_centroid_mode != 1;
+    if (!few_leaves) RSREG_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t nseg_launch = few_leaves ? (uint32_t)std::min<unsigned long long>(n_leaves, nfin) : h_misc[8];
 
     // ---- per-voxel moments on the device, one block per occupied leaf
-    const uint32_t n_parts = nseg <= 2048 ? 16u : 1u;   // (the reference's 1 m voxels: two dozen of 10^4 points each)
-    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg * n_parts * 10 * 8, 64 * 8)));
-    k_ndt_voxel_stats<<<nseg * n_parts, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, n_parts, ctx->d_ndt_out.as<double>());
+    const uint32_t n_parts = nseg_launch <= 2048 ? 16u : 1u;   // (the reference's 1 m voxels: two dozen of 10^4 points each)
+    RSREG_HIP(ctx, ctx->d_ndt_out.reserve(std::max<size_t>((size_t)nseg_launch * n_parts * 10 * 8, 64 * 8)));
+    k_ndt_voxel_stats<<<nseg_launch * n_parts, kNdtBlock, 0, st>>>(vals2, seg_begin, d_pts, pstride, n_parts, ctx->d_ndt_out.as<double>(),
+                                                                   few_leaves ? d_misc + 8 : nullptr);
     RSREG_HIP(ctx, hipGetLastError());
     // (through pinned memory: [partial moments | PCL-mode centroid sums | later the finished table])
-    const size_t n_parts_d = (size_t)nseg * n_parts * 10, parts_bytes = n_parts_d * 8;
-    const size_t csum_off = (parts_bytes + 255) & ~(size_t)255, csum_bytes = (size_t)nseg * 12;
+    const size_t n_parts_d = (size_t)nseg_launch * n_parts * 10, parts_bytes = n_parts_d * 8;
+    const size_t csum_off = (parts_bytes + 255) & ~(size_t)255, csum_bytes = (size_t)nseg_launch * 12;
     const size_t table_off = (csum_off + csum_bytes + 255) & ~(size_t)255;
-    RSREG_HIP(ctx, ctx->h_ndt_build.reserve(table_off + (size_t)nseg * sizeof(NdtVoxel) + 256));
+    RSREG_HIP(ctx, ctx->h_ndt_build.reserve(table_off + (size_t)nseg_launch * sizeof(NdtVoxel) + 256));
     const double *parts = ctx->h_ndt_build.as<double>();
     RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_ndt_build.ptr, ctx->d_ndt_out.ptr, parts_bytes, hipMemcpyDeviceToHost, st));
     const float *csum = nullptr;   // PCL-mode centroids (rsreg_ndt_set_centroid_mode)
     if (ctx->ndt_centroid_mode == 1) {
-        RSREG_HIP(ctx, ctx->d_scan.reserve(std::max<size_t>(n * 4, (size_t)nseg * 12)));   // (sid is no longer needed)
-        k_ndt_voxel_csum<<<nseg, 64, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_scan.as<float>());
+        RSREG_HIP(ctx, ctx->d_scan.reserve(std::max<size_t>(n * 4, (size_t)nseg_launch * 12)));   // (sid is no longer needed)
+        k_ndt_voxel_csum<<<nseg_launch, 64, 0, st>>>(vals2, seg_begin, d_pts, pstride, ctx->d_scan.as<float>());
         RSREG_HIP(ctx, hipGetLastError());
         RSREG_HIP(ctx, hipMemcpyAsync(ctx->h_ndt_build.as<char>() + csum_off, ctx->d_scan.ptr, csum_bytes, hipMemcpyDeviceToHost, st));
         csum = reinterpret_cast<const float *>(ctx->h_ndt_build.as<char>() + csum_off);
     }
     RSREG_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t nseg = h_misc[8];   // (few leaves: it came home with the moments)
+    if (nseg > nseg_launch) return fail(ctx, RSREG_ERR_STATE, "ndt: more occupied leaves than the grid has");
 
     // ---- host: mean, single-pass covariance, eigenvalue floor, inverse (App. A.6)
     std::vector<double> stats((size_t)nseg * 10, 0.0);

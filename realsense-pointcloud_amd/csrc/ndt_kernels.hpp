@@ -105,9 +105,11 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_seg_offsets(const uint32_t *s
 // 1 m voxels of a 5 x 10^5-point edge target: two dozen blocks on 256 CUs, each gathering 2 x 10^4 records.)
 // out[(v * parts + part) * 10 + k]: 0 n, 1..3 sum, 4..9 xx xy xz yy yz zz
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_voxel_stats(const uint32_t *vals, const uint32_t *seg_begin,
-                                                               const char *pts, size_t stride, uint32_t parts, double *out)
+                                                               const char *pts, size_t stride, uint32_t parts, double *out,
+                                                               const uint32_t *n_segments /* launched for more voxels than there may be: those beyond leave */)
 {
     const uint32_t v = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (n_segments && v >= *n_segments) return;
     const uint32_t vb = seg_begin[v], ve = seg_begin[v + 1];
     const uint32_t share = (ve - vb + parts - 1) / parts;
     const uint32_t b = min(ve, vb + part * share), e = min(ve, b + share);

@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", default=None, choices=["50k", "N300", "N1M"],
                     help="points per cloud (default: N1M for the pair workload -- the configuration the metric is quoted on -- and N300 for the chain, configs[4])")
     ap.add_argument("--iterations", type=int, default=30)

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <thread>
 #include <vector>
@@ -83,7 +84,25 @@ static void ticket_worker()
     w.shutdown();
 }
 
-// three staging slots taken in turn; the copy-out of a job runs when its "event" has fired
+// the streaming copy against memcpy: every size round the 64-byte blocks and the 4 096-byte threshold, every misalignment of source
+// and destination, and the bytes on either side untouched
+static void stream_copy_is_memcpy()
+{
+    std::vector<unsigned char> src(3u << 20), dst(3u << 20), want(3u << 20);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)(i * 2654435761u >> 24);
+    const size_t sizes[] = {0, 1, 15, 16, 63, 64, 65, 4095, 4096, 4097, 4096 + 63, 8191, 100000, (1u << 20) + 13};
+    for (size_t n : sizes)
+        for (size_t so : {(size_t)0, (size_t)1, (size_t)7, (size_t)16, (size_t)33})
+            for (size_t d_o : {(size_t)0, (size_t)3, (size_t)8, (size_t)16, (size_t)47}) {
+                std::fill(dst.begin(), dst.end(), (unsigned char)0xA5);
+                std::fill(want.begin(), want.end(), (unsigned char)0xA5);
+                std::memcpy(want.data() + 64 + d_o, src.data() + so, n);
+                stream_copy(dst.data() + 64 + d_o, src.data() + so, n);
+                REQUIRE(std::memcmp(dst.data(), want.data(), n + 256) == 0);
+            }
+}
+
+// four staging slots taken in turn, two jobs copied out side by side; the copy-out of a job runs when its "event" has fired
 static void download_worker()
 {
     DownloadWorker w;
@@ -94,16 +113,17 @@ static void download_worker()
         return j.device == 99 ? 5 : 0;   // (device 99: the stub's "event wait failed")
     };
     const size_t small = 4096, big = (size_t)5 << 20;   // (the big ones are copied out by four threads)
-    std::vector<std::vector<char>> stage(3, std::vector<char>(big)), dst(12, std::vector<char>(big));
+    std::vector<std::vector<char>> stage(DownloadWorker::kSlots, std::vector<char>(big)), dst(12, std::vector<char>(big)), sent(12);
     for (int k = 0; k < 12; ++k) {
-        const int slot = k % 3;
+        const int slot = k % DownloadWorker::kSlots;
         w.wait_slot(slot);   // (nobody copies out of this staging buffer any more)
-        const size_t bytes = k % 4 == 0 ? big : small;
-        for (size_t i = 0; i < bytes; i += 997) stage[slot][i] = (char)(k + 1);
+        const size_t bytes = k % 3 == 0 ? big - 17 * (size_t)k : small;
+        for (size_t i = 0; i < bytes; i += 997) stage[slot][i] = (char)(k + 1 + i / 997);
+        sent[k].assign(stage[slot].begin(), stage[slot].begin() + (long)bytes);
         w.post(DownloadWorker::Job{nullptr, stage[slot].data(), dst[k].data(), bytes, slot, 0});
     }
     REQUIRE(w.wait_idle() == 0);
-    for (int k = 0; k < 12; ++k) REQUIRE(dst[k][0] == (char)(k + 1));
+    for (int k = 0; k < 12; ++k) REQUIRE(std::memcmp(dst[k].data(), sent[k].data(), sent[k].size()) == 0);
     REQUIRE(ready_calls == 12);
     // a slot given back without a job (the error path of rsreg_cloud_download_async), from another thread
     w.wait_slot(0);
@@ -122,7 +142,7 @@ static void download_worker()
     std::vector<std::thread> th;
     for (int t = 0; t < 3; ++t) th.emplace_back([&] { for (int k = 0; k < 20; ++k) (void)w.wait_idle(); });
     for (int k = 0; k < 30; ++k) {
-        const int slot = k % 3;
+        const int slot = k % DownloadWorker::kSlots;
         w.wait_slot(slot);
         w.post(DownloadWorker::Job{nullptr, stage[slot].data(), dst[k % 12].data(), small, slot, 0});
     }
@@ -166,6 +186,7 @@ int main()
     source_worker();
     ticket_worker();
     download_worker();
+    stream_copy_is_memcpy();
     std::puts("workers ok");
     return 0;
 }

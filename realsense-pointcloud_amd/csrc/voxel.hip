@@ -283,20 +283,25 @@ __global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, siz
 // the true sum there, and the wave goes round again from the next lane with the binade of that sum.  A round costs what ~40
 // additions cost and settles up to 1 024 points; a run of 37 000 points (the longest of a 307 k-point frame) takes ~50 rounds.
 //
-// One workgroup per run.  Its eight waves fetch the run's records -- 8 192 points at a time, the next 8 192 in flight in
-// registers, the indices of the 8 192 after those as well -- and lay them out in the LDS by component; then six of the waves sum
-// ONE component each (x y z r g b), window after window of 1 024 points, every wave at its own pace: no wave waits for
-// another's rounds.  (PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back: the
+// One workgroup per run.  Two of its eight waves fetch the run's records -- 4 096 points at a time, in two halves of 2 048 (one
+// half's records and the other's indices in flight in registers between two steps) -- and lay them out in one half of the LDS
+// by component, while the other six sum ONE component each (x y z r g b) out of the other half, window after window of
+// 1 024 points, every wave at its own pace: no wave waits for another's rounds, and the gathers are issued beside the rounds,
+// not in front of them (with all eight waves fetching 8 192 points and then six of them summing, a quarter of the kernel was
+// issuing loads: 63 -> 49 us for the runs of a 307 k frame; the two fetching waves are now what a step waits for -- they hold
+// 222 registers for sixteen records in flight a lane, and a second set would spill).  (PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back: the
 // centroid's fourth component is not part of the output record, and this kernel leaves it out.)
 constexpr int kHB = 512;                          // threads of a workgroup
 constexpr int kHL = 16;                           // points of a lane in a window
 constexpr uint32_t kHWin = 64u * kHL;             // points of a window (one wave, one round at least)
-constexpr uint32_t kHWins = 8;                    // windows in the LDS at a time
-constexpr uint32_t kHSuper = kHWin * kHWins;      // = points the workgroup fetches at a time
-constexpr int kHPer = (int)(kHSuper / kHB);       // ... each thread this many
+constexpr uint32_t kHWins = 4;                    // windows in one half of the LDS
+constexpr uint32_t kHSuper = kHWin * kHWins;      // = points fetched at a time
+constexpr int kHLoaders = 128;                    // threads that fetch (the last two waves); the other six waves sum
+constexpr uint32_t kHHalf = kHSuper / 2;          // the fetching threads take the 4 096 in two halves (registers)
+constexpr int kHPer = (int)(kHHalf / kHLoaders);  // ... each of them this many points of a half
 constexpr uint32_t kHPitch = 68;                  // a window in the LDS: 16 rows (a lane's i-th point) of 64 values, 68 words apart:
                                                   //   64 consecutive points written (16 rows x 4 columns) hit 64 different banks, a row read does too
-static_assert(kHL == 16 && kHPer == 16, "the fetch loops and the window layout below are written for 16 points a thread");
+static_assert(kHL == 16 && kHB - kHLoaders == 6 * 64 && 2 * kHPer * kHLoaders == (int)kHSuper, "six summing waves, windows of 16 points a lane");
 
 struct HFn {   // m -> m + (m odd ? a1 : a0), modulo 2^32
     uint32_t a0, a1;
@@ -417,68 +422,90 @@ __global__ __launch_bounds__(kHB) void k_vox_huge_runs(const char *recs, size_t 
                                                        const uint32_t *svals, const uint32_t *start, const uint32_t *stats,
                                                        float *cent, uint32_t *ekey, uint32_t *erun, const uint32_t *huge_runs)
 {
-    // [component: x y z rgb][window][row][column]
-    __shared__ uint32_t sh[4][kHWins][kHL * kHPitch];
+    // [half][component: x y z rgb][window][row][column]
+    __shared__ uint32_t sh[2][4][kHWins][kHL * kHPitch];
     __shared__ uint32_t sh_s[6];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool loader = tid >= (uint32_t)(kHB - kHLoaders);
+    const uint32_t tl = tid - (uint32_t)(kHB - kHLoaders);   // (loaders) 0 .. 127
     const uint32_t nr = stats[0], nfin = stats[1], n_huge = stats[3];
     const bool vec = (stride % 16 == 0) && ((reinterpret_cast<size_t>(recs) & 15) == 0);
     for (uint32_t k = blockIdx.x; k < n_huge; k += gridDim.x) {
         const uint32_t r = huge_runs[k];
         const uint32_t a = start[r], b = (r + 1 < nr) ? start[r + 1] : nfin;
-        // thread t fetches the points base + t + kHB j (consecutive threads, consecutive indices).  Every load is unconditional
-        // -- a position past the end of the run reads SOME record of the cloud and is set to zero where it is written to the
-        // LDS -- so that nothing waits for a load before the next one is issued.
+        // loader tl fetches the points base + tl + 128 j of a half (2 048 points) of the 4 096 (consecutive threads, consecutive
+        // indices).  Every load is unconditional -- a position past the end of the run reads SOME record of the cloud and is set
+        // to zero where it is written to the LDS -- so that nothing waits for a load before the next one is issued.
         auto fetch_idx = [&](uint32_t base, uint32_t idx[kHPer]) {
 #pragma unroll
-            for (int j = 0; j < kHPer; ++j) idx[j] = svals[min(base + tid + (uint32_t)kHB * (uint32_t)j, n - 1u)];
+            for (int j = 0; j < kHPer; ++j) idx[j] = svals[min(base + tl + (uint32_t)kHLoaders * (uint32_t)j, n - 1u)];
         };
         auto fetch_recs = [&](const uint32_t idx[kHPer], VoxRaw rec[kHPer]) {
 #pragma unroll
             for (int j = 0; j < kHPer; ++j) rec[j] = vox_load(recs + (size_t)idx[j] * stride, vec);
         };
-        uint32_t idx[kHPer];
-        VoxRaw rec[kHPer];
-        fetch_idx(a, idx);
-        fetch_recs(idx, rec);
-        fetch_idx(a + kHSuper, idx);
-        uint32_t s = 0u;   // (waves 0..5) the wave's component so far: +0.0f
-        for (uint32_t base = a; base < b; base += kHSuper) {
-            __syncthreads();   // (the LDS has been read: the previous 8 192 points, or the previous run's)
+        // (half_no: which half of the 4 096 these records are; base: the run position of the 4 096's first point)
+        auto lay_out = [&](uint32_t lds_half, uint32_t base, uint32_t half_no, const VoxRaw rec[kHPer]) {
 #pragma unroll
             for (int j = 0; j < kHPer; ++j) {
-                const uint32_t e = tid + (uint32_t)kHB * (uint32_t)j;        // point e of these 8 192
+                const uint32_t e = half_no * kHHalf + tl + (uint32_t)kHLoaders * (uint32_t)j;   // point e of these 4 096
                 const uint32_t w = e / kHWin, ew = e % kHWin;                 // window, point of the window: lane ew / 16, its point ew % 16
                 const uint32_t at = (ew % (uint32_t)kHL) * kHPitch + ew / (uint32_t)kHL;
                 const bool in = base + e < b;   // (past the end of the run: +0.0f and a black byte leave every sum as it is)
-                sh[0][w][at] = in ? __float_as_uint(rec[j].x) : 0u;
-                sh[1][w][at] = in ? __float_as_uint(rec[j].y) : 0u;
-                sh[2][w][at] = in ? __float_as_uint(rec[j].z) : 0u;
-                sh[3][w][at] = in ? rec[j].rgb : 0u;
+                sh[lds_half][0][w][at] = in ? __float_as_uint(rec[j].x) : 0u;
+                sh[lds_half][1][w][at] = in ? __float_as_uint(rec[j].y) : 0u;
+                sh[lds_half][2][w][at] = in ? __float_as_uint(rec[j].z) : 0u;
+                sh[lds_half][3][w][at] = in ? rec[j].rgb : 0u;
             }
-            if (base + kHSuper < b) {   // (uniform) the next 8 192 records and the indices of those after them go out now
-                fetch_recs(idx, rec);
-                fetch_idx(base + 2u * kHSuper, idx);
-            }
-            __syncthreads();
-            if (wave < 6u) {
+        };
+        // in flight between two steps: the records of the first half of the next 4 096 (rec) and the indices of their second half (idx_b)
+        uint32_t idx_a[kHPer], idx_b[kHPer];
+        VoxRaw rec[kHPer];
+        __syncthreads();   // (the LDS has been read: the previous run's last points)
+        if (loader) {
+            fetch_idx(a, idx_a);
+            fetch_idx(a + kHHalf, idx_b);
+            fetch_recs(idx_a, rec);
+            fetch_idx(a + kHSuper, idx_a);
+            lay_out(0u, a, 0u, rec);
+            fetch_recs(idx_b, rec);
+            fetch_idx(a + kHSuper + kHHalf, idx_b);
+            lay_out(0u, a, 1u, rec);
+            fetch_recs(idx_a, rec);   // (the first half of the second 4 096; requested even past the end of the run: never laid out then)
+        }
+        __syncthreads();
+        uint32_t s = 0u;   // (waves 0..5) the wave's component so far: +0.0f
+        uint32_t half = 0u;
+        for (uint32_t base = a; base < b; base += kHSuper, half ^= 1u) {
+            if (loader) {
+                if (base + kHSuper < b) {   // the next 4 096 points into the other half of the LDS, beside the sums of this one
+                    const uint32_t nb = base + kHSuper;
+                    lay_out(half ^ 1u, nb, 0u, rec);
+                    fetch_recs(idx_b, rec);              // their second half: waited for below, by these two waves only
+                    fetch_idx(nb + kHSuper, idx_a);
+                    fetch_idx(nb + kHSuper + kHHalf, idx_b);
+                    lay_out(half ^ 1u, nb, 1u, rec);
+                    fetch_recs(idx_a, rec);              // the first half of the 4 096 after them
+                }
+            } else {
                 const uint32_t n_win = min(kHWins, (b - base + kHWin - 1u) / kHWin);
                 for (uint32_t w = 0; w < n_win; ++w) {
                     float t[kHL];
                     if (wave < 3u) {
 #pragma unroll
-                        for (int i = 0; i < kHL; ++i) t[i] = __uint_as_float(sh[wave][w][(uint32_t)i * kHPitch + lane]);
+                        for (int i = 0; i < kHL; ++i) t[i] = __uint_as_float(sh[half][wave][w][(uint32_t)i * kHPitch + lane]);
                         s = h_window<false>(t, s, lane);
                     } else {
                         const uint32_t shift = 8u * (5u - wave);
 #pragma unroll
-                        for (int i = 0; i < kHL; ++i) t[i] = (float)((sh[3][w][(uint32_t)i * kHPitch + lane] >> shift) & 0xffu);
+                        for (int i = 0; i < kHL; ++i) t[i] = (float)((sh[half][3][w][(uint32_t)i * kHPitch + lane] >> shift) & 0xffu);
                         s = h_window<true>(t, s, lane);
                     }
                 }
             }
+            __syncthreads();   // (this half has been summed, the other one is laid out)
         }
-        if (wave < 6u && lane == 0u) sh_s[wave] = s;
+        if (!loader && lane == 0u) sh_s[wave] = s;
         __syncthreads();
         if (tid == 0) {
             float all[7];

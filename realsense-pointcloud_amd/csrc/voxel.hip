@@ -13,8 +13,10 @@
 //     point arrives, i.e. at that point's position in the input; the last run of every slot is
 //     emitted at the end, in slot order;
 //   * a centroid is a float sum in input order divided by the count.
-// So: stable-sort the point indices by slot, cut the runs, let one thread add up each run in
-// order (same float additions as PCL), and sort the runs by their emission position.
+// So: stable-sort the point indices by slot, cut the runs, add up each run in order (same float
+// additions as PCL: a thread per short run, a wave per run of 48 points and more, and for the runs
+// of 1 024 points and more -- PCL's default 1 m leaf -- a workgroup that gets the same bits from a
+// scan of rounding steps, k_vox_huge_runs below), and sort the runs by their emission position.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -172,8 +174,9 @@ __device__ __forceinline__ VoxRaw vox_load(const char *rec, bool vec)
     return r;
 }
 
-// One wave per long run (a 1 m leaf puts 10^4..10^5 points in a run, and the largest run IS the filter's run time: its
-// seven sums are chains of dependent float additions in input order, like PCL's, ~8 cycles a link).  64 lanes fetch 64
+// One wave per long run (48 .. 1 023 points since round 6; longer ones go to k_vox_huge_runs: a 1 m leaf puts 10^4..10^5
+// points in a run, and such a run WAS the filter's run time here: its seven sums are chains of dependent float additions in
+// input order, like PCL's, ~8 cycles a link).  64 lanes fetch 64
 // points at a time and pass them through LDS (component-major); lanes 0..6 each add one component in input order.
 // Nothing but the chain may be on the critical path: the point indices are fetched eight chunks ahead and the records
 // four chunks ahead (a gather from HBM takes longer than four chunks of additions), and chunk k + 1 is written to the
@@ -289,8 +292,9 @@ __global__ __launch_bounds__(kVBlock) void k_vox_long_runs(const char *recs, siz
 // 1 024 points, every wave at its own pace: no wave waits for another's rounds, and the gathers are issued beside the rounds,
 // not in front of them (with all eight waves fetching 8 192 points and then six of them summing, a quarter of the kernel was
 // issuing loads: 63 -> 49 us for the runs of a 307 k frame; the two fetching waves are now what a step waits for -- they hold
-// 222 registers for sixteen records in flight a lane, and a second set would spill).  (PCL also accumulates the rgb word read as a float -- usually a NaN -- and never reads it back: the
-// centroid's fourth component is not part of the output record, and this kernel leaves it out.)
+// 222 registers for sixteen records in flight a lane, and a second set would spill).  (PCL also accumulates the rgb word read
+// as a float -- usually a NaN -- and never reads it back: the centroid's fourth component is not part of the output record, and
+// this kernel leaves it out.)
 constexpr int kHB = 512;                          // threads of a workgroup
 constexpr int kHL = 16;                           // points of a lane in a window
 constexpr uint32_t kHWin = 64u * kHL;             // points of a window (one wave, one round at least)

@@ -106,7 +106,8 @@ inline void stream_copy(void *dst_, const void *src_, size_t bytes)
 
 // Host-side record loops (32-byte records <-> packed xyz in pinned staging, staging <-> the caller's memory) are memory-bound
 // copies of tens of MB that want a handful of cores for a fraction of a millisecond: the threads are kept (starting eight
-// threads costs as much as the copy they are started for).  One loop at a time, process-wide; the caller's thread works too.
+// threads costs as much as the copy they are started for).  One loop at a time per pool (host_pool() below is the process-wide one,
+// the download worker keeps small ones of its own); the caller's thread works too.
 struct HostPool {
     std::vector<std::thread> th;
     std::mutex m, call_m;

@@ -633,6 +633,40 @@ def test_edge_features_and_filter_queued_on_the_side_worker(api, rs):
     assert L.rsreg_cloud_edge_features_async(other.h, unorganized.h, out.h) == lib.RSREG_ERR_INVALID_ARG
 
 
+@pytest.mark.parametrize("one_worker", ["0", "1"])
+def test_side_jobs_on_two_workers_and_on_one_give_the_synchronous_results(api, rs, monkeypatch, one_worker):
+    """Round 6: the side jobs of a context alternate between two worker threads (two scratch sets and streams each); a job
+    whose input is the output of a job still queued follows it on the same worker.  Twelve frames' extractions, each with
+    two filters chained on it (one more than a worker has sets), all queued before anything is asked for: the records of
+    the synchronous calls, on two workers (default) and on one (RSREG_ONE_SIDE_WORKER=1)."""
+    monkeypatch.setenv("RSREG_ONE_SIDE_WORKER", one_worker)
+    ctx = api.Context(0)   # (a context looks at the environment when it is created)
+    frames = [rs.synth.render_frame(k, "50k", "bench") for k in range(12)]
+    leaves = (np.array([0.01, 0.01, 0.01], np.float32), np.array([0.05, 0.04, 0.03], np.float32))
+
+    def filt(cloud, leaf, queued):
+        v = api.ApproximateVoxelGrid(ctx)
+        v.setLeafSize(*leaf)
+        v.setInputCloud(cloud)
+        return v.filter_async() if queued else v.filter()
+
+    want = []
+    for f in frames:
+        e = api.extract_edge_features(api.DeviceCloud(f, ctx))
+        want.append((e.download(), filt(e, leaves[0], False).download(), filt(e, leaves[1], False).download()))
+    queued = []
+    for f in frames:
+        d = api.DeviceCloud(ctx=ctx).upload_deferred(f)
+        e = api.extract_edge_features_async(d)
+        queued.append((d, e, filt(e, leaves[0], True), filt(e, leaves[1], True)))
+    for k in (5, 0, 11, 3, 8, 1, 10, 2, 9, 4, 7, 6):
+        _, e, r0, r1 = queued[k]
+        _same_records(r1.download(), want[k][2])
+        _same_records(e.download(), want[k][0])
+        _same_records(r0.download(), want[k][1])
+    monkeypatch.delenv("RSREG_ONE_SIDE_WORKER")
+
+
 def test_contexts_and_clouds_go_away_with_work_of_their_helper_threads_in_flight(api, rs):
     """A context owns helper threads (uploads, downloads, side jobs, source loads).  Dropping clouds, and closing the
     context, right after work has been handed to them must neither hang nor crash, whatever is still queued; a context

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -409,6 +410,7 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     {
         if (!dsource_ || !dtarget_) throw Error(RSREG_ERR_INVALID_ARG, "rsreg: setInputSource / setInputTarget (device clouds) not called");
         rsreg_ctx *c = ctx_->get();
+        const auto t0 = std::chrono::steady_clock::now();
         // a device cloud rewritten in place since it was loaded (filter(x, x), +=, a transform or an alignment into it) is
         // loaded again: PCL would see the new points through its pointer
         if (!source_dirty_ && cloud_stamp(dsource_->handle()) != source_stamp_) source_dirty_ = true;
@@ -419,6 +421,7 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
             source_dirty_ = false;
             ctx_->icp_source_owner = this;
         }
+        t1_ = std::chrono::steady_clock::now();
         if (target_dirty_ || ctx_->icp_target_owner != this) {
             if (!(reuse_target_index_ && rsreg_icp_target_is_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance)))
                 check(rsreg_icp_set_target_cloud(c, dtarget_->handle(), prm_.max_correspondence_distance), c);
@@ -426,9 +429,17 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
             target_dirty_ = false;
             ctx_->icp_target_owner = this;
         }
+        const auto t2 = std::chrono::steady_clock::now();
         check(rsreg_icp_align_cloud(c, guess.data(), &prm_, &res_, output.handle()), c);
         std::memcpy(final_.m, res_.transform, sizeof(final_.m));
+        const auto t3 = std::chrono::steady_clock::now();
+        call_ms[0] += std::chrono::duration<double, std::milli>(t1_ - t0).count();
+        call_ms[1] += std::chrono::duration<double, std::milli>(t2 - t1_).count();
+        call_ms[2] += std::chrono::duration<double, std::milli>(t3 - t2).count();
     }
+    // engine extra: host time of the device-cloud align() calls so far, in ms -- [0] loading the source (and waiting for whatever
+    // still makes it), [1] the target's index, [2] the alignment itself
+    double call_ms[3] = {0, 0, 0};
     bool hasConverged() const { return res_.converged != 0; }
     Matrix4f getFinalTransformation() const { return final_; }
     int getConvergenceState() const { return res_.state; }
@@ -445,6 +456,7 @@ template <typename PointSource, typename PointTarget> class IterativeClosestPoin
     const DeviceCloud<PointTarget> *dtarget_ = nullptr;
     bool source_dirty_ = true, target_dirty_ = true, reuse_target_index_ = false;
     std::pair<uint64_t, uint64_t> source_stamp_{0, 0}, target_stamp_{0, 0};   // (id, version) of the device clouds as loaded
+    std::chrono::steady_clock::time_point t1_;
 };
 
 // ---- pcl::NormalDistributionsTransform

@@ -577,6 +577,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         // frames only: the features of the next kAhead frames are extracted and voxel-filtered (a thread, streams and scratch of the
         // context's own) while frame k goes through its two alignments here, and frame k + kAhead + 1 is on the PCIe link: the
         // reference extracts all features before it registers anything (types.hpp:30-43), none depends on a registration
+        // (kAhead = 3, end of round 6: the coarse ICP waits 0.02 ms a frame for its source instead of 0.07, and the loops are no
+        //  faster -- ICP-edge level, NDT-edge 1-2 ms slower with more side work beside its passes)
         constexpr size_t kAhead = 2, kFulls = kAhead + 2, kFeat = kAhead + 1;
         rgb_device_cloud target, merged, fulls[kFulls], features_of[kFeat], reduced_of[kFeat], coarse_out, refined, moved;   // (inputs of queued jobs outlive their outputs)
         auto prepare = [&](size_t k) {
@@ -601,6 +603,8 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
         if (byproducts_on()) save_edge(0, target);   // (the reference writes all edge-k.pcd before the loop; the files are the same)
         float acc_rads = 0.f;
         frame_transforms.clear();
+        double coarse0[3];
+        coarse_call_ms(coarse0);
         clock_mark();
         for (size_t k = 1; k < n_frames; ++k, clock_mark()) {
             rgb_device_cloud &full = fulls[k % kFulls], &features = features_of[k % kFeat], &reduced = reduced_of[k % kFeat];
@@ -647,6 +651,11 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
             else { target.download(grown); save_edge_cloud(grown); }
         }
         say("[PCL] Done");
+        {   // (stage_ms[5..7]: the coarse ICP's share of stage_ms[1], call by call -- its source, the target's index, the alignment)
+            double c1[3];
+            coarse_call_ms(c1);
+            for (int q = 0; q < 3; ++q) stage_ms[5 + q] = c1[q] - coarse0[q];
+        }
         auto out = std::make_shared<rgb_point_cloud>();
         if (result) { result->finish(*out); note_finish(*result); }
         else merged.download(*out);
@@ -709,6 +718,7 @@ class EdgeBasedRegistrationBase : public TwoPhaseRegistrationScheme {
     virtual void configure_coarse() = 0;
     virtual Matrix4f coarse_align(const rgb_point_cloud_pointer &src, const rgb_point_cloud_pointer &tgt, rgb_point_cloud &out,
                                   const Matrix4f &guess) = 0;
+    virtual void coarse_call_ms(double out[3]) const { out[0] = out[1] = out[2] = 0; }   // (engine extra: IterativeClosestPoint::call_ms of the coarse ICP)
     virtual Matrix4f coarse_align_device(const rgb_device_cloud &src, const rgb_device_cloud &tgt, rgb_device_cloud &out,
                                          const Matrix4f &guess) = 0;
     virtual Matrix4f imu_guess(const float3 &theta) const = 0;
@@ -740,6 +750,7 @@ class ICPEdgeBasedRegistration : public EdgeBasedRegistrationBase {
         coarse_.align(out, guess);
         return coarse_.getFinalTransformation();
     }
+    void coarse_call_ms(double out[3]) const override { for (int k = 0; k < 3; ++k) out[k] = coarse_.call_ms[k]; }
     // AngleAxis(theta.x, Z) * AngleAxis(-theta.y, Y) * AngleAxis(theta.z, X), no translation
     Matrix4f imu_guess(const float3 &t) const override
     {

@@ -101,7 +101,7 @@ int main(int argc, char **argv)
                 stop();
                 frame_clock = s.frame_clock_ms;
                 for (int q = 0; q < 4; ++q) finish_ms[q] = s.stream_finish_ms[q];
-                stages.assign(s.stage_ms, s.stage_ms + 5);
+                stages.assign(s.stage_ms, s.stage_ms + 8);
             } else if (mode == "ndt_edge") {
                 NDTEdgeBasedRegistration s(-0.0261799f);
                 s.device_resident = !host_loop_t;
@@ -110,7 +110,7 @@ int main(int argc, char **argv)
                 stop();
                 frame_clock = s.frame_clock_ms;
                 for (int q = 0; q < 4; ++q) finish_ms[q] = s.stream_finish_ms[q];
-                stages.assign(s.stage_ms, s.stage_ms + 5);
+                stages.assign(s.stage_ms, s.stage_ms + 8);
             } else if (mode == "chain") {
                 // (the registrar lives across the repetitions, like a long-running caller's: run 0 pays for its contexts)
                 if (!chain) chain.reset(new ChainRegistrar(chain_in_flight));
@@ -132,9 +132,9 @@ int main(int argc, char **argv)
                 std::fprintf(stderr, "%s run %d frames: set-up %.2f |", mode.c_str(), rep, frame_clock[0]);
                 for (size_t k = 1; k + 1 < frame_clock.size(); ++k) std::fprintf(stderr, " %.2f", frame_clock[k] - frame_clock[k - 1]);
                 std::fprintf(stderr, " | merged cloud complete + %.2f (waited %.2f for frame 0's copy, %.2f for the downloads under way; handing the records over %.2f)\n", frame_clock.back() - frame_clock[frame_clock.size() - 2], finish_ms[0], finish_ms[1], finish_ms[3]);
-                if (stages.size() == 5) {   // (the edge schemes: the caller's thread, call by call, over all frames -- schemes.hpp: stage_ms)
-                    std::fprintf(stderr, "%s run %d calls: frames ahead queued %.2f | coarse alignment %.2f | refining ICP %.2f | transforms, grown target %.2f | result download queued %.2f ms\n",
-                                 mode.c_str(), rep, stages[0], stages[1], stages[2], stages[3], stages[4]);
+                if (stages.size() == 8) {   // (the edge schemes: the caller's thread, call by call, over all frames -- schemes.hpp: stage_ms)
+                    std::fprintf(stderr, "%s run %d calls: frames ahead queued %.2f | coarse alignment %.2f | refining ICP %.2f | transforms, grown target %.2f | result download queued %.2f ms  (coarse ICP: its source %.2f, the target's index %.2f, the alignment %.2f)\n",
+                                 mode.c_str(), rep, stages[0], stages[1], stages[2], stages[3], stages[4], stages[5], stages[6], stages[7]);
                 } else if (!stages.empty()) {   // (IncrementalICP: the caller's thread, call by call, over all frames -- schemes.hpp: stage_ms)
                     std::fprintf(stderr, "%s run %d calls: frames ahead queued %.2f | setInputSource %.2f | setInputTarget %.2f | align %.2f | transformPointCloud %.2f | += %.2f | result download queued %.2f ms\n",
                                  mode.c_str(), rep, stages[0], stages[1], stages[2], stages[3], stages[4], stages[5], stages[6]);

@@ -270,7 +270,11 @@ bool count_sort_pays(size_t n, size_t total)
     return tunables().count_sort && total <= std::max<size_t>(32 * n, (size_t)16 << 20) && total < (1ull << 31);
 }
 
-int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin)
+// sources up to this many points (the one-launch load's limit, kPlainSourceMax below) make their target's counting build leave
+// the occupancy words out when the gate fits into ring 1
+constexpr size_t kSmallSourceForTable = 65536;
+
+int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, double max_dist, uint32_t nfin, bool with_nbr)
 {
     hipStream_t st = ctx->stream;
     GridParams &gp = ctx->grid;
@@ -301,8 +305,11 @@ int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stri
     ctx->cnt_flip = !ctx->cnt_flip;
     const uint32_t count_blocks = div_up((uint32_t)n, kCcTile);
     // the occupancy words are cleared by the counting kernel on its way, unless that would be more than 64 words a thread
-    const bool occ_on_the_way = (total + 2) <= 64ull * count_blocks * kCcBlock;
-    if (!occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(occ, 0, (total + 2) * 4, st));
+    // (with_nbr false: an index without the words -- a small source's searches read them off the table, icp_dense.hpp:
+    //  dense_occ_from_table; for a sparse cloud the words were half the build: 18 scattered atomics per occupied cell and a
+    //  table's worth of zeroes)
+    const bool occ_on_the_way = with_nbr && (total + 2) <= 64ull * count_blocks * kCcBlock;
+    if (with_nbr && !occ_on_the_way) RSREG_HIP(ctx, hipMemsetAsync(occ, 0, (total + 2) * 4, st));
     k_cc_count<<<count_blocks, kCcBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, cnt, rank, coarse, span, occ_on_the_way ? occ : nullptr,
                                                    occ_on_the_way ? (uint32_t)(total + 2) : 0u, reinterpret_cast<uint32_t *>(coarse_next), 2u * kCcMaxSpans, stats);
     RSREG_HIP(ctx, hipGetLastError());
@@ -311,10 +318,13 @@ int build_dense_counted(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stri
     const uint32_t nbf = div_up(nfin, kBlock), scatter_blocks = div_up((uint32_t)n, kBlock);
     // (one wave per crowded cell, the waves of the grid in turn; the grid covers every cell a cloud of nfin points can crowd)
     const uint32_t big_blocks = std::max(1u, std::min(div_up(nfin / (kCcSmall + 1u) + 1u, kBlock / 64), 2048u));
-    if (!tunables().cc_apart) {
+    if (!tunables().cc_apart || !with_nbr) {
         // four dependent launches: scatter + occupancy words side by side (both need the scan only), then the in-cell order of the
         // small and of the crowded cells side by side
-        k_cc_scatter_nbr<<<nbf + scatter_blocks, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>(), nbf, cellslot, stats, occ);
+        if (with_nbr)
+            k_cc_scatter_nbr<<<nbf + scatter_blocks, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>(), nbf, cellslot, stats, occ);
+        else
+            k_cc_scatter<<<scatter_blocks, kBlock, 0, st>>>(d_pts, stride, (uint32_t)n, g, rank, table, ctx->d_arrived.as<float4>());
         RSREG_HIP(ctx, hipGetLastError());
         k_cc_small_big<<<big_blocks + nbf, kBlock, 0, st>>>(ctx->d_arrived.as<float4>(), g, table, big, ctx->d_tgt_sorted.as<float4>(), ctx->d_pos_of.as<uint32_t>(), stats,
                                                             big_blocks);
@@ -382,7 +392,11 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
     if (counted) {
         gp.xbits = (int)kCcXBits;   // what the crowded cells are ordered by (g.x_slack follows)
         gp.table_sparse = 0;        // every table entry is written
-        int rc = build_dense_counted(ctx, d_pts, n, stride, max_dist, nfin);
+        // a small source already loaded (the reference sets the source first: incremental_icp.hpp:57-58) and a gate inside
+        // ring 1: no occupancy words -- every launch over this index then takes the instantiation that reads them off the table
+        const bool small_source = ctx->have_source && ctx->n_source > 0 && ctx->n_source <= kSmallSourceForTable;
+        gp.have_nbr = !(small_source && gp.max_ring <= 1 && tunables().nbr_from_table) ? 1 : 0;
+        int rc = build_dense_counted(ctx, d_pts, n, stride, max_dist, nfin, gp.have_nbr != 0);
         if (rc) return rc;
         if (ctx->profiling) (void)hipEventRecord(ev1, st);
         // the build is queued, not waited for: the searches bound the record array by the number of finite points (the sorted
@@ -401,6 +415,7 @@ int build_dense(rsreg_ctx *ctx, const char *d_pts, size_t n, size_t stride, doub
             if (rcc) return rcc;
         }
     } else {
+        gp.have_nbr = 1;
         int rc = narrow ? build_dense_keyed<uint32_t>(ctx, d_pts, n, stride, max_dist, nfin, id_bits)
                         : build_dense_keyed<unsigned long long>(ctx, d_pts, n, stride, max_dist, nfin, id_bits);
         if (rc) return rc;
@@ -1114,7 +1129,7 @@ int launch_search(rsreg_ctx *ctx)
             k_scan_finish<<<1, kScanMaxSource, 0, ctx->stream>>>(keys, ctx->d_cur.as<float4>(), n, ctx->d_corr_pos.as<int>(),
                                                                 ctx->d_corr_d2.as<float>());
         } else if (ctx->grid.dense)
-            k_nn_search_dense<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n,
+            (ctx->grid.have_nbr ? k_nn_search_dense<0> : k_nn_search_dense<3>)<<<div_up(n, kBlock), kBlock, 0, ctx->stream>>>(ctx->d_cur.as<float4>(), n,
                                                                              dense_dev(ctx, s.prm.max_correspondence_distance), gate2,
                                                                              ctx->d_corr_pos.as<int>(), ctx->d_corr_d2.as<float>(),
                                                                              seed_ptr(ctx));
@@ -1442,12 +1457,13 @@ int launch_fused(rsreg_ctx *ctx, double *sums, bool want_corr, bool device_loop 
             const bool blocks = ctx->grid.max_ring <= 4 && !tunables().far_rows;
 #ifdef RSREG_DIAG
             const bool light = tunables().wave_times_light;
-            auto kern = wt ? (light ? (blocks ? k_icp_fused_dense<2, 1> : k_icp_fused_dense<2, 2>)
-                                    : (blocks ? k_icp_fused_dense<1, 1> : k_icp_fused_dense<1, 2>))
-                           : (blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>);
+            const bool tab = !ctx->grid.have_nbr;   // (an index without occupancy words: read off the table)
+            auto kern = wt ? (light ? (tab ? k_icp_fused_dense<2, 3> : blocks ? k_icp_fused_dense<2, 1> : k_icp_fused_dense<2, 2>)
+                                    : (tab ? k_icp_fused_dense<1, 3> : blocks ? k_icp_fused_dense<1, 1> : k_icp_fused_dense<1, 2>))
+                           : (tab ? k_icp_fused_dense<0, 3> : blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>);
 #else
             const bool light = false;
-            auto kern = blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>;
+            auto kern = !ctx->grid.have_nbr ? k_icp_fused_dense<0, 3> : blocks ? k_icp_fused_dense<0, 1> : k_icp_fused_dense<0, 2>;
 #endif
             const SchedCfg cfg = sched_cfg();
             const uint32_t n_tiles = reduce_blocks(n);

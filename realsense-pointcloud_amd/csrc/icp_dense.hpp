@@ -477,8 +477,29 @@ struct DRing1 {
     bool right_half;
 };
 
+// The occupancy word of a cell's 27-cell neighbourhood read off the cell table itself -- for an index built WITHOUT the words
+// (icp.hip: build_dense_counted for a small source; the table of a counting build has an entry for every cell of the padded
+// grid, and a cell holds points exactly when the entry behind it is larger): nine 16-byte loads, one per (y, z) row, entries
+// x - 1 .. x + 2, instead of one word that cost the build 18 scattered atomics per occupied cell of a sparse cloud.  The
+// own cell's range is the middle row's middle pair: that row is read with the first loads of a search, the other eight only
+// by the queries that have to open ring 1 at all.
+__device__ __forceinline__ uint32_t dense_occ_bits(const u32x4 &t) { return ((t.y > t.x) ? 1u : 0u) | ((t.z > t.y) ? 2u : 0u) | ((t.w > t.z) ? 4u : 0u); }
+__device__ __forceinline__ uint32_t dense_occ_from_table(const DenseDev &g, const DRes &rs, int base, uint32_t middle)
+{
+    uint32_t occ = middle << 12;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (r == 4) continue;
+        const int dz = r / 3, dy = r % 3;
+        const int row = base + (dz - 1) * g.sxy + (dy - 1) * g.sx - 1;   // the entry of the cell at x - 1 of that row
+        occ |= dense_occ_bits(__builtin_amdgcn_raw_buffer_load_b128(rs.tab, (uint32_t)row * 4u, 0, 0)) << (3 * r);
+    }
+    return occ;
+}
+
 // ring 0: the seed and the query's own cell (it usually holds the nearest point), then which neighbours have to be opened
-template <bool kDiag = false>
+// (kOccTab: the occupancy word comes from the table, above)
+template <bool kDiag = false, bool kOccTab = false>
 __device__ __forceinline__ uint32_t dense_own(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b, float &limit2,
                                               DSplit sp, DRing1 &r1, DDiag *dg = nullptr)
 {
@@ -488,11 +509,20 @@ __device__ __forceinline__ uint32_t dense_own(const DenseDev &g, const DRes &rs,
     const int base = (int)dense_cell_id(g, q.cx, q.cy, q.cz);
     // the three first loads (neighbourhood word, own cell's range, the seed point) go out together:
     // a search is a chain of dependent loads, and every round trip saved shortens the slowest waves
-    const uint32_t occ = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
-    u32x2 se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
-    dense_seed(rs, q, seed_pos, b, limit2);
-    // (an empty cell's table entry may be left over from an earlier build: k_dense_scatter writes occupied cells only)
-    if (!(occ & (1u << 13))) se = u32x2{0u, 0u};
+    uint32_t occ;
+    u32x2 se;
+    if (kOccTab) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs.tab, (uint32_t)(base - 1) * 4u, 0, 0);   // entries x - 1 .. x + 2 of the own row
+        dense_seed(rs, q, seed_pos, b, limit2);
+        se = u32x2{t.y, t.z};
+        occ = dense_occ_bits(t) << 12;   // (the own row's three bits: 12, 13, 14)
+    } else {
+        occ = __builtin_amdgcn_raw_buffer_load_b32(rs.nbr, (uint32_t)base * 4u, 0, 0);
+        se = __builtin_amdgcn_raw_buffer_load_b64(rs.tab, (uint32_t)base * 4u, 0, 0);
+        dense_seed(rs, q, seed_pos, b, limit2);
+        // (an empty cell's table entry may be left over from an earlier build: k_dense_scatter writes occupied cells only)
+        if (!(occ & (1u << 13))) se = u32x2{0u, 0u};
+    }
     const float x_slack = g.x_slack;
     const bool right_half = (q.ux - (float)q.cx) >= 0.5f;   // the query sits in the right half of its cell column
     DWalk w;
@@ -518,6 +548,10 @@ __device__ __forceinline__ uint32_t dense_own(const DenseDev &g, const DRes &rs,
 #ifdef RSREG_DIAG
     if (g.debug_skip & 2u) return occ;
 #endif
+    if (kOccTab) {
+        if (!any_face) return occ;
+        occ = dense_occ_from_table(g, rs, base, occ >> 12);
+    }
     if (!any_face || !(occ & ~(1u << 13))) return occ;
     uint32_t mask = 0;   // bit j = dz*9 + dy*3 + dx (offsets 0..2), centre excluded
 #pragma unroll
@@ -578,12 +612,12 @@ __device__ __forceinline__ void dense_ring1_lane(const DenseDev &g, const DRes &
 }
 
 // rings 0 and 1; returns the occupancy word of the query's 27-cell neighbourhood
-template <bool kDiag = false>
+template <bool kDiag = false, bool kOccTab = false>
 __device__ __forceinline__ uint32_t dense_near(const DenseDev &g, const DRes &rs, const DQuery &q, int seed_pos, DBest &b,
                                                float &limit2, DSplit sp, DDiag *dg = nullptr)
 {
     DRing1 r1;
-    const uint32_t occ = dense_own<kDiag>(g, rs, q, seed_pos, b, limit2, sp, r1, dg);
+    const uint32_t occ = dense_own<kDiag, kOccTab>(g, rs, q, seed_pos, b, limit2, sp, r1, dg);
     dense_ring1_lane<kDiag>(g, rs, q, r1, r1.mask, b, limit2, sp, dg);
     return occ;
 }
@@ -776,7 +810,8 @@ __device__ __forceinline__ Best dense_result(const DenseDev &g, const DBest &b)
 
 // Exact nearest neighbour within the gate over the dense table (same contract as nn_query).
 // kFar: which search beyond ring 1 is compiled in -- 0: both, chosen by the grid (max_ring <= 4: blocks); 1: blocks only
-// (the caller knows max_ring <= 4); 2: rows only
+// (the caller knows max_ring <= 4); 2: rows only; 3: none, and the index has no occupancy words (the caller knows max_ring
+// <= 1: the gate fits into ring 1; the words are read off the table, dense_occ_from_table)
 template <bool kDiag = false, int kFar = 0>
 __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, float qy, float qz, int seed_pos, DDiag *dg = nullptr,
                                                DSplit sp = DSplit{0u, 0u})
@@ -786,9 +821,9 @@ __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, floa
     const DQuery q = dense_query(g, qx, qy, qz);
     float limit2 = g.prune2;
     DBest b{__uint_as_float(0x7f800000u), 0xffffffffu};
-    dense_near<kDiag>(g, rs, q, seed_pos, b, limit2, sp, dg);
+    dense_near<kDiag, kFar == 3>(g, rs, q, seed_pos, b, limit2, sp, dg);
     if (kDiag) dg->t_near = wall_clock64();
-    const bool far = dense_needs_far(g, limit2);
+    const bool far = kFar != 3 && dense_needs_far(g, limit2);
     if (far) {
         if (kFar == 1 || (kFar == 0 && g.max_ring <= 4)) dense_far_blocks<kDiag>(g, rs, q, b, limit2, sp, dg);
         else dense_far<kDiag>(g, rs, q, b, limit2, sp, dg);
@@ -804,6 +839,7 @@ __device__ __forceinline__ Best nn_query_dense(const DenseDev &g, float qx, floa
     return dense_result(g, b);
 }
 
+template <int kFar = 0>
 __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, uint32_t n, DenseDev g, double gate2,
                                                             int *corr_pos, float *corr_d2, int *seed)
 {
@@ -813,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_search_dense(const float4 *cur, u
     int pos = -1;
     float d2 = 0.0f;
     if (q.w != 0.0f) {
-        const Best b = nn_query_dense(g, q.x, q.y, q.z, seed ? seed[i] : -1);
+        const Best b = nn_query_dense<false, kFar>(g, q.x, q.y, q.z, seed ? seed[i] : -1);
         if (seed) seed[i] = b.pos;
         if (b.pos >= 0 && !((double)b.d2 > gate2)) {  // PCL: if (distance > max_dist_sqr) continue;
             pos = b.pos;

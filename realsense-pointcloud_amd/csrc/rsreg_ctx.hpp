@@ -161,6 +161,7 @@ struct GridParams {
     int dense;             // 1: dense cell-start table (d_dense), 0: brick hash (d_table + d_cellpos), 2: no index (scan_target)
     int xbits;             // dense: bits of the x position inside a cell in the sort key (16, or what a 32-bit key leaves)
     int table_sparse;      // dense: only the table entries of occupied cells (and the slot behind each) are valid
+    int have_nbr;          // dense: the neighbourhood occupancy words are built (0: a counting build for a small source left them out, icp.hip)
 };
 
 struct BrickEntry {          // 32 B, one hash-table slot

@@ -28,6 +28,7 @@ struct Tunables {
     bool box_cache = true;                 // RSREG_NO_BOX_CACHE=1: a cloud handle's bounding box is measured by every build / load
     bool count_sort = true;                // RSREG_COUNT_SORT=0: the index by sorting (k_dense_keys, radix sort, k_dense_compact) instead of counting (cellsort.hpp)
     bool one_side_worker = false;          // RSREG_ONE_SIDE_WORKER=1: the side jobs of a context (filters, edge extractions of the frames ahead) on one thread as in rounds 3-5 (default: two, alternating)
+    bool nbr_from_table = true;            // RSREG_NO_NBR_FROM_TABLE=1: the counting build makes the occupancy words for a small source too (default: left out when the gate fits into ring 1, the search reads them off the cell table)
     bool cc_apart = false;                 // RSREG_CC_APART=1: the counting build's scatter / occupancy words / small cells / crowded cells as four launches (rounds 5; default: two)
     bool scan_apart = false;               // RSREG_SCAN_APART=1: sort-based build: flag, scan, scatter as three launches
     // ---- source
@@ -76,6 +77,7 @@ inline Tunables tunables_from_environment()
     v.box_cache = !on("RSREG_NO_BOX_CACHE");
     v.count_sort = !off("RSREG_COUNT_SORT");
     v.cc_apart = on("RSREG_CC_APART");
+    v.nbr_from_table = !on("RSREG_NO_NBR_FROM_TABLE");
     v.one_side_worker = on("RSREG_ONE_SIDE_WORKER");
     v.scan_apart = on("RSREG_SCAN_APART");
     v.sort_small = on("RSREG_SORT_SMALL");

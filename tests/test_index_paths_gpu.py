@@ -18,8 +18,13 @@ pytestmark = pytest.mark.gpu
                                  # round 6: the sort-based builds run on the library's own 64-bit radix sort and prefix sums
                                  # (csrc/osort.hpp, csrc/oscan.hpp; rocPRIM's until then)
                                  {"RSREG_COUNT_SORT": "0", "RSREG_KEYS64": "1"},
-                                 {"RSREG_COUNT_SORT": "0", "RSREG_SCAN_APART": "1", "RSREG_FULL_TABLE": "1"}],
-                         ids=["brick-hash", "dense-only-when-small", "sorted-build-64-bit-keys", "sorted-build-scans-apart-full-table"])
+                                 {"RSREG_COUNT_SORT": "0", "RSREG_SCAN_APART": "1", "RSREG_FULL_TABLE": "1"},
+                                 # round 6 (end): the counting build leaves the occupancy words out for a small source whose gate fits into
+                                 # ring 1 and the search reads them off the cell table (the default; the suite's 50 k clouds take it) --
+                                 # here: the words built for every source, as until then
+                                 {"RSREG_NO_NBR_FROM_TABLE": "1"}],
+                         ids=["brick-hash", "dense-only-when-small", "sorted-build-64-bit-keys", "sorted-build-scans-apart-full-table",
+                              "occupancy-words-for-small-sources-too"])
 def test_parity_suite_on_alternative_index_paths(env):
     e = dict(os.environ)
     e.update(env)
@@ -65,3 +70,49 @@ print("hash index intact")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSREG_FORCE_HASH="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert r.returncode == 0 and "hash index intact" in r.stdout, r.stderr[-3000:]
+
+
+def test_search_without_occupancy_words_gives_the_matches_of_the_search_with_them(tmp_path):
+    """The same pairs with the occupancy words built (RSREG_NO_NBR_FROM_TABLE=1) and read off the table (default for a source of
+    at most 65 536 points and a gate inside ring 1): every match index and squared distance, the sums and the transform bit for
+    bit -- on a dense pair, on a sparse edge-like pair (lone cells: most neighbours empty) and with queries outside the target's
+    box (border cells of the padded table)."""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import rsreg_amd
+from rsreg_amd import api, synth
+import rsreg_amd as rs
+out = []
+def pair(src, tgt, gate, guess=None):
+    icp = api.IterativeClosestPoint(api.Context(0))
+    icp.setMaxCorrespondenceDistance(gate)
+    icp.setMaximumIterations(3)
+    icp.setTransformationEpsilon(0)
+    icp.setEuclideanFitnessEpsilon(0)
+    icp.setInputSource(src)
+    icp.setInputTarget(tgt)
+    al = icp.align(guess)
+    r = icp.result
+    out.append((bytes(r.transform), r.n_correspondences, r.iterations, np.stack([al.points[k] for k in "xyz"]).tobytes(), bytes(memoryview(np.array(r.sums_last)))))
+a, b = synth.render_frame(0, "50k", "parity"), synth.render_frame(1, "50k", "parity")
+pair(b, a, 0.01)
+pair(b, a, 0.02, synth.small_transform(1.0, (0.01, -0.02, 0.015)).astype(np.float32))
+e0 = rs.PointCloud(np.ascontiguousarray(a.points[::7]))      # sparse: lone cells
+e1 = rs.PointCloud(np.ascontiguousarray(b.points[3::11]))
+pair(e1, e0, 0.01)
+far = rs.PointCloud(b.points.copy())
+far.points["x"] += 0.8                                        # half of the queries outside the target's box
+far.points["z"] -= 0.5
+pair(far, a, 0.015)
+import hashlib
+print("digest", hashlib.sha256(b"".join(x[0] + x[3] + x[4] + bytes([x[2]]) + x[1].to_bytes(8, "little") for x in out)).hexdigest(), [x[1] for x in out])
+''' % ROOT
+    res = []
+    for words in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSREG_NO_NBR_FROM_TABLE=words), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stderr[-3000:]
+        res.append([l for l in r.stdout.splitlines() if l.startswith("digest")][0])
+    assert res[0] == res[1], res
+    assert "[0, 0, 0, 0]" not in res[0]
